@@ -1,0 +1,177 @@
+/* ark355.h -- C ABI of libark355.so, the MI355X (gfx950) Groth16 prover backend.
+ *
+ * This is the drop-in boundary for the hot path of `ark_snark::SNARK::prove`
+ * (/root/reference/snark/src/lib.rs:50-54): the Rust host keeps `ark-relations`' ConstraintSystem
+ * (/root/reference/relations/src/gr1cs/constraint_system.rs) untouched, extracts
+ *   - the R1CS matrices once per circuit   (to_matrices, constraint_system.rs:768-774;
+ *                                           Matrix<F> = Vec<Vec<(F, usize)>>, utils/matrix.rs:4)
+ *   - the full assignment z per proof      (instance_assignment || witness_assignment,
+ *                                           constraint_system.rs:193-206, assignment.rs:11-21)
+ * and calls the entry points below; see INTEGRATION.md for the Rust `extern "C"` block.
+ *
+ * Conventions:
+ *  - every function returns int32: 0 = OK, negative = error (no exception crosses the boundary);
+ *  - field elements are ark-ff memory images: little-endian u64 limbs, MONTGOMERY form
+ *    (Fr: 32 B; Fq: 48 B BLS12-381 / 32 B BN254).  MSM scalars and r, s are CANONICAL
+ *    (`into_bigint`) 32-byte little-endian integers;
+ *  - G1 affine = x || y ; G2 affine = x.c0 || x.c1 || y.c0 || y.c1 ; the point at infinity is the
+ *    all-zero encoding (the shim maps `Affine::infinity == true` to zeros and back);
+ *  - the caller owns all host buffers; the library copies during the call and never retains host
+ *    pointers.  Handles are opaque and freed by the matching *_free / *_destroy;
+ *  - `*_dev` variants take DEVICE pointers (HIP allocations of the calling process) and a HIP
+ *    stream (void*, may be NULL for the context's own stream).
+ */
+#ifndef ARK355_H
+#define ARK355_H
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ark355_ctx ark355_ctx;
+typedef struct ark355_pk ark355_pk;
+typedef struct ark355_r1cs ark355_r1cs;
+
+enum { ARK355_BLS12_381 = 0, ARK355_BN254 = 1 };
+
+/* error codes; the -16.. block mirrors ark_relations SynthesisError (utils/error.rs:5-21) */
+enum {
+  ARK355_OK = 0,
+  ARK355_EINVAL = -1,
+  ARK355_ENOMEM = -2,
+  ARK355_EHIP = -3,
+  ARK355_ERCCL = -4,
+  ARK355_ENODEV = -5,
+  ARK355_E_ASSIGNMENT_MISSING = -16,      /* SynthesisError::AssignmentMissing        (error.rs:9)  */
+  ARK355_E_UNSATISFIABLE = -17,           /* SynthesisError::Unsatisfiable            (error.rs:14) */
+  ARK355_E_POLY_DEGREE_TOO_LARGE = -18    /* SynthesisError::PolynomialDegreeTooLarge (error.rs:16) */
+};
+
+/* ---- context ------------------------------------------------------------------------------ */
+int32_t ark355_ctx_create(int32_t device_id, ark355_ctx** out);
+void ark355_ctx_destroy(ark355_ctx* ctx);
+const char* ark355_last_error(const ark355_ctx* ctx);
+/* library/ABI version: (major << 16) | minor */
+uint32_t ark355_version(void);
+/* sizes in bytes for `curve`: what[0]=Fr, [1]=Fq, [2]=G1 affine, [3]=G2 affine */
+int32_t ark355_sizes(int32_t curve, uint32_t what[4]);
+
+/* ---- proving key (replaces holding ark_groth16::ProvingKey<E> on the host; SNARK::ProvingKey,
+ *      snark/src/lib.rs:25) ------------------------------------------------------------------- */
+typedef struct {
+  uint64_t num_instance;      /* ell, including the constant One (constraint_system.rs:218-220) */
+  uint64_t num_witness;       /* w   (constraint_system.rs:223-225)                            */
+  uint64_t domain_size;       /* N = next_pow2(n + ell); h_query holds N-1 points              */
+  const uint8_t* a_query;     /* (ell+w) G1 */
+  const uint8_t* b_g1_query;  /* (ell+w) G1 */
+  const uint8_t* b_g2_query;  /* (ell+w) G2 */
+  const uint8_t* h_query;     /* (N-1)   G1 */
+  const uint8_t* l_query;     /* w       G1 */
+  const uint8_t* alpha_g1;
+  const uint8_t* beta_g1;
+  const uint8_t* delta_g1;
+  const uint8_t* beta_g2;
+  const uint8_t* delta_g2;
+} ark355_pk_desc;
+
+int32_t ark355_pk_load(ark355_ctx* ctx, int32_t curve, const ark355_pk_desc* desc, ark355_pk** out);
+void ark355_pk_free(ark355_pk* pk);
+
+/* ---- R1CS matrices in CSR (replaces walking Matrix<F> rows on the host: mat_vec_mul,
+ *      utils/matrix.rs:26-36; column convention Variable::get_variable_index,
+ *      utils/variable.rs:105-113: 0 = One, 1..ell-1 = instance, ell.. = witness) --------------- */
+int32_t ark355_r1cs_load(ark355_ctx* ctx, int32_t curve, uint64_t n_constraints, uint64_t num_instance,
+                         uint64_t num_witness, const uint64_t* const row_ptr[3],
+                         const uint32_t* const col[3], const uint8_t* const coeff[3],
+                         ark355_r1cs** out);
+void ark355_r1cs_free(ark355_r1cs* r1cs);
+/* domain size N the library will use for this instance */
+uint64_t ark355_r1cs_domain_size(const ark355_r1cs* r1cs);
+
+/* ---- proof (SNARK::Proof, snark/src/lib.rs:32): affine A (G1), B (G2), C (G1), Montgomery raw */
+typedef struct {
+  uint8_t a[96];
+  uint8_t b[192];
+  uint8_t c[96];
+} ark355_proof_raw;
+
+/* SNARK::prove hot path (snark/src/lib.rs:50-54; upstream create_proof_with_reduction_and_matrices):
+ * z = full assignment (ell+w Fr, Montgomery), r/s canonical.  Returns ARK355_E_ASSIGNMENT_MISSING if
+ * z_len < ell+w. */
+int32_t ark355_prove(ark355_ctx* ctx, const ark355_pk* pk, const ark355_r1cs* r1cs, const uint8_t* z,
+                     uint64_t z_len, const uint8_t r[32], const uint8_t s[32], ark355_proof_raw* out);
+/* same, z already resident in HBM */
+int32_t ark355_prove_dev(ark355_ctx* ctx, const ark355_pk* pk, const ark355_r1cs* r1cs, const void* d_z,
+                         uint64_t z_len, const uint8_t r[32], const uint8_t s[32], ark355_proof_raw* out);
+
+/* ---- building blocks ---------------------------------------------------------------------- */
+/* R1CS -> QAP witness map h[0..N) (Montgomery), SURVEY Appendix A steps 1-5 */
+int32_t ark355_witness_map(ark355_ctx* ctx, const ark355_r1cs* r1cs, const uint8_t* z, uint64_t z_len,
+                           uint8_t* h_out);
+/* which_is_unsatisfied (constraint_system.rs:661-687) for the R1CS predicate: first_bad = -1 if
+ * satisfied, else the first constraint index with <A_i,z>*<B_i,z> != <C_i,z> */
+int32_t ark355_is_satisfied(ark355_ctx* ctx, const ark355_r1cs* r1cs, const uint8_t* z, uint64_t z_len,
+                            int64_t* first_bad);
+/* A z, B z, C z (n Fr each, Montgomery): mat_vec_mul, utils/matrix.rs:26-36 */
+int32_t ark355_r1cs_mat_vec(ark355_ctx* ctx, const ark355_r1cs* r1cs, const uint8_t* z, uint64_t z_len,
+                            uint8_t* az, uint8_t* bz, uint8_t* cz);
+
+/* in-place radix-2 NTT over Fr, natural order in and out (ark-poly Radix2EvaluationDomain
+ * fft / ifft / coset_fft / coset_ifft).  Errors with ARK355_E_POLY_DEGREE_TOO_LARGE past the
+ * field's two-adicity. */
+int32_t ark355_ntt_fr(ark355_ctx* ctx, int32_t curve, uint8_t* data, uint32_t log_n, int32_t inverse,
+                      int32_t coset);
+int32_t ark355_ntt_fr_dev(ark355_ctx* ctx, int32_t curve, void* d_data, void* d_scratch, uint32_t log_n,
+                          int32_t inverse, int32_t coset, void* stream);
+
+/* sum_i scalars[i] * bases[i] -> affine (ark-ec VariableBaseMSM::msm_bigint semantics: canonical
+ * scalars; zero scalars and infinity bases contribute nothing) */
+int32_t ark355_msm_g1(ark355_ctx* ctx, int32_t curve, const uint8_t* bases, const uint8_t* scalars,
+                      uint64_t n, uint8_t* out_affine);
+int32_t ark355_msm_g2(ark355_ctx* ctx, int32_t curve, const uint8_t* bases, const uint8_t* scalars,
+                      uint64_t n, uint8_t* out_affine);
+
+/* device-resident MSM: bases are uploaded once into a handle, scalars live in HBM */
+typedef struct ark355_bases ark355_bases;
+int32_t ark355_bases_load(ark355_ctx* ctx, int32_t curve, int32_t group /*1|2*/, const uint8_t* bases,
+                          uint64_t n, ark355_bases** out);
+void ark355_bases_free(ark355_bases* b);
+/* scalars_mont != 0: the scalars are Montgomery Fr images and are converted on device */
+int32_t ark355_msm_dev(ark355_ctx* ctx, const ark355_bases* bases, const void* d_scalars, uint64_t n,
+                       int32_t scalars_mont, uint8_t* out_affine);
+/* partial result as raw XYZZ (4 coordinates, Montgomery) for cross-GPU combination */
+int32_t ark355_msm_dev_partial(ark355_ctx* ctx, const ark355_bases* bases, const void* d_scalars,
+                               uint64_t n, int32_t scalars_mont, uint8_t* out_xyzz);
+/* sum of `count` raw XYZZ partials -> affine (the local EC-add after the RCCL all-gather) */
+int32_t ark355_xyzz_sum(ark355_ctx* ctx, int32_t curve, int32_t group, const uint8_t* partials,
+                        uint64_t count, uint8_t* out_affine);
+
+/* out[i] = scalars[i] * base (fixed base, canonical scalars) -> affine; used by
+ * circuit_specific_setup (snark/src/lib.rs:43-46) to build the query vectors */
+int32_t ark355_fixed_base_mul(ark355_ctx* ctx, int32_t curve, int32_t group, const uint8_t* base,
+                              const uint8_t* scalars, uint64_t n, uint8_t* out_affine);
+
+/* ---- timings of the last prove on this context (ms, measured with HIP events) --------------- */
+typedef struct {
+  float total_ms;
+  float h2d_ms;
+  float witness_map_ms;
+  float msm_h_ms;
+  float msm_l_ms;
+  float msm_ab_g1_ms;
+  float msm_b_g2_ms;
+  float finalize_ms;
+} ark355_timings;
+int32_t ark355_get_timings(const ark355_ctx* ctx, ark355_timings* out);
+
+/* per-kernel HIP-event timing of the dominant kernel (bucket accumulation) of the last MSM/prove
+ * on this context: sum of launch durations (ms), number of launches, points accumulated */
+int32_t ark355_get_kernel_stats(const ark355_ctx* ctx, float* accumulate_ms, uint64_t* launches,
+                                uint64_t* points);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ARK355_H */

@@ -1,0 +1,269 @@
+"""ctypes binding of the C ABI declared in ``include/ark355.h``.
+
+This is the Python-side image of the ``extern "C"`` block a Rust maintainer would write (see
+INTEGRATION.md).  It is deliberately free of torch: plain pointers and sizes only.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional, Sequence
+
+import numpy as np
+
+BLS12_381 = 0
+BN254 = 1
+
+OK = 0
+EINVAL = -1
+ENOMEM = -2
+EHIP = -3
+ERCCL = -4
+ENODEV = -5
+E_ASSIGNMENT_MISSING = -16
+E_UNSATISFIABLE = -17
+E_POLY_DEGREE_TOO_LARGE = -18
+
+_ERR_NAMES = {
+    EINVAL: "EINVAL", ENOMEM: "ENOMEM", EHIP: "EHIP", ERCCL: "ERCCL", ENODEV: "ENODEV",
+    E_ASSIGNMENT_MISSING: "AssignmentMissing", E_UNSATISFIABLE: "Unsatisfiable",
+    E_POLY_DEGREE_TOO_LARGE: "PolynomialDegreeTooLarge",
+}
+
+# every symbol include/ark355.h declares (checked by tests/test_abi.py)
+SYMBOLS = [
+    "ark355_ctx_create", "ark355_ctx_destroy", "ark355_last_error", "ark355_version", "ark355_sizes",
+    "ark355_pk_load", "ark355_pk_free", "ark355_r1cs_load", "ark355_r1cs_free",
+    "ark355_r1cs_domain_size", "ark355_prove", "ark355_prove_dev", "ark355_witness_map",
+    "ark355_is_satisfied", "ark355_r1cs_mat_vec", "ark355_ntt_fr", "ark355_ntt_fr_dev",
+    "ark355_msm_g1", "ark355_msm_g2", "ark355_bases_load", "ark355_bases_free", "ark355_msm_dev",
+    "ark355_msm_dev_partial", "ark355_xyzz_sum", "ark355_fixed_base_mul", "ark355_get_timings",
+    "ark355_get_kernel_stats",
+]
+
+
+class Ark355Error(RuntimeError):
+    def __init__(self, code, msg=""):
+        self.code = code
+        super().__init__("%s (%d)%s" % (_ERR_NAMES.get(code, "error"), code, (": " + msg) if msg else ""))
+
+
+class PkDesc(C.Structure):
+    _fields_ = [
+        ("num_instance", C.c_uint64), ("num_witness", C.c_uint64), ("domain_size", C.c_uint64),
+        ("a_query", C.c_void_p), ("b_g1_query", C.c_void_p), ("b_g2_query", C.c_void_p),
+        ("h_query", C.c_void_p), ("l_query", C.c_void_p),
+        ("alpha_g1", C.c_void_p), ("beta_g1", C.c_void_p), ("delta_g1", C.c_void_p),
+        ("beta_g2", C.c_void_p), ("delta_g2", C.c_void_p),
+    ]
+
+
+class ProofRaw(C.Structure):
+    _fields_ = [("a", C.c_uint8 * 96), ("b", C.c_uint8 * 192), ("c", C.c_uint8 * 96)]
+
+
+class Timings(C.Structure):
+    _fields_ = [(n, C.c_float) for n in (
+        "total_ms", "h2d_ms", "witness_map_ms", "msm_h_ms", "msm_l_ms", "msm_ab_g1_ms", "msm_b_g2_ms",
+        "finalize_ms")]
+
+
+def _buf(b):
+    """bytes / bytearray / numpy array -> (ctypes pointer, keepalive)."""
+    if b is None:
+        return None, None
+    if isinstance(b, np.ndarray):
+        a = np.ascontiguousarray(b)
+        return a.ctypes.data_as(C.c_void_p), a
+    if isinstance(b, (bytes, bytearray, memoryview)):
+        a = np.frombuffer(bytes(b), dtype=np.uint8) if not isinstance(b, bytearray) else np.frombuffer(b, dtype=np.uint8)
+        return a.ctypes.data_as(C.c_void_p), a
+    raise TypeError(type(b))
+
+
+class Lib:
+    """Loaded libark355 with typed signatures and thin call helpers."""
+
+    def __init__(self, path: str):
+        if not os.path.exists(path):
+            raise FileNotFoundError(path)
+        self.path = path
+        self.dll = C.CDLL(path, mode=C.RTLD_GLOBAL)
+        d = self.dll
+        vp, u64, u32, i32, i64 = C.c_void_p, C.c_uint64, C.c_uint32, C.c_int32, C.c_int64
+        P = C.POINTER
+        d.ark355_ctx_create.argtypes = [i32, P(vp)]
+        d.ark355_ctx_destroy.argtypes = [vp]
+        d.ark355_ctx_destroy.restype = None
+        d.ark355_last_error.argtypes = [vp]
+        d.ark355_last_error.restype = C.c_char_p
+        d.ark355_version.restype = u32
+        d.ark355_sizes.argtypes = [i32, P(u32 * 4)]
+        d.ark355_pk_load.argtypes = [vp, i32, P(PkDesc), P(vp)]
+        d.ark355_pk_free.argtypes = [vp]
+        d.ark355_pk_free.restype = None
+        d.ark355_r1cs_load.argtypes = [vp, i32, u64, u64, u64, P(vp * 3), P(vp * 3), P(vp * 3), P(vp)]
+        d.ark355_r1cs_free.argtypes = [vp]
+        d.ark355_r1cs_free.restype = None
+        d.ark355_r1cs_domain_size.argtypes = [vp]
+        d.ark355_r1cs_domain_size.restype = u64
+        d.ark355_prove.argtypes = [vp, vp, vp, vp, u64, vp, vp, P(ProofRaw)]
+        d.ark355_prove_dev.argtypes = [vp, vp, vp, vp, u64, vp, vp, P(ProofRaw)]
+        d.ark355_witness_map.argtypes = [vp, vp, vp, u64, vp]
+        d.ark355_is_satisfied.argtypes = [vp, vp, vp, u64, P(i64)]
+        d.ark355_r1cs_mat_vec.argtypes = [vp, vp, vp, u64, vp, vp, vp]
+        d.ark355_ntt_fr.argtypes = [vp, i32, vp, u32, i32, i32]
+        d.ark355_ntt_fr_dev.argtypes = [vp, i32, vp, vp, u32, i32, i32, vp]
+        d.ark355_msm_g1.argtypes = [vp, i32, vp, vp, u64, vp]
+        d.ark355_msm_g2.argtypes = [vp, i32, vp, vp, u64, vp]
+        d.ark355_bases_load.argtypes = [vp, i32, i32, vp, u64, P(vp)]
+        d.ark355_bases_free.argtypes = [vp]
+        d.ark355_bases_free.restype = None
+        d.ark355_msm_dev.argtypes = [vp, vp, vp, u64, i32, vp]
+        d.ark355_msm_dev_partial.argtypes = [vp, vp, vp, u64, i32, vp]
+        d.ark355_xyzz_sum.argtypes = [vp, i32, i32, vp, u64, vp]
+        d.ark355_fixed_base_mul.argtypes = [vp, i32, i32, vp, vp, u64, vp]
+        d.ark355_get_timings.argtypes = [vp, P(Timings)]
+        d.ark355_get_kernel_stats.argtypes = [vp, P(C.c_float), P(u64), P(u64)]
+        for name in SYMBOLS:
+            fn = getattr(d, name)
+            if fn.restype is C.c_int:      # default: make every status-returning call int32
+                fn.restype = i32
+
+    # ---- helpers ---------------------------------------------------------------------------------
+    def check(self, ctx, rc):
+        if rc != OK:
+            msg = ""
+            if ctx:
+                m = self.dll.ark355_last_error(ctx)
+                msg = m.decode() if m else ""
+            raise Ark355Error(rc, msg)
+
+    def sizes(self, curve):
+        out = (C.c_uint32 * 4)()
+        self.check(None, self.dll.ark355_sizes(curve, C.byref(out)))
+        return {"fr": out[0], "fq": out[1], "g1": out[2], "g2": out[3]}
+
+    def ctx_create(self, device=0):
+        h = C.c_void_p()
+        rc = self.dll.ark355_ctx_create(device, C.byref(h))
+        if rc != OK:
+            raise Ark355Error(rc, "ark355_ctx_create")
+        return h
+
+    def ctx_destroy(self, ctx):
+        self.dll.ark355_ctx_destroy(ctx)
+
+    def pk_load(self, ctx, curve, ell, w, N, a_query, b_g1_query, b_g2_query, h_query, l_query,
+                alpha_g1, beta_g1, delta_g1, beta_g2, delta_g2):
+        keep = []
+        d = PkDesc()
+        d.num_instance, d.num_witness, d.domain_size = ell, w, N
+        for name, val in (("a_query", a_query), ("b_g1_query", b_g1_query), ("b_g2_query", b_g2_query),
+                          ("h_query", h_query), ("l_query", l_query), ("alpha_g1", alpha_g1),
+                          ("beta_g1", beta_g1), ("delta_g1", delta_g1), ("beta_g2", beta_g2),
+                          ("delta_g2", delta_g2)):
+            p, k = _buf(val if (val is None or len(val)) else None)
+            keep.append(k)
+            setattr(d, name, p.value if p is not None else None)
+        h = C.c_void_p()
+        self.check(ctx, self.dll.ark355_pk_load(ctx, curve, C.byref(d), C.byref(h)))
+        return h
+
+    def r1cs_load(self, ctx, curve, n, ell, w, mats):
+        """mats: three (row_ptr u64[n+1], col u32[nnz], coeff bytes nnz*fr) tuples."""
+        keep = []
+        rp = (C.c_void_p * 3)()
+        cl = (C.c_void_p * 3)()
+        cf = (C.c_void_p * 3)()
+        for i, (row_ptr, col, coeff) in enumerate(mats):
+            a = np.ascontiguousarray(row_ptr, dtype=np.uint64)
+            b = np.ascontiguousarray(col, dtype=np.uint32)
+            c, kc = _buf(coeff if len(coeff) else b"\0")
+            keep += [a, b, kc]
+            rp[i] = a.ctypes.data
+            cl[i] = b.ctypes.data if b.size else np.zeros(1, np.uint32).ctypes.data
+            cf[i] = c.value
+        h = C.c_void_p()
+        self.check(ctx, self.dll.ark355_r1cs_load(ctx, curve, n, ell, w, C.byref(rp), C.byref(cl), C.byref(cf),
+                                                  C.byref(h)))
+        return h
+
+    def prove(self, ctx, pk, r1cs, z, z_len, r: bytes, s: bytes, sizes, z_is_device_ptr=False):
+        out = ProofRaw()
+        rb, k1 = _buf(r)
+        sb, k2 = _buf(s)
+        if z_is_device_ptr:
+            rc = self.dll.ark355_prove_dev(ctx, pk, r1cs, C.c_void_p(z), z_len, rb, sb, C.byref(out))
+        else:
+            zb, k3 = _buf(z)
+            rc = self.dll.ark355_prove(ctx, pk, r1cs, zb, z_len, rb, sb, C.byref(out))
+        self.check(ctx, rc)
+        return bytes(out.a)[:sizes["g1"]], bytes(out.b)[:sizes["g2"]], bytes(out.c)[:sizes["g1"]]
+
+    def witness_map(self, ctx, r1cs, z, z_len, fr_size):
+        N = self.dll.ark355_r1cs_domain_size(r1cs)
+        out = np.zeros(N * fr_size, dtype=np.uint8)
+        zb, k = _buf(z)
+        self.check(ctx, self.dll.ark355_witness_map(ctx, r1cs, zb, z_len, out.ctypes.data_as(C.c_void_p)))
+        return out.tobytes()
+
+    def is_satisfied(self, ctx, r1cs, z, z_len):
+        fb = C.c_int64(0)
+        zb, k = _buf(z)
+        self.check(ctx, self.dll.ark355_is_satisfied(ctx, r1cs, zb, z_len, C.byref(fb)))
+        return fb.value
+
+    def mat_vec(self, ctx, r1cs, z, z_len, n, fr_size):
+        outs = [np.zeros(max(1, n * fr_size), dtype=np.uint8) for _ in range(3)]
+        zb, k = _buf(z)
+        self.check(ctx, self.dll.ark355_r1cs_mat_vec(ctx, r1cs, zb, z_len, *[o.ctypes.data_as(C.c_void_p) for o in outs]))
+        return [o.tobytes()[:n * fr_size] for o in outs]
+
+    def ntt(self, ctx, curve, data: bytes, log_n, inverse=False, coset=False):
+        a = np.frombuffer(bytearray(data), dtype=np.uint8)
+        self.check(ctx, self.dll.ark355_ntt_fr(ctx, curve, a.ctypes.data_as(C.c_void_p), log_n, int(inverse), int(coset)))
+        return a.tobytes()
+
+    def msm(self, ctx, curve, group, bases: bytes, scalars: bytes, n, out_size):
+        out = np.zeros(out_size, dtype=np.uint8)
+        bb, k1 = _buf(bases if n else None)
+        sb, k2 = _buf(scalars if n else None)
+        fn = self.dll.ark355_msm_g1 if group == 1 else self.dll.ark355_msm_g2
+        self.check(ctx, fn(ctx, curve, bb, sb, n, out.ctypes.data_as(C.c_void_p)))
+        return out.tobytes()
+
+    def bases_load(self, ctx, curve, group, bases, n):
+        h = C.c_void_p()
+        bb, k = _buf(bases if n else None)
+        self.check(ctx, self.dll.ark355_bases_load(ctx, curve, group, bb, n, C.byref(h)))
+        return h
+
+    def msm_dev(self, ctx, bases_h, d_scalars_ptr, n, mont, out_size, partial=False):
+        out = np.zeros(out_size, dtype=np.uint8)
+        fn = self.dll.ark355_msm_dev_partial if partial else self.dll.ark355_msm_dev
+        self.check(ctx, fn(ctx, bases_h, C.c_void_p(d_scalars_ptr), n, int(mont), out.ctypes.data_as(C.c_void_p)))
+        return out.tobytes()
+
+    def xyzz_sum(self, ctx, curve, group, partials: bytes, count, out_size):
+        out = np.zeros(out_size, dtype=np.uint8)
+        pb, k = _buf(partials if count else None)
+        self.check(ctx, self.dll.ark355_xyzz_sum(ctx, curve, group, pb, count, out.ctypes.data_as(C.c_void_p)))
+        return out.tobytes()
+
+    def fixed_base_mul(self, ctx, curve, group, base: bytes, scalars, n, point_size):
+        out = np.zeros(max(1, n * point_size), dtype=np.uint8)
+        bb, k1 = _buf(base)
+        sb, k2 = _buf(scalars if n else None)
+        self.check(ctx, self.dll.ark355_fixed_base_mul(ctx, curve, group, bb, sb, n, out.ctypes.data_as(C.c_void_p)))
+        return out.tobytes()[:n * point_size]
+
+    def timings(self, ctx):
+        t = Timings()
+        self.check(ctx, self.dll.ark355_get_timings(ctx, C.byref(t)))
+        return {n: getattr(t, n) for n, _ in Timings._fields_}
+
+    def kernel_stats(self, ctx):
+        ms, l, p = C.c_float(0), C.c_uint64(0), C.c_uint64(0)
+        self.check(ctx, self.dll.ark355_get_kernel_stats(ctx, C.byref(ms), C.byref(l), C.byref(p)))
+        return {"accumulate_ms": ms.value, "launches": l.value, "points": p.value}

@@ -1,0 +1,230 @@
+// Per-curve implementation of the C ABI (explicitly instantiated in ark355_bls.hip / ark355_bn.hip).
+#pragma once
+#include "common.h"
+#include "groth16_impl.cuh"
+
+namespace ark355 {
+
+struct BasesDev {
+  int curve = 0, group = 1;
+  uint64_t n = 0;
+  DevBuf pts;
+};
+
+// one lane per scalar: k * P by double-and-add, then affine (setup-time fixed-base multiplications)
+template <class F, class Fr>
+__global__ void __launch_bounds__(128)
+fixed_base_mul_kernel(const Affine<F>* __restrict__ base, const Fr* __restrict__ scalars, uint64_t n,
+                      Affine<F>* __restrict__ out) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const Fr k = scalars[i];
+  const XYZZ<F> p = XYZZ<F>::from_affine(*base);
+  out[i] = xyzz_to_affine(xyzz_mul_scalar(p, k.l, Fr::N));
+}
+
+struct GenericScratch {
+  MsmSort sort;
+  MsmBuckets bk;
+  DevBuf a, b, c;
+};
+
+template <class Curve>
+struct Api {
+  using Fr = typename Curve::Fr;
+  using Fq = typename Curve::Fq;
+  using Fq2 = typename Curve::Fq2;
+
+  static void sizes(uint32_t what[4]) {
+    what[0] = sizeof(Fr);
+    what[1] = sizeof(Fq);
+    what[2] = sizeof(Affine<Fq>);
+    what[3] = sizeof(Affine<Fq2>);
+  }
+
+  static PkDev* pk_load(const ark355_pk_desc* d) { return pk_upload<Curve>(d); }
+
+  static R1csDev* r1cs_load(uint64_t n, uint64_t ell, uint64_t w, const uint64_t* const rp[3],
+                            const uint32_t* const col[3], const uint8_t* const coeff[3]) {
+    return r1cs_upload<Curve>(n, ell, w, rp, col, coeff);
+  }
+
+  static void prove(ark355_ctx* ctx, ProverScratch& sc, const PkDev& pk, const R1csDev& r1, const void* z,
+                    bool on_dev, const uint8_t* r, const uint8_t* s, ark355_proof_raw* out) {
+    prove_run<Curve>(ctx, sc, pk, r1, z, on_dev, r, s, out);
+  }
+
+  static void witness_map(ark355_ctx* ctx, ProverScratch& sc, const R1csDev& r1, const uint8_t* z, uint8_t* h_out) {
+    hipStream_t st = ctx->stream;
+    sc.zx.ensure((r1.m + 4) * sizeof(Fr));
+    ARK_CHECK_HIP(hipMemcpyAsync(sc.zx.p, z, r1.m * sizeof(Fr), hipMemcpyHostToDevice, st));
+    void* d_h = witness_map_run<Curve>(ctx, r1, sc.zx.p, sc.ws, st);
+    ARK_CHECK_HIP(hipMemcpyAsync(h_out, d_h, r1.N * sizeof(Fr), hipMemcpyDeviceToHost, st));
+    ARK_CHECK_HIP(hipStreamSynchronize(st));
+  }
+
+  static void mat_vec(ark355_ctx* ctx, ProverScratch& sc, const R1csDev& r1, const uint8_t* z, uint8_t* az,
+                      uint8_t* bz, uint8_t* cz, int64_t* first_bad) {
+    hipStream_t st = ctx->stream;
+    sc.zx.ensure((r1.m + 4) * sizeof(Fr));
+    ARK_CHECK_HIP(hipMemcpyAsync(sc.zx.p, z, r1.m * sizeof(Fr), hipMemcpyHostToDevice, st));
+    spmv_run<Curve>(r1, sc.zx.p, sc.ws, st);
+    if (az) ARK_CHECK_HIP(hipMemcpyAsync(az, sc.ws.buf[0].p, r1.n * sizeof(Fr), hipMemcpyDeviceToHost, st));
+    if (bz) ARK_CHECK_HIP(hipMemcpyAsync(bz, sc.ws.buf[2].p, r1.n * sizeof(Fr), hipMemcpyDeviceToHost, st));
+    if (cz) ARK_CHECK_HIP(hipMemcpyAsync(cz, sc.ws.buf[4].p, r1.n * sizeof(Fr), hipMemcpyDeviceToHost, st));
+    if (first_bad) {
+      sc.ws.first_bad.ensure(8);
+      ARK_CHECK_HIP(hipMemsetAsync(sc.ws.first_bad.p, 0xFF, 8, st));
+      if (r1.n) {
+        const uint32_t grid = (uint32_t)((r1.n + 255) / 256);
+        ARK_LAUNCH((r1cs_check_kernel<Fr>), dim3(grid), dim3(256), 0, st, sc.ws.buf[0].as<Fr>(),
+                   sc.ws.buf[2].as<Fr>(), sc.ws.buf[4].as<Fr>(), r1.n, sc.ws.first_bad.as<unsigned long long>());
+        ARK_CHECK_LAUNCH();
+      }
+      unsigned long long fb = 0;
+      ARK_CHECK_HIP(hipMemcpyAsync(&fb, sc.ws.first_bad.p, 8, hipMemcpyDeviceToHost, st));
+      ARK_CHECK_HIP(hipStreamSynchronize(st));
+      *first_bad = (fb == ~0ull) ? -1 : (int64_t)fb;
+    }
+    ARK_CHECK_HIP(hipStreamSynchronize(st));
+  }
+
+  static void ntt_host(ark355_ctx* ctx, GenericScratch& g, uint8_t* data, uint32_t log_n, bool inverse, bool coset) {
+    hipStream_t st = ctx->stream;
+    const size_t bytes = sizeof(Fr) << log_n;
+    g.a.ensure(bytes);
+    g.b.ensure(bytes);
+    ARK_CHECK_HIP(hipMemcpyAsync(g.a.p, data, bytes, hipMemcpyHostToDevice, st));
+    void* res = ntt_run<Curve>(ctx, g.a.p, g.b.p, log_n, inverse, coset, st);
+    ARK_CHECK_HIP(hipMemcpyAsync(data, res, bytes, hipMemcpyDeviceToHost, st));
+    ARK_CHECK_HIP(hipStreamSynchronize(st));
+  }
+
+  static void ntt_dev(ark355_ctx* ctx, void* d_data, void* d_scratch, uint32_t log_n, bool inverse, bool coset,
+                      hipStream_t st) {
+    const size_t bytes = sizeof(Fr) << log_n;
+    void* res = ntt_run<Curve>(ctx, d_data, d_scratch, log_n, inverse, coset, st);
+    if (res != d_data) ARK_CHECK_HIP(hipMemcpyAsync(d_data, res, bytes, hipMemcpyDeviceToDevice, st));
+  }
+
+  template <class F>
+  static void msm_generic(ark355_ctx* ctx, GenericScratch& g, const Affine<F>* d_bases, const void* d_scalars,
+                          uint64_t n, int mont, uint8_t* out, bool want_affine) {
+    hipStream_t st = ctx->stream;
+    g.c.ensure(sizeof(XYZZ<F>) + sizeof(Affine<F>));
+    XYZZ<F>* d_res = g.c.as<XYZZ<F>>();
+    Affine<F>* d_aff = reinterpret_cast<Affine<F>*>(d_res + 1);
+    hipEvent_t e0, e1;
+    ARK_CHECK_HIP(hipEventCreate(&e0));
+    ARK_CHECK_HIP(hipEventCreate(&e1));
+    try {
+      msm_sort<Fr>(ctx, g.sort, d_scalars, n, mont, st);
+      msm_buckets<F>(ctx, g.sort, g.bk, d_bases, d_res, 0, st, n ? e0 : nullptr, n ? e1 : nullptr);
+      if (want_affine) {
+        ARK_LAUNCH((xyzz_to_affine_kernel<F>), dim3(1), dim3(64), 0, st, (const XYZZ<F>*)d_res, d_aff, 1u);
+        ARK_CHECK_LAUNCH();
+        ARK_CHECK_HIP(hipMemcpyAsync(out, d_aff, sizeof(Affine<F>), hipMemcpyDeviceToHost, st));
+      } else {
+        ARK_CHECK_HIP(hipMemcpyAsync(out, d_res, sizeof(XYZZ<F>), hipMemcpyDeviceToHost, st));
+      }
+      ARK_CHECK_HIP(hipStreamSynchronize(st));
+      float ms = 0;
+      if (n) (void)hipEventElapsedTime(&ms, e0, e1);
+      ctx->acc_ms = ms;
+      ctx->acc_launches = n ? 1 : 0;
+      ctx->acc_points = (uint64_t)g.sort.plan.windows * n;
+    } catch (...) {
+      (void)hipEventDestroy(e0);
+      (void)hipEventDestroy(e1);
+      throw;
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+  }
+
+  static void msm_host(ark355_ctx* ctx, GenericScratch& g, int group, const uint8_t* bases, const uint8_t* scalars,
+                       uint64_t n, uint8_t* out) {
+    hipStream_t st = ctx->stream;
+    const size_t psz = group == 1 ? sizeof(Affine<Fq>) : sizeof(Affine<Fq2>);
+    g.a.ensure(n * psz);
+    g.b.ensure(n * sizeof(Fr));
+    if (n) {
+      ARK_CHECK_HIP(hipMemcpyAsync(g.a.p, bases, n * psz, hipMemcpyHostToDevice, st));
+      ARK_CHECK_HIP(hipMemcpyAsync(g.b.p, scalars, n * sizeof(Fr), hipMemcpyHostToDevice, st));
+    }
+    if (group == 1) msm_generic<Fq>(ctx, g, g.a.as<Affine<Fq>>(), g.b.p, n, 0, out, true);
+    else msm_generic<Fq2>(ctx, g, g.a.as<Affine<Fq2>>(), g.b.p, n, 0, out, true);
+  }
+
+  static BasesDev* bases_load(int group, const uint8_t* bases, uint64_t n) {
+    auto* b = new BasesDev();
+    try {
+      b->curve = Curve::ID;
+      b->group = group;
+      b->n = n;
+      const size_t psz = group == 1 ? sizeof(Affine<Fq>) : sizeof(Affine<Fq2>);
+      b->pts.alloc(n * psz);
+      if (n) ARK_CHECK_HIP(hipMemcpy(b->pts.p, bases, n * psz, hipMemcpyHostToDevice));
+    } catch (...) {
+      delete b;
+      throw;
+    }
+    return b;
+  }
+
+  static void msm_dev(ark355_ctx* ctx, GenericScratch& g, const BasesDev& b, const void* d_scalars, uint64_t n, int mont,
+                      uint8_t* out, bool want_affine) {
+    ARK_REQUIRE(n <= b.n, ARK355_EINVAL, "more scalars than bases");
+    if (b.group == 1) msm_generic<Fq>(ctx, g, b.pts.as<Affine<Fq>>(), d_scalars, n, mont, out, want_affine);
+    else msm_generic<Fq2>(ctx, g, b.pts.as<Affine<Fq2>>(), d_scalars, n, mont, out, want_affine);
+  }
+
+  template <class F>
+  static void xyzz_sum_t(ark355_ctx* ctx, GenericScratch& g, const uint8_t* partials, uint64_t count, uint8_t* out) {
+    hipStream_t st = ctx->stream;
+    g.a.ensure(count * sizeof(XYZZ<F>) + sizeof(XYZZ<F>) + sizeof(Affine<F>));
+    XYZZ<F>* d_in = g.a.as<XYZZ<F>>();
+    XYZZ<F>* d_sum = d_in + count;
+    Affine<F>* d_aff = reinterpret_cast<Affine<F>*>(d_sum + 1);
+    if (count) ARK_CHECK_HIP(hipMemcpyAsync(d_in, partials, count * sizeof(XYZZ<F>), hipMemcpyHostToDevice, st));
+    ARK_LAUNCH((xyzz_sum_kernel<F>), dim3(1), dim3(64), 0, st, (const XYZZ<F>*)d_in, (uint32_t)count, d_sum);
+    ARK_CHECK_LAUNCH();
+    ARK_LAUNCH((xyzz_to_affine_kernel<F>), dim3(1), dim3(64), 0, st, (const XYZZ<F>*)d_sum, d_aff, 1u);
+    ARK_CHECK_LAUNCH();
+    ARK_CHECK_HIP(hipMemcpyAsync(out, d_aff, sizeof(Affine<F>), hipMemcpyDeviceToHost, st));
+    ARK_CHECK_HIP(hipStreamSynchronize(st));
+  }
+
+  static void xyzz_sum(ark355_ctx* ctx, GenericScratch& g, int group, const uint8_t* partials, uint64_t count,
+                       uint8_t* out) {
+    if (group == 1) xyzz_sum_t<Fq>(ctx, g, partials, count, out);
+    else xyzz_sum_t<Fq2>(ctx, g, partials, count, out);
+  }
+
+  template <class F>
+  static void fixed_base_t(ark355_ctx* ctx, GenericScratch& g, const uint8_t* base, const uint8_t* scalars, uint64_t n,
+                           uint8_t* out) {
+    hipStream_t st = ctx->stream;
+    g.a.ensure(sizeof(Affine<F>));
+    g.b.ensure(n * sizeof(Fr));
+    g.c.ensure(n * sizeof(Affine<F>));
+    ARK_CHECK_HIP(hipMemcpyAsync(g.a.p, base, sizeof(Affine<F>), hipMemcpyHostToDevice, st));
+    if (n) {
+      ARK_CHECK_HIP(hipMemcpyAsync(g.b.p, scalars, n * sizeof(Fr), hipMemcpyHostToDevice, st));
+      const uint32_t grid = (uint32_t)((n + 127) / 128);
+      ARK_LAUNCH((fixed_base_mul_kernel<F, Fr>), dim3(grid), dim3(128), 0, st, g.a.as<Affine<F>>(), g.b.as<Fr>(), n,
+                 g.c.as<Affine<F>>());
+      ARK_CHECK_LAUNCH();
+      ARK_CHECK_HIP(hipMemcpyAsync(out, g.c.p, n * sizeof(Affine<F>), hipMemcpyDeviceToHost, st));
+    }
+    ARK_CHECK_HIP(hipStreamSynchronize(st));
+  }
+
+  static void fixed_base(ark355_ctx* ctx, GenericScratch& g, int group, const uint8_t* base, const uint8_t* scalars,
+                         uint64_t n, uint8_t* out) {
+    if (group == 1) fixed_base_t<Fq>(ctx, g, base, scalars, n, out);
+    else fixed_base_t<Fq2>(ctx, g, base, scalars, n, out);
+  }
+};
+
+}  // namespace ark355

@@ -1,0 +1,311 @@
+// extern "C" surface of libark355.so (include/ark355.h).  No C++ exception crosses this boundary:
+// every entry point catches and maps to an error code (the reference builds with panic='abort' for
+// exactly that reason, /root/reference/Cargo.toml:33,45).
+#include <new>
+#include "api_impl.cuh"
+
+namespace ark355 {
+extern template struct Api<BlsCurve>;
+extern template struct Api<BnCurve>;
+}  // namespace ark355
+
+using namespace ark355;
+
+struct ark355_pk {
+  PkDev* d;
+};
+struct ark355_r1cs {
+  R1csDev* d;
+};
+struct ark355_bases {
+  BasesDev* d;
+};
+
+namespace {
+struct CtxExtra {
+  ProverScratch prover;
+  GenericScratch generic;
+};
+std::mutex g_extra_mu;
+std::map<ark355_ctx*, CtxExtra*> g_extra;
+
+CtxExtra& extra(ark355_ctx* ctx) {
+  std::lock_guard<std::mutex> lk(g_extra_mu);
+  auto it = g_extra.find(ctx);
+  if (it == g_extra.end()) it = g_extra.emplace(ctx, new CtxExtra()).first;
+  return *it->second;
+}
+
+template <class Fn>
+int32_t guarded(ark355_ctx* ctx, Fn&& fn) {
+  try {
+    if (ctx) {
+      std::lock_guard<std::mutex> lk(ctx->mu);
+      (void)hipSetDevice(ctx->device);
+      fn();
+    } else {
+      fn();
+    }
+    return ARK355_OK;
+  } catch (const HipError& e) {
+    if (ctx) ctx->last_error = e.what;
+    return e.code;
+  } catch (const std::bad_alloc&) {
+    if (ctx) ctx->last_error = "host allocation failed";
+    return ARK355_ENOMEM;
+  } catch (const std::exception& e) {
+    if (ctx) ctx->last_error = e.what();
+    return ARK355_EINVAL;
+  } catch (...) {
+    if (ctx) ctx->last_error = "unknown error";
+    return ARK355_EINVAL;
+  }
+}
+
+#define CURVE_DISPATCH(curve, CALL)                                           \
+  do {                                                                        \
+    if ((curve) == ARK355_BLS12_381) {                                        \
+      using A = Api<BlsCurve>;                                                \
+      CALL;                                                                   \
+    } else if ((curve) == ARK355_BN254) {                                     \
+      using A = Api<BnCurve>;                                                 \
+      CALL;                                                                   \
+    } else {                                                                  \
+      throw HipError{ARK355_EINVAL, "unknown curve id"};                      \
+    }                                                                         \
+  } while (0)
+}  // namespace
+
+extern "C" {
+
+uint32_t ark355_version(void) { return (0u << 16) | 1u; }
+
+int32_t ark355_sizes(int32_t curve, uint32_t what[4]) {
+  return guarded(nullptr, [&] { CURVE_DISPATCH(curve, A::sizes(what)); });
+}
+
+int32_t ark355_ctx_create(int32_t device_id, ark355_ctx** out) {
+  if (!out) return ARK355_EINVAL;
+  *out = nullptr;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return ARK355_ENODEV;
+  if (device_id < 0 || device_id >= count) return ARK355_EINVAL;
+  ark355_ctx* ctx = new (std::nothrow) ark355_ctx();
+  if (!ctx) return ARK355_ENOMEM;
+  ctx->device = device_id;
+  if (hipSetDevice(device_id) != hipSuccess || hipStreamCreate(&ctx->stream) != hipSuccess) {
+    delete ctx;
+    return ARK355_EHIP;
+  }
+  *out = ctx;
+  return ARK355_OK;
+}
+
+void ark355_ctx_destroy(ark355_ctx* ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  {
+    std::lock_guard<std::mutex> lk(g_extra_mu);
+    auto it = g_extra.find(ctx);
+    if (it != g_extra.end()) {
+      delete it->second;
+      g_extra.erase(it);
+    }
+  }
+  for (auto& kv : ctx->ntt_tables) delete kv.second;
+  (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+const char* ark355_last_error(const ark355_ctx* ctx) { return ctx ? ctx->last_error.c_str() : "null context"; }
+
+int32_t ark355_pk_load(ark355_ctx* ctx, int32_t curve, const ark355_pk_desc* desc, ark355_pk** out) {
+  if (!ctx || !desc || !out) return ARK355_EINVAL;
+  *out = nullptr;
+  return guarded(ctx, [&] {
+    PkDev* d = nullptr;
+    CURVE_DISPATCH(curve, d = A::pk_load(desc));
+    *out = new ark355_pk{d};
+  });
+}
+void ark355_pk_free(ark355_pk* pk) {
+  if (!pk) return;
+  delete pk->d;
+  delete pk;
+}
+
+int32_t ark355_r1cs_load(ark355_ctx* ctx, int32_t curve, uint64_t n, uint64_t ell, uint64_t w,
+                         const uint64_t* const row_ptr[3], const uint32_t* const col[3],
+                         const uint8_t* const coeff[3], ark355_r1cs** out) {
+  if (!ctx || !row_ptr || !col || !coeff || !out) return ARK355_EINVAL;
+  *out = nullptr;
+  for (int i = 0; i < 3; i++)
+    if (!row_ptr[i]) return ARK355_EINVAL;
+  return guarded(ctx, [&] {
+    R1csDev* d = nullptr;
+    CURVE_DISPATCH(curve, d = A::r1cs_load(n, ell, w, row_ptr, col, coeff));
+    *out = new ark355_r1cs{d};
+  });
+}
+void ark355_r1cs_free(ark355_r1cs* r) {
+  if (!r) return;
+  delete r->d;
+  delete r;
+}
+uint64_t ark355_r1cs_domain_size(const ark355_r1cs* r) { return r ? r->d->N : 0; }
+
+static int32_t prove_common(ark355_ctx* ctx, const ark355_pk* pk, const ark355_r1cs* r1, const void* z, uint64_t z_len,
+                            bool on_dev, const uint8_t* r, const uint8_t* s, ark355_proof_raw* out) {
+  if (!ctx || !pk || !r1 || !z || !r || !s || !out) return ARK355_EINVAL;
+  if (z_len < r1->d->m) {
+    ctx->last_error = "assignment shorter than num_instance + num_witness";
+    return ARK355_E_ASSIGNMENT_MISSING;
+  }
+  return guarded(ctx, [&] {
+    CtxExtra& ex = extra(ctx);
+    CURVE_DISPATCH(pk->d->curve, A::prove(ctx, ex.prover, *pk->d, *r1->d, z, on_dev, r, s, out));
+  });
+}
+
+int32_t ark355_prove(ark355_ctx* ctx, const ark355_pk* pk, const ark355_r1cs* r1, const uint8_t* z, uint64_t z_len,
+                     const uint8_t r[32], const uint8_t s[32], ark355_proof_raw* out) {
+  return prove_common(ctx, pk, r1, z, z_len, false, r, s, out);
+}
+int32_t ark355_prove_dev(ark355_ctx* ctx, const ark355_pk* pk, const ark355_r1cs* r1, const void* d_z, uint64_t z_len,
+                         const uint8_t r[32], const uint8_t s[32], ark355_proof_raw* out) {
+  return prove_common(ctx, pk, r1, d_z, z_len, true, r, s, out);
+}
+
+int32_t ark355_witness_map(ark355_ctx* ctx, const ark355_r1cs* r1, const uint8_t* z, uint64_t z_len, uint8_t* h_out) {
+  if (!ctx || !r1 || !z || !h_out) return ARK355_EINVAL;
+  if (z_len < r1->d->m) return ARK355_E_ASSIGNMENT_MISSING;
+  return guarded(ctx, [&] {
+    CtxExtra& ex = extra(ctx);
+    CURVE_DISPATCH(r1->d->curve, A::witness_map(ctx, ex.prover, *r1->d, z, h_out));
+  });
+}
+
+int32_t ark355_is_satisfied(ark355_ctx* ctx, const ark355_r1cs* r1, const uint8_t* z, uint64_t z_len,
+                            int64_t* first_bad) {
+  if (!ctx || !r1 || !z || !first_bad) return ARK355_EINVAL;
+  if (z_len < r1->d->m) return ARK355_E_ASSIGNMENT_MISSING;
+  return guarded(ctx, [&] {
+    CtxExtra& ex = extra(ctx);
+    CURVE_DISPATCH(r1->d->curve, A::mat_vec(ctx, ex.prover, *r1->d, z, nullptr, nullptr, nullptr, first_bad));
+  });
+}
+
+int32_t ark355_r1cs_mat_vec(ark355_ctx* ctx, const ark355_r1cs* r1, const uint8_t* z, uint64_t z_len, uint8_t* az,
+                            uint8_t* bz, uint8_t* cz) {
+  if (!ctx || !r1 || !z) return ARK355_EINVAL;
+  if (z_len < r1->d->m) return ARK355_E_ASSIGNMENT_MISSING;
+  return guarded(ctx, [&] {
+    CtxExtra& ex = extra(ctx);
+    CURVE_DISPATCH(r1->d->curve, A::mat_vec(ctx, ex.prover, *r1->d, z, az, bz, cz, nullptr));
+  });
+}
+
+int32_t ark355_ntt_fr(ark355_ctx* ctx, int32_t curve, uint8_t* data, uint32_t log_n, int32_t inverse, int32_t coset) {
+  if (!ctx || !data) return ARK355_EINVAL;
+  if (log_n > 40) return ARK355_E_POLY_DEGREE_TOO_LARGE;
+  return guarded(ctx, [&] {
+    CtxExtra& ex = extra(ctx);
+    CURVE_DISPATCH(curve, A::ntt_host(ctx, ex.generic, data, log_n, inverse != 0, coset != 0));
+  });
+}
+
+int32_t ark355_ntt_fr_dev(ark355_ctx* ctx, int32_t curve, void* d_data, void* d_scratch, uint32_t log_n,
+                          int32_t inverse, int32_t coset, void* stream) {
+  if (!ctx || !d_data || !d_scratch) return ARK355_EINVAL;
+  if (log_n > 40) return ARK355_E_POLY_DEGREE_TOO_LARGE;
+  return guarded(ctx, [&] {
+    hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    CURVE_DISPATCH(curve, A::ntt_dev(ctx, d_data, d_scratch, log_n, inverse != 0, coset != 0, st));
+  });
+}
+
+static int32_t msm_host_common(ark355_ctx* ctx, int32_t curve, int group, const uint8_t* bases, const uint8_t* scalars,
+                               uint64_t n, uint8_t* out) {
+  if (!ctx || !out || (n && (!bases || !scalars))) return ARK355_EINVAL;
+  return guarded(ctx, [&] {
+    CtxExtra& ex = extra(ctx);
+    CURVE_DISPATCH(curve, A::msm_host(ctx, ex.generic, group, bases, scalars, n, out));
+  });
+}
+int32_t ark355_msm_g1(ark355_ctx* ctx, int32_t curve, const uint8_t* bases, const uint8_t* scalars, uint64_t n,
+                      uint8_t* out) {
+  return msm_host_common(ctx, curve, 1, bases, scalars, n, out);
+}
+int32_t ark355_msm_g2(ark355_ctx* ctx, int32_t curve, const uint8_t* bases, const uint8_t* scalars, uint64_t n,
+                      uint8_t* out) {
+  return msm_host_common(ctx, curve, 2, bases, scalars, n, out);
+}
+
+int32_t ark355_bases_load(ark355_ctx* ctx, int32_t curve, int32_t group, const uint8_t* bases, uint64_t n,
+                          ark355_bases** out) {
+  if (!ctx || !out || (n && !bases) || (group != 1 && group != 2)) return ARK355_EINVAL;
+  *out = nullptr;
+  return guarded(ctx, [&] {
+    BasesDev* d = nullptr;
+    CURVE_DISPATCH(curve, d = A::bases_load(group, bases, n));
+    *out = new ark355_bases{d};
+  });
+}
+void ark355_bases_free(ark355_bases* b) {
+  if (!b) return;
+  delete b->d;
+  delete b;
+}
+
+int32_t ark355_msm_dev(ark355_ctx* ctx, const ark355_bases* bases, const void* d_scalars, uint64_t n,
+                       int32_t scalars_mont, uint8_t* out_affine) {
+  if (!ctx || !bases || !out_affine || (n && !d_scalars)) return ARK355_EINVAL;
+  return guarded(ctx, [&] {
+    CtxExtra& ex = extra(ctx);
+    CURVE_DISPATCH(bases->d->curve, A::msm_dev(ctx, ex.generic, *bases->d, d_scalars, n, scalars_mont, out_affine, true));
+  });
+}
+int32_t ark355_msm_dev_partial(ark355_ctx* ctx, const ark355_bases* bases, const void* d_scalars, uint64_t n,
+                               int32_t scalars_mont, uint8_t* out_xyzz) {
+  if (!ctx || !bases || !out_xyzz || (n && !d_scalars)) return ARK355_EINVAL;
+  return guarded(ctx, [&] {
+    CtxExtra& ex = extra(ctx);
+    CURVE_DISPATCH(bases->d->curve, A::msm_dev(ctx, ex.generic, *bases->d, d_scalars, n, scalars_mont, out_xyzz, false));
+  });
+}
+
+int32_t ark355_xyzz_sum(ark355_ctx* ctx, int32_t curve, int32_t group, const uint8_t* partials, uint64_t count,
+                        uint8_t* out_affine) {
+  if (!ctx || !out_affine || (count && !partials) || (group != 1 && group != 2) || count >= (1ull << 31))
+    return ARK355_EINVAL;
+  return guarded(ctx, [&] {
+    CtxExtra& ex = extra(ctx);
+    CURVE_DISPATCH(curve, A::xyzz_sum(ctx, ex.generic, group, partials, count, out_affine));
+  });
+}
+
+int32_t ark355_fixed_base_mul(ark355_ctx* ctx, int32_t curve, int32_t group, const uint8_t* base,
+                              const uint8_t* scalars, uint64_t n, uint8_t* out_affine) {
+  if (!ctx || !base || (n && (!scalars || !out_affine)) || (group != 1 && group != 2)) return ARK355_EINVAL;
+  return guarded(ctx, [&] {
+    CtxExtra& ex = extra(ctx);
+    CURVE_DISPATCH(curve, A::fixed_base(ctx, ex.generic, group, base, scalars, n, out_affine));
+  });
+}
+
+int32_t ark355_get_timings(const ark355_ctx* ctx, ark355_timings* out) {
+  if (!ctx || !out) return ARK355_EINVAL;
+  *out = ctx->timings;
+  return ARK355_OK;
+}
+
+int32_t ark355_get_kernel_stats(const ark355_ctx* ctx, float* accumulate_ms, uint64_t* launches, uint64_t* points) {
+  if (!ctx) return ARK355_EINVAL;
+  if (accumulate_ms) *accumulate_ms = ctx->acc_ms;
+  if (launches) *launches = ctx->acc_launches;
+  if (points) *points = ctx->acc_points;
+  return ARK355_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,164 @@
+// Short-Weierstrass (a = 0) group arithmetic for G1 (over Fq) and G2 (over Fq2), host + device.
+//
+// Device-side replacement for the un-vendored ark-ec `short_weierstrass::{Affine, Projective}`
+// used by `VariableBaseMSM`.  Accumulators are kept in extended Jacobian
+// ("XYZZ": x = X/ZZ, y = Y/ZZZ, ZZ^3 = ZZZ^2) because the mixed addition is the cheapest known
+// inversion-free one (8M + 2S); results are normalised to affine, which is canonical, so the choice of
+// coordinates cannot change any output byte.
+//
+// Conventions: affine infinity is (0, 0) (not on either curve since b != 0); XYZZ infinity is ZZ == 0.
+#pragma once
+#include "field.cuh"
+
+namespace ark355 {
+
+template <class F>
+struct Affine {
+  F x, y;
+  ARK_HD bool is_inf() const { return x.is_zero() && y.is_zero(); }
+  ARK_HD static Affine inf() { return Affine{F::zero(), F::zero()}; }
+  ARK_HD static Affine neg(const Affine& p) { return Affine{p.x, F::neg(p.y)}; }
+};
+
+template <class F>
+struct XYZZ {
+  F x, y, zz, zzz;
+  ARK_HD bool is_inf() const { return zz.is_zero(); }
+  ARK_HD static XYZZ inf() { return XYZZ{F::zero(), F::zero(), F::zero(), F::zero()}; }
+  ARK_HD static XYZZ from_affine(const Affine<F>& p) {
+    if (p.is_inf()) return inf();
+    return XYZZ{p.x, p.y, F::one(), F::one()};
+  }
+  ARK_HD static XYZZ neg(const XYZZ& p) { return XYZZ{p.x, F::neg(p.y), p.zz, p.zzz}; }
+};
+
+// 2*P for affine P (mdbl-2008-s-1)
+template <class F>
+ARK_HD XYZZ<F> xyzz_dbl_affine(const Affine<F>& p) {
+  if (p.is_inf() || p.y.is_zero()) return XYZZ<F>::inf();
+  F U = F::mul2(p.y);
+  F V = F::sqr(U);
+  F W = F::mul(U, V);
+  F S = F::mul(p.x, V);
+  F M = F::mul3(F::sqr(p.x));
+  F X3 = F::sub(F::sqr(M), F::mul2(S));
+  F Y3 = F::sub(F::mul(M, F::sub(S, X3)), F::mul(W, p.y));
+  return XYZZ<F>{X3, Y3, V, W};
+}
+
+// 2*P (dbl-2008-s-1, a = 0)
+template <class F>
+ARK_HD XYZZ<F> xyzz_dbl(const XYZZ<F>& p) {
+  if (p.is_inf() || p.y.is_zero()) return XYZZ<F>::inf();
+  F U = F::mul2(p.y);
+  F V = F::sqr(U);
+  F W = F::mul(U, V);
+  F S = F::mul(p.x, V);
+  F M = F::mul3(F::sqr(p.x));
+  F X3 = F::sub(F::sqr(M), F::mul2(S));
+  F Y3 = F::sub(F::mul(M, F::sub(S, X3)), F::mul(W, p.y));
+  return XYZZ<F>{X3, Y3, F::mul(V, p.zz), F::mul(W, p.zzz)};
+}
+
+// acc += P, P affine (madd-2008-s); handles every special case.
+template <class F>
+ARK_HD void xyzz_madd(XYZZ<F>& acc, const Affine<F>& p) {
+  if (p.is_inf()) return;
+  if (acc.is_inf()) {
+    acc = XYZZ<F>{p.x, p.y, F::one(), F::one()};
+    return;
+  }
+  F U2 = F::mul(p.x, acc.zz);
+  F S2 = F::mul(p.y, acc.zzz);
+  F Pd = F::sub(U2, acc.x);
+  F R = F::sub(S2, acc.y);
+  if (Pd.is_zero()) {
+    if (R.is_zero()) {
+      acc = xyzz_dbl_affine(p);
+    } else {
+      acc = XYZZ<F>::inf();
+    }
+    return;
+  }
+  F PP = F::sqr(Pd);
+  F PPP = F::mul(Pd, PP);
+  F Q = F::mul(acc.x, PP);
+  F X3 = F::sub(F::sub(F::sqr(R), PPP), F::mul2(Q));
+  F Y3 = F::sub(F::mul(R, F::sub(Q, X3)), F::mul(acc.y, PPP));
+  acc.x = X3;
+  acc.y = Y3;
+  acc.zz = F::mul(acc.zz, PP);
+  acc.zzz = F::mul(acc.zzz, PPP);
+}
+
+// acc += (neg ? -P : P)
+template <class F>
+ARK_HD void xyzz_madd_signed(XYZZ<F>& acc, const Affine<F>& p, bool neg) {
+  Affine<F> q = p;
+  if (neg) q.y = F::neg(q.y);
+  xyzz_madd(acc, q);
+}
+
+// a + b (add-2008-s); handles every special case.
+template <class F>
+ARK_HD XYZZ<F> xyzz_add(const XYZZ<F>& a, const XYZZ<F>& b) {
+  if (a.is_inf()) return b;
+  if (b.is_inf()) return a;
+  F U1 = F::mul(a.x, b.zz);
+  F U2 = F::mul(b.x, a.zz);
+  F S1 = F::mul(a.y, b.zzz);
+  F S2 = F::mul(b.y, a.zzz);
+  F Pd = F::sub(U2, U1);
+  F R = F::sub(S2, S1);
+  if (Pd.is_zero()) {
+    if (R.is_zero()) return xyzz_dbl(a);
+    return XYZZ<F>::inf();
+  }
+  F PP = F::sqr(Pd);
+  F PPP = F::mul(Pd, PP);
+  F Q = F::mul(U1, PP);
+  F X3 = F::sub(F::sub(F::sqr(R), PPP), F::mul2(Q));
+  F Y3 = F::sub(F::mul(R, F::sub(Q, X3)), F::mul(S1, PPP));
+  F ZZ3 = F::mul(F::mul(a.zz, b.zz), PP);
+  F ZZZ3 = F::mul(F::mul(a.zzz, b.zzz), PPP);
+  return XYZZ<F>{X3, Y3, ZZ3, ZZZ3};
+}
+
+// canonical affine image (one field inversion)
+template <class F>
+ARK_HD Affine<F> xyzz_to_affine(const XYZZ<F>& p) {
+  if (p.is_inf()) return Affine<F>::inf();
+  F i3 = F::inv(p.zzz);           // 1/Z^3
+  F iz = F::mul(p.zz, i3);        // 1/Z
+  F i2 = F::sqr(iz);              // 1/Z^2
+  return Affine<F>{F::mul(p.x, i2), F::mul(p.y, i3)};
+}
+
+// k * P by double-and-add over a little-endian u32 scalar of `nlimbs` limbs (tails only).
+template <class F>
+ARK_HD XYZZ<F> xyzz_mul_scalar(const XYZZ<F>& p, const uint32_t* k, int nlimbs) {
+  XYZZ<F> acc = XYZZ<F>::inf();
+  bool started = false;
+  for (int i = nlimbs - 1; i >= 0; i--) {
+    uint32_t w = k[i];
+    for (int b = 31; b >= 0; b--) {
+      if (started) acc = xyzz_dbl(acc);
+      if ((w >> b) & 1) {
+        acc = xyzz_add(acc, p);
+        started = true;
+      }
+    }
+  }
+  return acc;
+}
+
+using BlsG1Affine = Affine<BlsFq>;
+using BlsG2Affine = Affine<BlsFq2>;
+using BlsG1 = XYZZ<BlsFq>;
+using BlsG2 = XYZZ<BlsFq2>;
+using BnG1Affine = Affine<BnFq>;
+using BnG2Affine = Affine<BnFq2>;
+using BnG1 = XYZZ<BnFq>;
+using BnG2 = XYZZ<BnFq2>;
+
+}  // namespace ark355

@@ -1,0 +1,234 @@
+// Montgomery prime-field arithmetic on 32-bit limbs for gfx950 (and the host side of the library).
+//
+// Replaces, on the device, what the un-vendored ark-ff `Fp<MontBackend<_, N>>` does on the CPU
+// (ark-ff/src/fields/models/fp/montgomery_backend.rs); the in-memory image is identical:
+// little-endian limbs of a*R mod p with R = 2^(64*N64) = 2^(32*N32), so buffers produced by the
+// arkworks host (SURVEY.md 8b "Numeric conventions") are consumed without conversion.
+//
+// CDNA4 has no 64x64 multiplier: the inner product is v_mad_u64_u32 (32x32+64 -> 64), hence
+// 32-bit limbs.  Everything is fully unrolled so limbs live in VGPRs.
+#pragma once
+#include <stdint.h>
+#include "hd.h"
+#include "curve_params.h"
+
+namespace ark355 {
+
+template <class P>
+struct Fp {
+  static constexpr int N = P::N;
+  using Params = P;
+  uint32_t l[N];
+
+  ARK_HD static Fp zero() {
+    Fp r;
+#pragma unroll
+    for (int i = 0; i < N; i++) r.l[i] = 0;
+    return r;
+  }
+  ARK_HD static Fp one() {
+    Fp r;
+#pragma unroll
+    for (int i = 0; i < N; i++) r.l[i] = P::one(i);
+    return r;
+  }
+  ARK_HD static Fp r2() {
+    Fp r;
+#pragma unroll
+    for (int i = 0; i < N; i++) r.l[i] = P::r2(i);
+    return r;
+  }
+  ARK_HD bool is_zero() const {
+    uint32_t acc = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) acc |= l[i];
+    return acc == 0;
+  }
+  ARK_HD bool operator==(const Fp& o) const {
+    uint32_t acc = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) acc |= (l[i] ^ o.l[i]);
+    return acc == 0;
+  }
+  ARK_HD bool operator!=(const Fp& o) const { return !(*this == o); }
+
+  // r = a - p if a >= p else a   (a < 2p)
+  ARK_HD static Fp reduce_once(const Fp& a, uint32_t top) {
+    Fp d;
+    uint64_t br = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+      uint64_t t = (uint64_t)a.l[i] - P::mod(i) - br;
+      d.l[i] = (uint32_t)t;
+      br = (t >> 32) & 1;
+    }
+    // a >= p  <=>  no final borrow, or the (N+1)-th limb `top` absorbs it
+    bool ge = (top != 0) || (br == 0);
+    Fp r;
+#pragma unroll
+    for (int i = 0; i < N; i++) r.l[i] = ge ? d.l[i] : a.l[i];
+    return r;
+  }
+
+  ARK_HD static Fp add(const Fp& a, const Fp& b) {
+    Fp s;
+    uint64_t c = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+      c += (uint64_t)a.l[i] + b.l[i];
+      s.l[i] = (uint32_t)c;
+      c >>= 32;
+    }
+    return reduce_once(s, (uint32_t)c);
+  }
+
+  ARK_HD static Fp sub(const Fp& a, const Fp& b) {
+    Fp d;
+    uint64_t br = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+      uint64_t t = (uint64_t)a.l[i] - b.l[i] - br;
+      d.l[i] = (uint32_t)t;
+      br = (t >> 32) & 1;
+    }
+    uint32_t mask = (uint32_t)0 - (uint32_t)br;
+    uint64_t c = 0;
+    Fp r;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+      c += (uint64_t)d.l[i] + (P::mod(i) & mask);
+      r.l[i] = (uint32_t)c;
+      c >>= 32;
+    }
+    return r;
+  }
+
+  ARK_HD static Fp neg(const Fp& a) {
+    if (a.is_zero()) return a;
+    Fp r;
+    uint64_t br = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+      uint64_t t = (uint64_t)P::mod(i) - a.l[i] - br;
+      r.l[i] = (uint32_t)t;
+      br = (t >> 32) & 1;
+    }
+    return r;
+  }
+
+  ARK_HD static Fp dbl(const Fp& a) { return add(a, a); }
+
+  // Montgomery product a*b*R^-1 mod p (CIOS, operand scanning).  The moduli used here all leave
+  // at least one spare bit in the top limb, so the running value fits in N+1 limbs.
+  ARK_HD static Fp mul(const Fp& a, const Fp& b) {
+    static_assert(P::BITS <= 32 * N - 1, "needs a spare top bit");
+    uint32_t t[N + 1];
+#pragma unroll
+    for (int i = 0; i <= N; i++) t[i] = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+      uint64_t c = 0;
+      const uint32_t bi = b.l[i];
+#pragma unroll
+      for (int j = 0; j < N; j++) {
+        uint64_t x = (uint64_t)a.l[j] * bi + t[j] + c;
+        t[j] = (uint32_t)x;
+        c = x >> 32;
+      }
+      uint64_t top = (uint64_t)t[N] + c;
+      const uint32_t m = t[0] * P::INV;
+      uint64_t x = (uint64_t)m * P::mod(0) + t[0];
+      c = x >> 32;
+#pragma unroll
+      for (int j = 1; j < N; j++) {
+        x = (uint64_t)m * P::mod(j) + t[j] + c;
+        t[j - 1] = (uint32_t)x;
+        c = x >> 32;
+      }
+      top += c;
+      t[N - 1] = (uint32_t)top;
+      t[N] = (uint32_t)(top >> 32);
+    }
+    Fp r;
+#pragma unroll
+    for (int i = 0; i < N; i++) r.l[i] = t[i];
+    return reduce_once(r, t[N]);
+  }
+
+  ARK_HD static Fp sqr(const Fp& a) { return mul(a, a); }
+
+  // a^(p-2): Fermat inversion (tails only; a hot path never inverts per element).
+  ARK_HD static Fp inv(const Fp& a) {
+    Fp result = one();
+    bool started = false;
+    for (int i = N - 1; i >= 0; i--) {
+      uint32_t w = P::pm2(i);
+      for (int b = 31; b >= 0; b--) {
+        if (started) result = sqr(result);
+        if ((w >> b) & 1) {
+          result = started ? mul(result, a) : a;
+          started = true;
+        }
+      }
+    }
+    return result;
+  }
+
+  // canonical integer <-> Montgomery image
+  ARK_HD static Fp to_mont(const Fp& canon) { return mul(canon, r2()); }
+  ARK_HD static Fp from_mont(const Fp& m) {
+    Fp o = zero();
+    o.l[0] = 1;
+    return mul(m, o);
+  }
+
+  // small-constant helpers
+  ARK_HD static Fp mul2(const Fp& a) { return add(a, a); }
+  ARK_HD static Fp mul3(const Fp& a) { return add(add(a, a), a); }
+};
+
+// Quadratic extension Fp[u]/(u^2 + 1) (BLS12-381 and BN254 both use non-residue -1).
+template <class P>
+struct Fp2 {
+  using Base = Fp<P>;
+  Base c0, c1;
+
+  ARK_HD static Fp2 zero() { return Fp2{Base::zero(), Base::zero()}; }
+  ARK_HD static Fp2 one() { return Fp2{Base::one(), Base::zero()}; }
+  ARK_HD bool is_zero() const { return c0.is_zero() && c1.is_zero(); }
+  ARK_HD bool operator==(const Fp2& o) const { return c0 == o.c0 && c1 == o.c1; }
+  ARK_HD bool operator!=(const Fp2& o) const { return !(*this == o); }
+  ARK_HD static Fp2 add(const Fp2& a, const Fp2& b) { return Fp2{Base::add(a.c0, b.c0), Base::add(a.c1, b.c1)}; }
+  ARK_HD static Fp2 sub(const Fp2& a, const Fp2& b) { return Fp2{Base::sub(a.c0, b.c0), Base::sub(a.c1, b.c1)}; }
+  ARK_HD static Fp2 neg(const Fp2& a) { return Fp2{Base::neg(a.c0), Base::neg(a.c1)}; }
+  ARK_HD static Fp2 dbl(const Fp2& a) { return add(a, a); }
+  ARK_HD static Fp2 mul2(const Fp2& a) { return add(a, a); }
+  ARK_HD static Fp2 mul3(const Fp2& a) { return add(add(a, a), a); }
+  // Karatsuba: 3 base multiplications
+  ARK_HD static Fp2 mul(const Fp2& a, const Fp2& b) {
+    Base v0 = Base::mul(a.c0, b.c0);
+    Base v1 = Base::mul(a.c1, b.c1);
+    Base s = Base::mul(Base::add(a.c0, a.c1), Base::add(b.c0, b.c1));
+    return Fp2{Base::sub(v0, v1), Base::sub(Base::sub(s, v0), v1)};
+  }
+  // (a0+a1)(a0-a1), 2 a0 a1
+  ARK_HD static Fp2 sqr(const Fp2& a) {
+    Base t = Base::mul(Base::add(a.c0, a.c1), Base::sub(a.c0, a.c1));
+    Base m = Base::mul(a.c0, a.c1);
+    return Fp2{t, Base::add(m, m)};
+  }
+  ARK_HD static Fp2 inv(const Fp2& a) {
+    Base n = Base::add(Base::sqr(a.c0), Base::sqr(a.c1));
+    Base ni = Base::inv(n);
+    return Fp2{Base::mul(a.c0, ni), Base::neg(Base::mul(a.c1, ni))};
+  }
+};
+
+using BlsFq = Fp<BlsFqParams>;
+using BlsFr = Fp<BlsFrParams>;
+using BlsFq2 = Fp2<BlsFqParams>;
+using BnFq = Fp<BnFqParams>;
+using BnFr = Fp<BnFrParams>;
+using BnFq2 = Fp2<BnFqParams>;
+
+}  // namespace ark355

@@ -1,0 +1,234 @@
+// Groth16 prover on the device: everything behind `SNARK::prove`
+// (/root/reference/snark/src/lib.rs:50-54) after synthesis -- the un-vendored ark-groth16
+// `create_proof_with_reduction_and_matrices` / `create_proof_with_assignment` (SURVEY.md 3.1, 3.2,
+// Appendix A "Proof").
+//
+// All constant terms are folded into the MSMs so that no 255-bit scalar multiplication of a fixed key
+// element is ever done on its own.  With the extended scalar vector
+//     zx = [ z_0 .. z_{m-1},  -r*s,  1,  r,  s ]                       (Montgomery Fr, device)
+// and base vectors extended at pk-load time by
+//     a_ext   = [ a_query,    O, alpha_1, delta_1, O       ]
+//     b1_ext  = [ b_g1_query, O, beta_1,  O,       delta_1 ]
+//     b2_ext  = [ b_g2_query, O, beta_2,  O,       delta_2 ]
+//     l_ext   = [ l_query, delta_1 ]                                   (scalars zx[ell .. m+1))
+// one gets  A = MSM(a_ext, zx), B1 = MSM(b1_ext, zx), B2 = MSM(b2_ext, zx) (ONE digit/sort pass shared
+// by the three), L' = MSM(l_ext, zx[ell..m+1)) = l_acc - r s delta_1, H = MSM(h_query, h[0..N-1)), and
+//     C = s*A + r*B1 + L' + H.
+// The only remaining sequential work is s*A and r*B1 (two 255-bit double-and-add chains, run in
+// parallel waves of the finalize kernel) and three affine normalisations.
+#pragma once
+#include "common.h"
+#include "msm_impl.cuh"
+#include "witness_impl.cuh"
+
+namespace ark355 {
+
+struct PkDev {
+  int curve = 0;
+  uint64_t ell = 0, w = 0, m = 0, N = 0;
+  DevBuf a_ext, b1_ext, b2_ext, h_query, l_ext;
+};
+
+struct ProverScratch {
+  MsmSort sort;
+  MsmBuckets bk1, bk2;
+  WitnessScratch ws;
+  DevBuf zx;        // extended scalar vector
+  DevBuf results;   // XYZZ results: A, B1, L, H (G1) then B2 (G2)
+  DevBuf proof;     // raw affine proof A | B | C
+  DevBuf rs;        // canonical r, s (2 x Fr)
+};
+
+// out layout (device): Affine<Fq> A | Affine<Fq2> B | Affine<Fq> C
+template <class Curve>
+__global__ void __launch_bounds__(192)
+groth16_finalize_kernel(const XYZZ<typename Curve::Fq>* __restrict__ g1res,   // A, B1, L', H
+                        const XYZZ<typename Curve::Fq2>* __restrict__ g2res,  // B2
+                        const typename Curve::Fr* __restrict__ rs_canon,      // r, s canonical
+                        unsigned char* __restrict__ out) {
+  using Fq = typename Curve::Fq;
+  using Fq2 = typename Curve::Fq2;
+  using Fr = typename Curve::Fr;
+  __shared__ uint32_t xch[2 * (sizeof(XYZZ<Fq>) / 4)];
+  constexpr int WORDS = sizeof(XYZZ<Fq>) / 4;
+  const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  Affine<Fq>* outA = reinterpret_cast<Affine<Fq>*>(out);
+  Affine<Fq2>* outB = reinterpret_cast<Affine<Fq2>*>(out + sizeof(Affine<Fq>));
+  Affine<Fq>* outC = reinterpret_cast<Affine<Fq>*>(out + sizeof(Affine<Fq>) + sizeof(Affine<Fq2>));
+  if (lane == 0) {
+    if (wave == 0) {
+      // s * A
+      Fr s = rs_canon[1];
+      XYZZ<Fq> sa = xyzz_mul_scalar(g1res[0], s.l, Fr::N);
+      const uint32_t* src = reinterpret_cast<const uint32_t*>(&sa);
+      for (int i = 0; i < WORDS; i++) xch[i] = src[i];
+    } else if (wave == 1) {
+      // r * B1
+      Fr r = rs_canon[0];
+      XYZZ<Fq> rb = xyzz_mul_scalar(g1res[1], r.l, Fr::N);
+      const uint32_t* src = reinterpret_cast<const uint32_t*>(&rb);
+      for (int i = 0; i < WORDS; i++) xch[WORDS + i] = src[i];
+    } else {
+      *outA = xyzz_to_affine(g1res[0]);
+      *outB = xyzz_to_affine(g2res[0]);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    XYZZ<Fq> sa, rb;
+    uint32_t* d0 = reinterpret_cast<uint32_t*>(&sa);
+    uint32_t* d1 = reinterpret_cast<uint32_t*>(&rb);
+    for (int i = 0; i < WORDS; i++) {
+      d0[i] = xch[i];
+      d1[i] = xch[WORDS + i];
+    }
+    XYZZ<Fq> c = xyzz_add(sa, rb);
+    c = xyzz_add(c, g1res[2]);
+    c = xyzz_add(c, g1res[3]);
+    *outC = xyzz_to_affine(c);
+  }
+}
+
+template <class Curve>
+static PkDev* pk_upload(const ark355_pk_desc* d) {
+  using Fq = typename Curve::Fq;
+  using Fq2 = typename Curve::Fq2;
+  constexpr size_t G1 = sizeof(Affine<Fq>), G2 = sizeof(Affine<Fq2>);
+  auto* pk = new PkDev();
+  try {
+    pk->curve = Curve::ID;
+    pk->ell = d->num_instance;
+    pk->w = d->num_witness;
+    pk->m = pk->ell + pk->w;
+    pk->N = d->domain_size;
+    ARK_REQUIRE(pk->ell >= 1 && pk->N >= 1 && (pk->N & (pk->N - 1)) == 0, ARK355_EINVAL, "bad pk dimensions");
+    ARK_REQUIRE(d->a_query && d->b_g1_query && d->b_g2_query && (d->h_query || pk->N == 1) && (d->l_query || pk->w == 0) &&
+                    d->alpha_g1 && d->beta_g1 && d->delta_g1 && d->beta_g2 && d->delta_g2,
+                ARK355_EINVAL, "null pointer in pk descriptor");
+    const uint64_t m = pk->m;
+    auto ext = [&](DevBuf& dst, const uint8_t* query, size_t psz, const uint8_t* t1, const uint8_t* t2, const uint8_t* t3) {
+      // [query (m), O, t1, t2, t3]; null tail pointers mean infinity
+      dst.alloc((m + 4) * psz);
+      ARK_CHECK_HIP(hipMemcpy(dst.p, query, m * psz, hipMemcpyHostToDevice));
+      std::vector<uint8_t> tail(4 * psz, 0);
+      if (t1) memcpy(tail.data() + 1 * psz, t1, psz);
+      if (t2) memcpy(tail.data() + 2 * psz, t2, psz);
+      if (t3) memcpy(tail.data() + 3 * psz, t3, psz);
+      ARK_CHECK_HIP(hipMemcpy((uint8_t*)dst.p + m * psz, tail.data(), 4 * psz, hipMemcpyHostToDevice));
+    };
+    ext(pk->a_ext, d->a_query, G1, d->alpha_g1, d->delta_g1, nullptr);
+    ext(pk->b1_ext, d->b_g1_query, G1, d->beta_g1, nullptr, d->delta_g1);
+    ext(pk->b2_ext, d->b_g2_query, G2, d->beta_g2, nullptr, d->delta_g2);
+    pk->h_query.alloc((pk->N ? pk->N - 1 : 0) * G1);
+    if (pk->N > 1) ARK_CHECK_HIP(hipMemcpy(pk->h_query.p, d->h_query, (pk->N - 1) * G1, hipMemcpyHostToDevice));
+    pk->l_ext.alloc((pk->w + 1) * G1);
+    if (pk->w) ARK_CHECK_HIP(hipMemcpy(pk->l_ext.p, d->l_query, pk->w * G1, hipMemcpyHostToDevice));
+    ARK_CHECK_HIP(hipMemcpy((uint8_t*)pk->l_ext.p + pk->w * G1, d->delta_g1, G1, hipMemcpyHostToDevice));
+  } catch (...) {
+    delete pk;
+    throw;
+  }
+  return pk;
+}
+
+// z_src: host or device pointer to m Fr (Montgomery); z_on_device selects the copy kind.
+template <class Curve>
+static void prove_run(ark355_ctx* ctx, ProverScratch& sc, const PkDev& pk, const R1csDev& r1, const void* z_src,
+                      bool z_on_device, const uint8_t r_canon[32], const uint8_t s_canon[32], ark355_proof_raw* out) {
+  using Fr = typename Curve::Fr;
+  using Fq = typename Curve::Fq;
+  using Fq2 = typename Curve::Fq2;
+  ARK_REQUIRE(pk.curve == Curve::ID && r1.curve == Curve::ID, ARK355_EINVAL, "curve mismatch");
+  ARK_REQUIRE(pk.ell == r1.ell && pk.w == r1.w && pk.N == r1.N, ARK355_EINVAL,
+              "proving key and R1CS dimensions differ");
+  hipStream_t st = ctx->stream;
+  const uint64_t m = pk.m, ell = pk.ell;
+  hipEvent_t ev[8];
+  for (auto& e : ev) ARK_CHECK_HIP(hipEventCreate(&e));
+  hipEvent_t acc0[5], acc1[5];
+  for (int i = 0; i < 5; i++) {
+    ARK_CHECK_HIP(hipEventCreate(&acc0[i]));
+    ARK_CHECK_HIP(hipEventCreate(&acc1[i]));
+  }
+  try {
+    // r, s -> Montgomery on the host (our own field code, not the oracle); tail = [-rs, 1, r, s]
+    Fr rc, scn;
+    memcpy(rc.l, r_canon, sizeof(Fr));
+    memcpy(scn.l, s_canon, sizeof(Fr));
+    Fr rm = Fr::to_mont(rc), sm = Fr::to_mont(scn);
+    Fr tail[4] = {Fr::neg(Fr::mul(rm, sm)), Fr::one(), rm, sm};
+    Fr rs_c[2] = {rc, scn};
+    sc.zx.ensure((m + 4) * sizeof(Fr));
+    sc.rs.ensure(2 * sizeof(Fr));
+    sc.results.ensure(4 * sizeof(XYZZ<Fq>) + sizeof(XYZZ<Fq2>));
+    sc.proof.ensure(2 * sizeof(Affine<Fq>) + sizeof(Affine<Fq2>));
+    ARK_CHECK_HIP(hipEventRecord(ev[0], st));
+    ARK_CHECK_HIP(hipMemcpyAsync(sc.zx.p, z_src, m * sizeof(Fr), z_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
+    ARK_CHECK_HIP(hipMemcpyAsync((uint8_t*)sc.zx.p + m * sizeof(Fr), tail, sizeof(tail), hipMemcpyHostToDevice, st));
+    ARK_CHECK_HIP(hipMemcpyAsync(sc.rs.p, rs_c, sizeof(rs_c), hipMemcpyHostToDevice, st));
+    ARK_CHECK_HIP(hipEventRecord(ev[1], st));
+    // witness map -> h
+    void* d_h = witness_map_run<Curve>(ctx, r1, sc.zx.p, sc.ws, st);
+    ARK_CHECK_HIP(hipEventRecord(ev[2], st));
+    XYZZ<Fq>* g1res = sc.results.as<XYZZ<Fq>>();
+    XYZZ<Fq2>* g2res = reinterpret_cast<XYZZ<Fq2>*>(g1res + 4);
+    // H = MSM(h_query, h[0..N-1))
+    msm_sort<Fr>(ctx, sc.sort, d_h, pk.N - 1, /*mont=*/1, st);
+    msm_buckets<Fq>(ctx, sc.sort, sc.bk1, pk.h_query.as<Affine<Fq>>(), g1res + 3, 0, st, acc0[0], acc1[0]);
+    uint64_t pts = (uint64_t)sc.sort.plan.windows * (pk.N - 1);
+    ARK_CHECK_HIP(hipEventRecord(ev[3], st));
+    // L' = MSM(l_ext, zx[ell .. m+1))
+    msm_sort<Fr>(ctx, sc.sort, (const uint8_t*)sc.zx.p + ell * sizeof(Fr), pk.w + 1, 1, st);
+    msm_buckets<Fq>(ctx, sc.sort, sc.bk1, pk.l_ext.as<Affine<Fq>>(), g1res + 2, 0, st, acc0[1], acc1[1]);
+    pts += (uint64_t)sc.sort.plan.windows * (pk.w + 1);
+    ARK_CHECK_HIP(hipEventRecord(ev[4], st));
+    // A, B1, B2 share one sort of zx[0 .. m+4)
+    msm_sort<Fr>(ctx, sc.sort, sc.zx.p, m + 4, 1, st);
+    msm_buckets<Fq>(ctx, sc.sort, sc.bk1, pk.a_ext.as<Affine<Fq>>(), g1res + 0, 0, st, acc0[2], acc1[2]);
+    msm_buckets<Fq>(ctx, sc.sort, sc.bk1, pk.b1_ext.as<Affine<Fq>>(), g1res + 1, 0, st, acc0[3], acc1[3]);
+    pts += 2 * (uint64_t)sc.sort.plan.windows * (m + 4);
+    ARK_CHECK_HIP(hipEventRecord(ev[5], st));
+    msm_buckets<Fq2>(ctx, sc.sort, sc.bk2, pk.b2_ext.as<Affine<Fq2>>(), g2res, 0, st, acc0[4], acc1[4]);
+    pts += (uint64_t)sc.sort.plan.windows * (m + 4);
+    ARK_CHECK_HIP(hipEventRecord(ev[6], st));
+    ARK_LAUNCH((groth16_finalize_kernel<Curve>), dim3(1), dim3(192), 0, st, (const XYZZ<Fq>*)g1res,
+               (const XYZZ<Fq2>*)g2res, sc.rs.as<Fr>(), sc.proof.as<unsigned char>());
+    ARK_CHECK_LAUNCH();
+    memset(out, 0, sizeof(*out));
+    ARK_CHECK_HIP(hipMemcpyAsync(out->a, sc.proof.p, sizeof(Affine<Fq>), hipMemcpyDeviceToHost, st));
+    ARK_CHECK_HIP(hipMemcpyAsync(out->b, (uint8_t*)sc.proof.p + sizeof(Affine<Fq>), sizeof(Affine<Fq2>), hipMemcpyDeviceToHost, st));
+    ARK_CHECK_HIP(hipMemcpyAsync(out->c, (uint8_t*)sc.proof.p + sizeof(Affine<Fq>) + sizeof(Affine<Fq2>), sizeof(Affine<Fq>), hipMemcpyDeviceToHost, st));
+    ARK_CHECK_HIP(hipEventRecord(ev[7], st));
+    ARK_CHECK_HIP(hipStreamSynchronize(st));
+    auto el = [&](int a, int b) {
+      float ms = 0;
+      (void)hipEventElapsedTime(&ms, ev[a], ev[b]);
+      return ms;
+    };
+    ctx->timings.total_ms = el(0, 7);
+    ctx->timings.h2d_ms = el(0, 1);
+    ctx->timings.witness_map_ms = el(1, 2);
+    ctx->timings.msm_h_ms = el(2, 3);
+    ctx->timings.msm_l_ms = el(3, 4);
+    ctx->timings.msm_ab_g1_ms = el(4, 5);
+    ctx->timings.msm_b_g2_ms = el(5, 6);
+    ctx->timings.finalize_ms = el(6, 7);
+    float acc_ms = 0;
+    for (int i = 0; i < 5; i++) {
+      float ms = 0;
+      (void)hipEventElapsedTime(&ms, acc0[i], acc1[i]);
+      acc_ms += ms;
+    }
+    ctx->acc_ms = acc_ms;
+    ctx->acc_launches = 5;
+    ctx->acc_points = pts;
+  } catch (...) {
+    for (auto& e : ev) (void)hipEventDestroy(e);
+    for (int i = 0; i < 5; i++) { (void)hipEventDestroy(acc0[i]); (void)hipEventDestroy(acc1[i]); }
+    throw;
+  }
+  for (auto& e : ev) (void)hipEventDestroy(e);
+  for (int i = 0; i < 5; i++) { (void)hipEventDestroy(acc0[i]); (void)hipEventDestroy(acc1[i]); }
+}
+
+}  // namespace ark355

@@ -1,0 +1,423 @@
+// Pippenger multi-scalar multiplication for gfx950 (G1 over Fq, G2 over Fq2; BLS12-381 and BN254).
+//
+// Device replacement for ark-ec `VariableBaseMSM::msm_bigint` (un-vendored crate,
+// ark-ec/src/scalar_mul/variable_base/mod.rs) as called five times by the Groth16 prover
+// (SURVEY.md 3.1 HOT LOOP #5).  Same mathematics -- signed c-bit window digits, bucket
+// accumulation, running-sum bucket reduction, window combination -- laid out for the GPU:
+//
+//   K2 digits      one thread per scalar: Montgomery -> canonical (optional), signed digits,
+//                  key = window*B + |d|-1, histogram of bucket sizes (global atomics, L2 resident)
+//   K3 sort        exclusive scan of the histogram + scatter = counting sort of (key, base index|sign)
+//   K4 accumulate  THE dominant kernel: the sorted entry list is cut into fixed segments of L
+//                  entries, one lane per segment, so every lane performs exactly L mixed additions
+//                  (XYZZ += affine) whatever the bucket-size distribution; runs that cover a whole
+//                  bucket are written straight to the bucket array, the at most two partial runs
+//                  per segment go to head/tail slots
+//      merge       one thread per bucket that straddles segments adds its partial runs
+//   K5 reduce      per window sum_b (b+1) B_b: every lane takes K consecutive buckets (running sum),
+//                  adds (first index)*S via a short double-and-add, then wave-wide butterfly
+//                  reduction with __shfl_xor, one partial per workgroup
+//      combine     lane w sums window w's partials, doubles it c*w times, __shfl_xor tree over windows
+//
+// Algorithmic bytes per term: 32 B scalar + affine base (G1 96 B / G2 192 B BLS12-381).
+#pragma once
+#include "common.h"
+
+namespace ark355 {
+
+constexpr uint32_t MSM_INVALID = 0xFFFFFFFFu;
+constexpr uint32_t MSM_SEG = 32;          // entries per accumulate lane
+constexpr uint32_t MSM_RED_K = 16;        // buckets per reduce lane
+constexpr uint32_t MSM_THREADS = 256;
+
+struct MsmPlan {
+  uint64_t n = 0;
+  uint32_t c = 0, windows = 0, buckets_per_window = 0, total_buckets = 0;
+  uint32_t scalar_bits = 0;
+};
+
+inline MsmPlan msm_plan(uint64_t n, uint32_t scalar_bits, int force_c = 0) {
+  MsmPlan p;
+  p.n = n;
+  p.scalar_bits = scalar_bits;
+  uint32_t lg = 0;
+  while ((1ull << (lg + 1)) <= (n ? n : 1)) lg++;
+  int c = (int)lg - 4;
+  if (c < 4) c = 4;
+  if (c > 16) c = 16;
+  if (force_c) c = force_c;
+  p.c = (uint32_t)c;
+  // one extra bit so that the top window never produces a carry
+  p.windows = (scalar_bits + 1 + p.c - 1) / p.c;
+  p.buckets_per_window = 1u << (p.c - 1);
+  p.total_buckets = p.windows * p.buckets_per_window;
+  return p;
+}
+
+// ---- K2: signed window digits + histogram ----------------------------------------------------------
+template <class Fr>
+__global__ void __launch_bounds__(MSM_THREADS)
+msm_digits_kernel(const Fr* __restrict__ scalars, uint32_t n, int mont, uint32_t c, uint32_t windows,
+                  uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, uint32_t* __restrict__ counts) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Fr k = scalars[i];
+  if (mont) k = Fr::from_mont(k);
+  const uint32_t B = 1u << (c - 1);
+  const uint32_t full = 1u << c;
+  uint32_t carry = 0;
+  for (uint32_t w = 0; w < windows; w++) {
+    const uint32_t bit = w * c;
+    const uint32_t limb = bit >> 5, off = bit & 31;
+    uint32_t d = 0;
+    if (limb < (uint32_t)Fr::N) {
+      uint64_t v = k.l[limb];
+      if (limb + 1 < (uint32_t)Fr::N) v |= (uint64_t)k.l[limb + 1] << 32;
+      d = (uint32_t)(v >> off) & (full - 1);
+    }
+    d += carry;
+    uint32_t neg = 0;
+    if (d > B) {
+      d = full - d;
+      neg = 1;
+      carry = 1;
+    } else {
+      carry = 0;
+    }
+    const uint64_t e = (uint64_t)w * n + i;
+    if (d == 0) {
+      keys[e] = MSM_INVALID;
+      vals[e] = 0;
+    } else {
+      const uint32_t key = w * B + d - 1;
+      keys[e] = key;
+      vals[e] = i | (neg << 31);
+      atomicAdd(&counts[key], 1u);
+    }
+  }
+}
+
+// ---- exclusive scan of `m` u32 counters by one workgroup ---------------------------------------------
+static __global__ void __launch_bounds__(1024)
+scan_exclusive_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, uint32_t m,
+                      uint32_t* __restrict__ total) {
+  __shared__ uint32_t part[1024];
+  const uint32_t tid = threadIdx.x, nth = blockDim.x;
+  const uint32_t chunk = (m + nth - 1) / nth;
+  const uint32_t lo = tid * chunk;
+  const uint32_t hi = (lo + chunk < m) ? lo + chunk : m;
+  uint32_t s = 0;
+  for (uint32_t i = lo; i < hi; i++) s += in[i];
+  part[tid] = s;
+  __syncthreads();
+  for (uint32_t d = 1; d < nth; d <<= 1) {
+    uint32_t v = (tid >= d) ? part[tid - d] : 0;
+    __syncthreads();
+    part[tid] += v;
+    __syncthreads();
+  }
+  uint32_t run = part[tid] - s;
+  for (uint32_t i = lo; i < hi; i++) {
+    const uint32_t v = in[i];
+    out[i] = run;
+    run += v;
+  }
+  if (tid == nth - 1 && total) *total = part[tid];
+}
+
+// ---- K3: scatter (counting sort) ----------------------------------------------------------------------
+static __global__ void __launch_bounds__(MSM_THREADS)
+msm_scatter_kernel(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals, uint64_t entries,
+                   const uint32_t* __restrict__ offsets, uint32_t* __restrict__ cursor,
+                   uint32_t* __restrict__ sorted_keys, uint32_t* __restrict__ sorted_vals) {
+  const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= entries) return;
+  const uint32_t key = keys[e];
+  if (key == MSM_INVALID) return;
+  const uint32_t pos = offsets[key] + atomicAdd(&cursor[key], 1u);
+  sorted_keys[pos] = key;
+  sorted_vals[pos] = vals[e];
+}
+
+// ---- K4: bucket accumulation -----------------------------------------------------------------------------
+template <class F>
+struct SegPartial {
+  XYZZ<F> pt;
+};
+
+template <class F>
+ARK_D void msm_flush_run(uint32_t key, const XYZZ<F>& acc, bool first_run, uint32_t run_start, uint32_t run_end,
+                         uint32_t seg, const uint32_t* offsets, const uint32_t* counts, XYZZ<F>* buckets,
+                         XYZZ<F>* head, uint32_t* head_key, XYZZ<F>* tail, uint32_t* tail_key) {
+  const uint32_t o = offsets[key], cnt = counts[key];
+  const bool complete = (run_start == o) && (run_end == o + cnt);
+  if (complete) {
+    buckets[key] = acc;
+  } else if (first_run) {
+    head[seg] = acc;
+    head_key[seg] = key;
+  } else {
+    tail[seg] = acc;
+    tail_key[seg] = key;
+  }
+}
+
+template <class F>
+__global__ void __launch_bounds__(MSM_THREADS)
+msm_accumulate_kernel(const Affine<F>* __restrict__ bases, const uint32_t* __restrict__ sorted_keys,
+                      const uint32_t* __restrict__ sorted_vals, const uint32_t* __restrict__ total_ptr,
+                      const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ counts,
+                      XYZZ<F>* __restrict__ buckets, XYZZ<F>* __restrict__ head, uint32_t* __restrict__ head_key,
+                      XYZZ<F>* __restrict__ tail, uint32_t* __restrict__ tail_key) {
+  const uint32_t seg = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t total = *total_ptr;
+  const uint64_t start64 = (uint64_t)seg * MSM_SEG;
+  if (start64 >= total) return;
+  const uint32_t start = (uint32_t)start64;
+  const uint32_t end = (start + MSM_SEG < total) ? start + MSM_SEG : total;
+  uint32_t cur_key = sorted_keys[start];
+  uint32_t run_start = start;
+  bool first_run = true;
+  XYZZ<F> acc = XYZZ<F>::inf();
+  for (uint32_t e = start; e < end; e++) {
+    const uint32_t key = sorted_keys[e];
+    if (key != cur_key) {
+      msm_flush_run<F>(cur_key, acc, first_run, run_start, e, seg, offsets, counts, buckets, head, head_key, tail,
+                       tail_key);
+      cur_key = key;
+      run_start = e;
+      first_run = false;
+      acc = XYZZ<F>::inf();
+    }
+    const uint32_t v = sorted_vals[e];
+    Affine<F> p = bases[v & 0x7FFFFFFFu];
+    if (v >> 31) p.y = F::neg(p.y);
+    xyzz_madd(acc, p);
+  }
+  msm_flush_run<F>(cur_key, acc, first_run, run_start, end, seg, offsets, counts, buckets, head, head_key, tail,
+                   tail_key);
+}
+
+// buckets whose entries straddle segment boundaries: add their partial runs
+template <class F>
+__global__ void __launch_bounds__(MSM_THREADS)
+msm_merge_kernel(uint32_t total_buckets, const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ counts,
+                 XYZZ<F>* __restrict__ buckets, const XYZZ<F>* __restrict__ head, const uint32_t* __restrict__ head_key,
+                 const XYZZ<F>* __restrict__ tail, const uint32_t* __restrict__ tail_key) {
+  const uint32_t key = blockIdx.x * blockDim.x + threadIdx.x;
+  if (key >= total_buckets) return;
+  const uint32_t cnt = counts[key];
+  if (cnt == 0) return;
+  const uint32_t o = offsets[key];
+  const uint32_t t0 = o / MSM_SEG, t1 = (o + cnt - 1) / MSM_SEG;
+  if (t0 == t1) return;   // the single run was complete and already written
+  XYZZ<F> sum = XYZZ<F>::inf();
+  for (uint32_t t = t0; t <= t1; t++) {
+    if (head_key[t] == key) sum = xyzz_add(sum, head[t]);
+    if (tail_key[t] == key) sum = xyzz_add(sum, tail[t]);
+  }
+  buckets[key] = sum;
+}
+
+// ---- wave-level reduction of XYZZ points with __shfl_xor ---------------------------------------------------
+template <class F>
+ARK_D XYZZ<F> xyzz_shfl_xor(const XYZZ<F>& p, int mask) {
+  XYZZ<F> r;
+  const uint32_t* src = reinterpret_cast<const uint32_t*>(&p);
+  uint32_t* dst = reinterpret_cast<uint32_t*>(&r);
+  constexpr int WORDS = sizeof(XYZZ<F>) / 4;
+#pragma unroll
+  for (int i = 0; i < WORDS; i++) dst[i] = (uint32_t)__shfl_xor((int)src[i], mask, 64);
+  return r;
+}
+
+template <class F>
+ARK_D XYZZ<F> wave_reduce_sum(XYZZ<F> v) {
+  for (int mask = 32; mask >= 1; mask >>= 1) {
+    XYZZ<F> o = xyzz_shfl_xor(v, mask);
+    v = xyzz_add(v, o);
+  }
+  return v;
+}
+
+// ---- K5: bucket reduction: per window sum_{b} (b+1) * bucket[b] -----------------------------------------------
+// grid.x = blocks per window, grid.y = windows.  Output: partials[window * gridDim.x + blockIdx.x].
+template <class F>
+__global__ void __launch_bounds__(MSM_THREADS)
+msm_reduce_kernel(const XYZZ<F>* __restrict__ buckets, uint32_t buckets_per_window, XYZZ<F>* __restrict__ partials) {
+  __shared__ uint32_t wave_out[(MSM_THREADS / 64) * (sizeof(XYZZ<F>) / 4)];
+  const uint32_t w = blockIdx.y;
+  const uint32_t chunk = blockIdx.x * blockDim.x + threadIdx.x;   // chunk index inside the window
+  const uint32_t first = chunk * MSM_RED_K;
+  XYZZ<F> contrib = XYZZ<F>::inf();
+  if (first < buckets_per_window) {
+    const uint32_t last = (first + MSM_RED_K < buckets_per_window) ? first + MSM_RED_K : buckets_per_window;
+    const XYZZ<F>* wb = buckets + (uint64_t)w * buckets_per_window;
+    XYZZ<F> running = XYZZ<F>::inf();
+    XYZZ<F> acc = XYZZ<F>::inf();
+    for (uint32_t b = last; b-- > first;) {
+      running = xyzz_add(running, wb[b]);
+      acc = xyzz_add(acc, running);
+    }
+    // acc = sum (b - first + 1) * bucket[b];  add first * running
+    if (first != 0 && !running.is_inf()) {
+      uint32_t k = first;
+      acc = xyzz_add(acc, xyzz_mul_scalar(running, &k, 1));
+    }
+    contrib = acc;
+  }
+  contrib = wave_reduce_sum(contrib);
+  constexpr int WORDS = sizeof(XYZZ<F>) / 4;
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) {
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(&contrib);
+    for (int i = 0; i < WORDS; i++) wave_out[wave * WORDS + i] = src[i];
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    XYZZ<F> sum = XYZZ<F>::inf();
+    for (uint32_t v = 0; v < blockDim.x / 64; v++) {
+      XYZZ<F> t;
+      uint32_t* dst = reinterpret_cast<uint32_t*>(&t);
+      for (int i = 0; i < WORDS; i++) dst[i] = wave_out[v * WORDS + i];
+      sum = xyzz_add(sum, t);
+    }
+    partials[w * gridDim.x + blockIdx.x] = sum;
+  }
+}
+
+// one wave: lane w -> 2^(c*w) * (sum of window w's partials); butterfly over lanes; lane 0 accumulates into *out
+template <class F>
+__global__ void __launch_bounds__(64)
+msm_combine_kernel(const XYZZ<F>* __restrict__ partials, uint32_t per_window, uint32_t windows, uint32_t c,
+                   XYZZ<F>* __restrict__ out, int accumulate) {
+  const uint32_t w = threadIdx.x;
+  XYZZ<F> v = XYZZ<F>::inf();
+  if (w < windows) {
+    for (uint32_t i = 0; i < per_window; i++) v = xyzz_add(v, partials[w * per_window + i]);
+    if (!v.is_inf()) {
+      const uint32_t dbl = c * w;
+      for (uint32_t i = 0; i < dbl; i++) v = xyzz_dbl(v);
+    }
+  }
+  v = wave_reduce_sum(v);
+  if (threadIdx.x == 0) {
+    if (accumulate) v = xyzz_add(v, *out);
+    *out = v;
+  }
+}
+
+// XYZZ -> affine for `count` points (one lane each)
+template <class F>
+__global__ void __launch_bounds__(64)
+xyzz_to_affine_kernel(const XYZZ<F>* __restrict__ in, Affine<F>* __restrict__ out, uint32_t count) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < count) out[i] = xyzz_to_affine(in[i]);
+}
+
+// sum of `count` XYZZ points -> out[0] (single wave; the cross-GPU combine of SURVEY 8e)
+template <class F>
+__global__ void __launch_bounds__(64)
+xyzz_sum_kernel(const XYZZ<F>* __restrict__ in, uint32_t count, XYZZ<F>* __restrict__ out) {
+  XYZZ<F> v = XYZZ<F>::inf();
+  for (uint32_t i = threadIdx.x; i < count; i += 64) v = xyzz_add(v, in[i]);
+  v = wave_reduce_sum(v);
+  if (threadIdx.x == 0) *out = v;
+}
+
+// ---- host driver ---------------------------------------------------------------------------------------------
+// Scratch for one MSM "sort" (shared by several accumulations over the same scalars).
+struct MsmSort {
+  MsmPlan plan;
+  DevBuf keys, vals, counts, offsets, cursor, sorted_keys, sorted_vals, total;
+  uint32_t max_segments = 0;
+};
+
+template <class Fr>
+static void msm_sort(ark355_ctx* ctx, MsmSort& s, const void* d_scalars, uint64_t n, int mont, hipStream_t stream,
+                     int force_c = 0) {
+  ARK_REQUIRE(n < (1ull << 31), ARK355_EINVAL, "MSM size must be < 2^31");
+  s.plan = msm_plan(n, Fr::Params::BITS, force_c);
+  const MsmPlan& p = s.plan;
+  const uint64_t entries = (uint64_t)p.windows * n;
+  ARK_REQUIRE(entries < (1ull << 32), ARK355_EINVAL, "MSM entry count must be < 2^32");
+  s.keys.ensure(entries * 4);
+  s.vals.ensure(entries * 4);
+  s.sorted_keys.ensure(entries * 4 + 16);
+  s.sorted_vals.ensure(entries * 4 + 16);
+  s.counts.ensure((size_t)p.total_buckets * 4);
+  s.offsets.ensure((size_t)p.total_buckets * 4);
+  s.cursor.ensure((size_t)p.total_buckets * 4);
+  s.total.ensure(16);
+  s.max_segments = (uint32_t)((entries + MSM_SEG - 1) / MSM_SEG);
+  if (n == 0) {
+    ARK_CHECK_HIP(hipMemsetAsync(s.total.p, 0, 4, stream));
+    ARK_CHECK_HIP(hipMemsetAsync(s.counts.p, 0, (size_t)p.total_buckets * 4, stream));
+    ARK_CHECK_HIP(hipMemsetAsync(s.offsets.p, 0, (size_t)p.total_buckets * 4, stream));
+    return;
+  }
+  ARK_CHECK_HIP(hipMemsetAsync(s.counts.p, 0, (size_t)p.total_buckets * 4, stream));
+  ARK_CHECK_HIP(hipMemsetAsync(s.cursor.p, 0, (size_t)p.total_buckets * 4, stream));
+  const uint32_t grid_n = (uint32_t)((n + MSM_THREADS - 1) / MSM_THREADS);
+  ARK_LAUNCH((msm_digits_kernel<Fr>), dim3(grid_n), dim3(MSM_THREADS), 0, stream, (const Fr*)d_scalars, (uint32_t)n,
+             mont, p.c, p.windows, s.keys.as<uint32_t>(), s.vals.as<uint32_t>(), s.counts.as<uint32_t>());
+  ARK_CHECK_LAUNCH();
+  ARK_LAUNCH(scan_exclusive_kernel, dim3(1), dim3(1024), 0, stream, s.counts.as<uint32_t>(),
+             s.offsets.as<uint32_t>(), p.total_buckets, s.total.as<uint32_t>());
+  ARK_CHECK_LAUNCH();
+  const uint32_t grid_e = (uint32_t)((entries + MSM_THREADS - 1) / MSM_THREADS);
+  ARK_LAUNCH(msm_scatter_kernel, dim3(grid_e), dim3(MSM_THREADS), 0, stream, s.keys.as<uint32_t>(),
+             s.vals.as<uint32_t>(), entries, s.offsets.as<uint32_t>(), s.cursor.as<uint32_t>(),
+             s.sorted_keys.as<uint32_t>(), s.sorted_vals.as<uint32_t>());
+  ARK_CHECK_LAUNCH();
+}
+
+// Scratch for the bucket phase of one group type.
+struct MsmBuckets {
+  DevBuf buckets, head, tail, head_key, tail_key, partials;
+};
+
+// Accumulate + reduce over an existing sort; writes/accumulates the XYZZ result into d_out (device).
+template <class F>
+static void msm_buckets(ark355_ctx* ctx, const MsmSort& s, MsmBuckets& b, const Affine<F>* d_bases, XYZZ<F>* d_out,
+                        int accumulate, hipStream_t stream, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr) {
+  const MsmPlan& p = s.plan;
+  if (p.n == 0) {
+    if (!accumulate) ARK_CHECK_HIP(hipMemsetAsync(d_out, 0, sizeof(XYZZ<F>), stream));
+    return;
+  }
+  const uint32_t segs = s.max_segments;
+  b.buckets.ensure((size_t)p.total_buckets * sizeof(XYZZ<F>));
+  b.head.ensure((size_t)segs * sizeof(XYZZ<F>));
+  b.tail.ensure((size_t)segs * sizeof(XYZZ<F>));
+  b.head_key.ensure((size_t)segs * 4);
+  b.tail_key.ensure((size_t)segs * 4);
+  ARK_CHECK_HIP(hipMemsetAsync(b.buckets.p, 0, (size_t)p.total_buckets * sizeof(XYZZ<F>), stream));
+  ARK_CHECK_HIP(hipMemsetAsync(b.head_key.p, 0xFF, (size_t)segs * 4, stream));
+  ARK_CHECK_HIP(hipMemsetAsync(b.tail_key.p, 0xFF, (size_t)segs * 4, stream));
+  const uint32_t grid_s = (segs + MSM_THREADS - 1) / MSM_THREADS;
+  if (ev0) ARK_CHECK_HIP(hipEventRecord(ev0, stream));
+  ARK_LAUNCH((msm_accumulate_kernel<F>), dim3(grid_s), dim3(MSM_THREADS), 0, stream, d_bases,
+             s.sorted_keys.as<uint32_t>(), s.sorted_vals.as<uint32_t>(), s.total.as<uint32_t>(),
+             s.offsets.as<uint32_t>(), s.counts.as<uint32_t>(), b.buckets.as<XYZZ<F>>(), b.head.as<XYZZ<F>>(),
+             b.head_key.as<uint32_t>(), b.tail.as<XYZZ<F>>(), b.tail_key.as<uint32_t>());
+  ARK_CHECK_LAUNCH();
+  if (ev1) ARK_CHECK_HIP(hipEventRecord(ev1, stream));
+  const uint32_t grid_b = (p.total_buckets + MSM_THREADS - 1) / MSM_THREADS;
+  ARK_LAUNCH((msm_merge_kernel<F>), dim3(grid_b), dim3(MSM_THREADS), 0, stream, p.total_buckets,
+             s.offsets.as<uint32_t>(), s.counts.as<uint32_t>(), b.buckets.as<XYZZ<F>>(), b.head.as<XYZZ<F>>(),
+             b.head_key.as<uint32_t>(), b.tail.as<XYZZ<F>>(), b.tail_key.as<uint32_t>());
+  ARK_CHECK_LAUNCH();
+  const uint32_t chunks = (p.buckets_per_window + MSM_RED_K - 1) / MSM_RED_K;
+  const uint32_t blocks_per_window = (chunks + MSM_THREADS - 1) / MSM_THREADS;
+  b.partials.ensure((size_t)blocks_per_window * p.windows * sizeof(XYZZ<F>));
+  ARK_LAUNCH((msm_reduce_kernel<F>), dim3(blocks_per_window, p.windows), dim3(MSM_THREADS), 0, stream,
+             b.buckets.as<XYZZ<F>>(), p.buckets_per_window, b.partials.as<XYZZ<F>>());
+  ARK_CHECK_LAUNCH();
+  ARK_REQUIRE(p.windows <= 64, ARK355_EINVAL, "window count exceeds one wave");
+  ARK_LAUNCH((msm_combine_kernel<F>), dim3(1), dim3(64), 0, stream, b.partials.as<XYZZ<F>>(), blocks_per_window,
+             p.windows, p.c, d_out, accumulate);
+  ARK_CHECK_LAUNCH();
+}
+
+}  // namespace ark355

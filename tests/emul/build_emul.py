@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""TEST INFRASTRUCTURE: build tests/emul/libark355_emul.so -- the library's own sources compiled with
+g++ -DARK_EMUL against the single-threaded HIP emulator (hip_emul.h).  Used only by
+`pytest -m "not gpu"` to exercise kernel/orchestration logic without a GPU; never loaded by snark_amd."""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.normpath(os.path.join(HERE, "..", ".."))
+CSRC = os.path.join(ROOT, "snark_amd", "csrc")
+OUT = os.path.join(HERE, "libark355_emul.so")
+SRCS = [os.path.join(CSRC, f) for f in ("capi.hip", "ark355_bls.hip", "ark355_bn.hip")] + [
+    os.path.join(HERE, "hip_emul.cpp")]
+
+
+def newest_src():
+    t = 0
+    for d in (CSRC, HERE, os.path.join(ROOT, "include")):
+        for f in os.listdir(d):
+            if f.endswith((".h", ".cuh", ".hip", ".cpp")):
+                t = max(t, os.path.getmtime(os.path.join(d, f)))
+    return t
+
+
+def build(force=False):
+    if not force and os.path.exists(OUT) and os.path.getmtime(OUT) >= newest_src():
+        return OUT
+    objs = []
+    flags = ["-O1", "-g", "-std=c++17", "-fPIC", "-DARK_EMUL", "-I", HERE, "-I", CSRC, "-w"]
+
+    def cc(src):
+        obj = os.path.join(HERE, os.path.basename(src) + ".emul.o")
+        subprocess.check_call(["g++", "-x", "c++", *flags, "-c", src, "-o", obj])
+        return obj
+
+    with ThreadPoolExecutor(4) as ex:
+        objs = list(ex.map(cc, SRCS))
+    subprocess.check_call(["g++", "-shared", "-o", OUT, *objs, "-lpthread"])
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv))
