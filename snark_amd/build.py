@@ -1,0 +1,75 @@
+"""Build libark355.so (hipcc, gfx950 only) in-tree: snark_amd/libark355.so.
+
+`python -m snark_amd.build [--force]`.  hipcc cross-compiles without a GPU; the .so is git-ignored but
+travels to the GPU box with the gpurun snapshot.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+INCLUDE = os.path.normpath(os.path.join(HERE, "..", "include"))
+OUT = os.path.join(HERE, "libark355.so")
+OBJDIR = os.path.join(HERE, "build")
+SOURCES = ["capi.hip", "ark355_bls.hip", "ark355_bn.hip"]
+ARCH = "gfx950"
+FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-DNDEBUG", "-Wno-unused-result"]
+
+
+def hipcc():
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(exe):
+        raise RuntimeError("hipcc not found: libark355 is built for gfx950 only and has no CPU fallback")
+    return exe
+
+
+def _newest_source():
+    t = 0.0
+    for d in (CSRC, INCLUDE):
+        for f in os.listdir(d):
+            if f.endswith((".h", ".cuh", ".hip", ".cpp")):
+                t = max(t, os.path.getmtime(os.path.join(d, f)))
+    return t
+
+
+def is_fresh():
+    return os.path.exists(OUT) and os.path.getmtime(OUT) >= _newest_source()
+
+
+def build(force=False, verbose=True, resource_log=False):
+    if not force and is_fresh():
+        return OUT
+    os.makedirs(OBJDIR, exist_ok=True)
+    cc = hipcc()
+
+    def compile_one(src):
+        obj = os.path.join(OBJDIR, src + ".o")
+        cmd = [cc, *FLAGS, "-I", CSRC, "-c", os.path.join(CSRC, src), "-o", obj]
+        if resource_log:
+            cmd.append("-Rpass-analysis=kernel-resource-usage")
+        if verbose:
+            print("[snark_amd.build]", " ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if resource_log:
+            with open(os.path.join(OBJDIR, src + ".resources.log"), "w") as f:
+                f.write(r.stderr)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed for %s:\n%s" % (src, r.stderr[-4000:]))
+        return obj
+
+    with ThreadPoolExecutor(len(SOURCES)) as ex:
+        objs = list(ex.map(compile_one, SOURCES))
+    cmd = [cc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", OUT, *objs]
+    if verbose:
+        print("[snark_amd.build]", " ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, resource_log="--resources" in sys.argv))

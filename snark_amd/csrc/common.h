@@ -2,6 +2,8 @@
 #pragma once
 #include <stdint.h>
 #include <stddef.h>
+#include <string.h>
+#include <cstring>
 #include <map>
 #include <mutex>
 #include <string>

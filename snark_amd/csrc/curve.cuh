@@ -7,10 +7,25 @@
 // coordinates cannot change any output byte.
 //
 // Conventions: affine infinity is (0, 0) (not on either curve since b != 0); XYZZ infinity is ZZ == 0.
+//
+// Every formula exists in two instantiations: NI = false inlines the field multiplications (the hot
+// bucket-accumulation kernel), NI = true calls the out-of-line field routines and is itself wrapped in
+// out-of-line functions (`*_ni`) for the cold kernels.
 #pragma once
 #include "field.cuh"
 
 namespace ark355 {
+
+template <bool NI, class F>
+ARK_HD F fmul(const F& a, const F& b) {
+  if constexpr (NI) return F::mul_ni(a, b);
+  else return F::mul(a, b);
+}
+template <bool NI, class F>
+ARK_HD F fsqr(const F& a) {
+  if constexpr (NI) return F::sqr_ni(a);
+  else return F::sqr(a);
+}
 
 template <class F>
 struct Affine {
@@ -33,110 +48,122 @@ struct XYZZ {
 };
 
 // 2*P for affine P (mdbl-2008-s-1)
-template <class F>
-ARK_HD XYZZ<F> xyzz_dbl_affine(const Affine<F>& p) {
+template <bool NI, class F>
+ARK_HD XYZZ<F> xyzz_dbl_affine_t(const Affine<F>& p) {
   if (p.is_inf() || p.y.is_zero()) return XYZZ<F>::inf();
   F U = F::mul2(p.y);
-  F V = F::sqr(U);
-  F W = F::mul(U, V);
-  F S = F::mul(p.x, V);
-  F M = F::mul3(F::sqr(p.x));
-  F X3 = F::sub(F::sqr(M), F::mul2(S));
-  F Y3 = F::sub(F::mul(M, F::sub(S, X3)), F::mul(W, p.y));
+  F V = fsqr<NI>(U);
+  F W = fmul<NI>(U, V);
+  F S = fmul<NI>(p.x, V);
+  F M = F::mul3(fsqr<NI>(p.x));
+  F X3 = F::sub(fsqr<NI>(M), F::mul2(S));
+  F Y3 = F::sub(fmul<NI>(M, F::sub(S, X3)), fmul<NI>(W, p.y));
   return XYZZ<F>{X3, Y3, V, W};
 }
 
 // 2*P (dbl-2008-s-1, a = 0)
-template <class F>
-ARK_HD XYZZ<F> xyzz_dbl(const XYZZ<F>& p) {
+template <bool NI, class F>
+ARK_HD XYZZ<F> xyzz_dbl_t(const XYZZ<F>& p) {
   if (p.is_inf() || p.y.is_zero()) return XYZZ<F>::inf();
   F U = F::mul2(p.y);
-  F V = F::sqr(U);
-  F W = F::mul(U, V);
-  F S = F::mul(p.x, V);
-  F M = F::mul3(F::sqr(p.x));
-  F X3 = F::sub(F::sqr(M), F::mul2(S));
-  F Y3 = F::sub(F::mul(M, F::sub(S, X3)), F::mul(W, p.y));
-  return XYZZ<F>{X3, Y3, F::mul(V, p.zz), F::mul(W, p.zzz)};
+  F V = fsqr<NI>(U);
+  F W = fmul<NI>(U, V);
+  F S = fmul<NI>(p.x, V);
+  F M = F::mul3(fsqr<NI>(p.x));
+  F X3 = F::sub(fsqr<NI>(M), F::mul2(S));
+  F Y3 = F::sub(fmul<NI>(M, F::sub(S, X3)), fmul<NI>(W, p.y));
+  return XYZZ<F>{X3, Y3, fmul<NI>(V, p.zz), fmul<NI>(W, p.zzz)};
 }
 
 // acc += P, P affine (madd-2008-s); handles every special case.
-template <class F>
-ARK_HD void xyzz_madd(XYZZ<F>& acc, const Affine<F>& p) {
+template <bool NI, class F>
+ARK_HD void xyzz_madd_t(XYZZ<F>& acc, const Affine<F>& p) {
   if (p.is_inf()) return;
   if (acc.is_inf()) {
     acc = XYZZ<F>{p.x, p.y, F::one(), F::one()};
     return;
   }
-  F U2 = F::mul(p.x, acc.zz);
-  F S2 = F::mul(p.y, acc.zzz);
+  F U2 = fmul<NI>(p.x, acc.zz);
+  F S2 = fmul<NI>(p.y, acc.zzz);
   F Pd = F::sub(U2, acc.x);
   F R = F::sub(S2, acc.y);
   if (Pd.is_zero()) {
     if (R.is_zero()) {
-      acc = xyzz_dbl_affine(p);
+      acc = xyzz_dbl_affine_t<true>(p);     // rare: always the out-of-line flavour
     } else {
       acc = XYZZ<F>::inf();
     }
     return;
   }
-  F PP = F::sqr(Pd);
-  F PPP = F::mul(Pd, PP);
-  F Q = F::mul(acc.x, PP);
-  F X3 = F::sub(F::sub(F::sqr(R), PPP), F::mul2(Q));
-  F Y3 = F::sub(F::mul(R, F::sub(Q, X3)), F::mul(acc.y, PPP));
+  F PP = fsqr<NI>(Pd);
+  F PPP = fmul<NI>(Pd, PP);
+  F Q = fmul<NI>(acc.x, PP);
+  F X3 = F::sub(F::sub(fsqr<NI>(R), PPP), F::mul2(Q));
+  F Y3 = F::sub(fmul<NI>(R, F::sub(Q, X3)), fmul<NI>(acc.y, PPP));
   acc.x = X3;
   acc.y = Y3;
-  acc.zz = F::mul(acc.zz, PP);
-  acc.zzz = F::mul(acc.zzz, PPP);
-}
-
-// acc += (neg ? -P : P)
-template <class F>
-ARK_HD void xyzz_madd_signed(XYZZ<F>& acc, const Affine<F>& p, bool neg) {
-  Affine<F> q = p;
-  if (neg) q.y = F::neg(q.y);
-  xyzz_madd(acc, q);
+  acc.zz = fmul<NI>(acc.zz, PP);
+  acc.zzz = fmul<NI>(acc.zzz, PPP);
 }
 
 // a + b (add-2008-s); handles every special case.
-template <class F>
-ARK_HD XYZZ<F> xyzz_add(const XYZZ<F>& a, const XYZZ<F>& b) {
+template <bool NI, class F>
+ARK_HD XYZZ<F> xyzz_add_t(const XYZZ<F>& a, const XYZZ<F>& b) {
   if (a.is_inf()) return b;
   if (b.is_inf()) return a;
-  F U1 = F::mul(a.x, b.zz);
-  F U2 = F::mul(b.x, a.zz);
-  F S1 = F::mul(a.y, b.zzz);
-  F S2 = F::mul(b.y, a.zzz);
+  F U1 = fmul<NI>(a.x, b.zz);
+  F U2 = fmul<NI>(b.x, a.zz);
+  F S1 = fmul<NI>(a.y, b.zzz);
+  F S2 = fmul<NI>(b.y, a.zzz);
   F Pd = F::sub(U2, U1);
   F R = F::sub(S2, S1);
   if (Pd.is_zero()) {
-    if (R.is_zero()) return xyzz_dbl(a);
+    if (R.is_zero()) return xyzz_dbl_t<true>(a);
     return XYZZ<F>::inf();
   }
-  F PP = F::sqr(Pd);
-  F PPP = F::mul(Pd, PP);
-  F Q = F::mul(U1, PP);
-  F X3 = F::sub(F::sub(F::sqr(R), PPP), F::mul2(Q));
-  F Y3 = F::sub(F::mul(R, F::sub(Q, X3)), F::mul(S1, PPP));
-  F ZZ3 = F::mul(F::mul(a.zz, b.zz), PP);
-  F ZZZ3 = F::mul(F::mul(a.zzz, b.zzz), PPP);
+  F PP = fsqr<NI>(Pd);
+  F PPP = fmul<NI>(Pd, PP);
+  F Q = fmul<NI>(U1, PP);
+  F X3 = F::sub(F::sub(fsqr<NI>(R), PPP), F::mul2(Q));
+  F Y3 = F::sub(fmul<NI>(R, F::sub(Q, X3)), fmul<NI>(S1, PPP));
+  F ZZ3 = fmul<NI>(fmul<NI>(a.zz, b.zz), PP);
+  F ZZZ3 = fmul<NI>(fmul<NI>(a.zzz, b.zzz), PPP);
   return XYZZ<F>{X3, Y3, ZZ3, ZZZ3};
+}
+
+// ---- hot (inlined) flavour: the bucket-accumulation kernel ------------------------------------------
+template <class F>
+ARK_HD void xyzz_madd(XYZZ<F>& acc, const Affine<F>& p) {
+  xyzz_madd_t<false>(acc, p);
+}
+
+// ---- cold (out-of-line) flavours -------------------------------------------------------------------------
+template <class F>
+ARK_HD_NOINLINE void xyzz_madd_ni(XYZZ<F>& acc, const Affine<F>& p) {
+  xyzz_madd_t<true>(acc, p);
+}
+template <class F>
+ARK_HD_NOINLINE XYZZ<F> xyzz_add(const XYZZ<F>& a, const XYZZ<F>& b) {
+  return xyzz_add_t<true>(a, b);
+}
+template <class F>
+ARK_HD_NOINLINE XYZZ<F> xyzz_dbl(const XYZZ<F>& p) {
+  return xyzz_dbl_t<true>(p);
 }
 
 // canonical affine image (one field inversion)
 template <class F>
-ARK_HD Affine<F> xyzz_to_affine(const XYZZ<F>& p) {
+ARK_HD_NOINLINE Affine<F> xyzz_to_affine(const XYZZ<F>& p) {
   if (p.is_inf()) return Affine<F>::inf();
-  F i3 = F::inv(p.zzz);           // 1/Z^3
-  F iz = F::mul(p.zz, i3);        // 1/Z
-  F i2 = F::sqr(iz);              // 1/Z^2
-  return Affine<F>{F::mul(p.x, i2), F::mul(p.y, i3)};
+  F i3 = F::inv(p.zzz);               // 1/Z^3
+  F iz = F::mul_ni(p.zz, i3);         // 1/Z
+  F i2 = F::sqr_ni(iz);               // 1/Z^2
+  return Affine<F>{F::mul_ni(p.x, i2), F::mul_ni(p.y, i3)};
 }
 
 // k * P by double-and-add over a little-endian u32 scalar of `nlimbs` limbs (tails only).
 template <class F>
-ARK_HD XYZZ<F> xyzz_mul_scalar(const XYZZ<F>& p, const uint32_t* k, int nlimbs) {
+ARK_HD_NOINLINE XYZZ<F> xyzz_mul_scalar(const XYZZ<F>& p, const uint32_t* k, int nlimbs) {
   XYZZ<F> acc = XYZZ<F>::inf();
   bool started = false;
   for (int i = nlimbs - 1; i >= 0; i--) {

@@ -157,16 +157,21 @@ struct Fp {
 
   ARK_HD static Fp sqr(const Fp& a) { return mul(a, a); }
 
+  // Out-of-line copies for the cold kernels (reduction tails, normalisation, setup): one ~1.5k
+  // instruction body per field instead of one per call site keeps code size and compile time sane.
+  ARK_HD_NOINLINE static Fp mul_ni(const Fp& a, const Fp& b) { return mul(a, b); }
+  ARK_HD static Fp sqr_ni(const Fp& a) { return mul_ni(a, a); }
+
   // a^(p-2): Fermat inversion (tails only; a hot path never inverts per element).
-  ARK_HD static Fp inv(const Fp& a) {
+  ARK_HD_NOINLINE static Fp inv(const Fp& a) {
     Fp result = one();
     bool started = false;
     for (int i = N - 1; i >= 0; i--) {
       uint32_t w = P::pm2(i);
       for (int b = 31; b >= 0; b--) {
-        if (started) result = sqr(result);
+        if (started) result = mul_ni(result, result);
         if ((w >> b) & 1) {
-          result = started ? mul(result, a) : a;
+          result = started ? mul_ni(result, a) : a;
           started = true;
         }
       }
@@ -175,11 +180,11 @@ struct Fp {
   }
 
   // canonical integer <-> Montgomery image
-  ARK_HD static Fp to_mont(const Fp& canon) { return mul(canon, r2()); }
+  ARK_HD static Fp to_mont(const Fp& canon) { return mul_ni(canon, r2()); }
   ARK_HD static Fp from_mont(const Fp& m) {
     Fp o = zero();
     o.l[0] = 1;
-    return mul(m, o);
+    return mul_ni(m, o);
   }
 
   // small-constant helpers
@@ -217,10 +222,21 @@ struct Fp2 {
     Base m = Base::mul(a.c0, a.c1);
     return Fp2{t, Base::add(m, m)};
   }
-  ARK_HD static Fp2 inv(const Fp2& a) {
-    Base n = Base::add(Base::sqr(a.c0), Base::sqr(a.c1));
+  ARK_HD_NOINLINE static Fp2 mul_ni(const Fp2& a, const Fp2& b) {
+    Base v0 = Base::mul_ni(a.c0, b.c0);
+    Base v1 = Base::mul_ni(a.c1, b.c1);
+    Base s = Base::mul_ni(Base::add(a.c0, a.c1), Base::add(b.c0, b.c1));
+    return Fp2{Base::sub(v0, v1), Base::sub(Base::sub(s, v0), v1)};
+  }
+  ARK_HD_NOINLINE static Fp2 sqr_ni(const Fp2& a) {
+    Base t = Base::mul_ni(Base::add(a.c0, a.c1), Base::sub(a.c0, a.c1));
+    Base m = Base::mul_ni(a.c0, a.c1);
+    return Fp2{t, Base::add(m, m)};
+  }
+  ARK_HD_NOINLINE static Fp2 inv(const Fp2& a) {
+    Base n = Base::add(Base::sqr_ni(a.c0), Base::sqr_ni(a.c1));
     Base ni = Base::inv(n);
-    return Fp2{Base::mul(a.c0, ni), Base::neg(Base::mul(a.c1, ni))};
+    return Fp2{Base::mul_ni(a.c0, ni), Base::neg(Base::mul_ni(a.c1, ni))};
   }
 };
 

@@ -8,7 +8,7 @@
 #if defined(ARK_EMUL)
 #include "hip_emul.h"
 #define ARK_HD inline
-#define ARK_HD_NOINLINE
+#define ARK_HD_NOINLINE __attribute__((noinline))
 #define ARK_D inline
 #define ARK_LAUNCH(kernel, grid, block, smem, stream, ...) \
   emu::launch((grid), (block), (smem), [&]() { kernel(__VA_ARGS__); })
@@ -26,6 +26,6 @@
 #else
 // plain host translation unit (no kernels): arithmetic headers only
 #define ARK_HD inline
-#define ARK_HD_NOINLINE
+#define ARK_HD_NOINLINE __attribute__((noinline))
 #define ARK_D inline
 #endif

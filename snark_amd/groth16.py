@@ -1,0 +1,299 @@
+"""Host-side mirror of the reference's trait surface for the Groth16 path, over the C ABI.
+
+Mirrors ``ark_snark::SNARK`` (/root/reference/snark/src/lib.rs:22-81) for one implementor,
+``Groth16``:
+
+* ``circuit_specific_setup``  (lib.rs:43-46, :87-92)  -> host computes the QAP scalars
+  (u_i(tau), v_i(tau), w_i(tau), ...; SURVEY.md Appendix A "Setup"), the device performs the
+  fixed-base multiplications (``ark355_fixed_base_mul``);
+* ``prove``                   (lib.rs:50-54)           -> ``ark355_prove`` (the hot path);
+* ``verify`` / ``process_vk`` (lib.rs:59-80)           -> not part of the accelerated path; the
+  arkworks host keeps its own CPU verifier (the proofs are byte-compatible).  Raises here.
+
+Inputs come from the unchanged ``ark-relations`` constraint system on the host:
+``R1CS.from_rows`` takes exactly what ``ConstraintSystem::to_matrices()["R1CS"]`` returns
+(/root/reference/relations/src/gr1cs/constraint_system.rs:768-774; ``Matrix<F> = Vec<Vec<(F, usize)>>``,
+utils/matrix.rs:4) and ``z`` is ``instance_assignment || witness_assignment``
+(constraint_system.rs:193-206).  Error behaviour follows ``SynthesisError`` (utils/error.rs:5-21).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import lib as _lib
+from ._binding import Ark355Error
+from .params import Curve, CURVES
+
+
+class SynthesisError(Exception):
+    """Mirror of ark_relations::utils::error::SynthesisError (utils/error.rs:5-21)."""
+
+
+@dataclass
+class R1CS:
+    """CSR image of the three R1CS matrices (column convention utils/variable.rs:105-113)."""
+    curve: Curve
+    n: int
+    ell: int
+    w: int
+    row_ptr: Tuple[np.ndarray, np.ndarray, np.ndarray]
+    col: Tuple[np.ndarray, np.ndarray, np.ndarray]
+    coeff: Tuple[bytes, bytes, bytes]          # Montgomery Fr images, 32 B per non-zero
+    coeff_int: Optional[Tuple[list, list, list]] = None   # canonical ints (setup needs them)
+
+    @staticmethod
+    def from_rows(curve: Curve, A, B, C, ell: int, w: int) -> "R1CS":
+        """A, B, C: Vec<Vec<(F, usize)>> with F as canonical Python ints."""
+        rps, cols, cfs, cis = [], [], [], []
+        for M in (A, B, C):
+            rp = np.zeros(len(M) + 1, dtype=np.uint64)
+            cl, cf, ci = [], [], []
+            k = 0
+            for i, row in enumerate(M):
+                for c, j in row:
+                    cl.append(j)
+                    ci.append(c % curve.r)
+                    cf.append(curve.fr_mont(c))
+                    k += 1
+                rp[i + 1] = k
+            rps.append(rp)
+            cols.append(np.array(cl, dtype=np.uint32))
+            cfs.append(b"".join(cf))
+            cis.append(ci)
+        return R1CS(curve, len(A), ell, w, tuple(rps), tuple(cols), tuple(cfs), tuple(cis))
+
+    @property
+    def m(self):
+        return self.ell + self.w
+
+    @property
+    def domain_size(self):
+        need = self.n + self.ell
+        N = 1
+        while N < need:
+            N <<= 1
+        return N
+
+
+@dataclass
+class VerifyingKey:
+    alpha_g1: bytes
+    beta_g2: bytes
+    gamma_g2: bytes
+    delta_g2: bytes
+    gamma_abc_g1: bytes        # ell raw G1 points
+
+
+@dataclass
+class ProvingKey:
+    vk: VerifyingKey
+    beta_g1: bytes
+    delta_g1: bytes
+    a_query: bytes
+    b_g1_query: bytes
+    b_g2_query: bytes
+    h_query: bytes
+    l_query: bytes
+    ell: int
+    w: int
+    N: int
+    # retained only when setup is asked to keep the toxic waste (tests / benches: closed-form check)
+    trapdoor: Optional[dict] = None
+
+
+@dataclass
+class Proof:
+    """Raw affine points (Montgomery images); `ark_groth16::Proof {a, b, c}`."""
+    a: bytes
+    b: bytes
+    c: bytes
+
+
+def _batch_inverse(vals, p):
+    pref, acc = [], 1
+    for v in vals:
+        acc = acc * v % p
+        pref.append(acc)
+    inv = pow(acc, -1, p)
+    out = [0] * len(vals)
+    for i in range(len(vals) - 1, -1, -1):
+        prev = pref[i - 1] if i else 1
+        out[i] = inv * prev % p
+        inv = inv * vals[i] % p
+    return out
+
+
+def _lagrange_at(curve: Curve, log_n: int, tau: int):
+    """[L_k(tau)] over the radix-2 domain H of size 2^log_n."""
+    r = curve.r
+    n = 1 << log_n
+    omega = curve.root_of_unity(log_n)
+    zt = (pow(tau, n, r) - 1) % r
+    ws, w = [], 1
+    for _ in range(n):
+        ws.append(w)
+        w = w * omega % r
+    if zt == 0:
+        return [1 if wk == tau % r else 0 for wk in ws], zt
+    invs = _batch_inverse([(tau - wk) % r for wk in ws], r)
+    c = zt * pow(n, -1, r) % r
+    return [c * wk % r * iv % r for wk, iv in zip(ws, invs)], zt
+
+
+class Groth16:
+    """`impl SNARK<Fr> for Groth16` over the MI355X backend."""
+
+    def __init__(self, curve="bls12_381", device: int = 0, lib=None):
+        self.curve: Curve = CURVES[curve] if not isinstance(curve, Curve) else curve
+        # `lib` is injectable only so that tests can drive this host logic over the CPU emulator build;
+        # the default (and only shipped) backend is the HIP library.
+        self.lib = lib if lib is not None else _lib()
+        self.ctx = self.lib.ctx_create(device)
+        self.sizes = self.lib.sizes(self.curve.curve_id)
+        self._handles = {}
+
+    def close(self):
+        for kind, h in list(self._handles.values()):
+            (self.lib.dll.ark355_pk_free if kind == "pk" else self.lib.dll.ark355_r1cs_free)(h)
+        self._handles.clear()
+        if self.ctx is not None:
+            self.lib.ctx_destroy(self.ctx)
+            self.ctx = None
+
+    # ---- SNARK::circuit_specific_setup (snark/src/lib.rs:43-46) ---------------------------------------
+    def circuit_specific_setup(self, r1cs: R1CS, rng, keep_trapdoor=False) -> Tuple[ProvingKey, VerifyingKey]:
+        """`rng` yields field elements: callable rng() -> int (uniform mod r)."""
+        cv, r = self.curve, self.curve.r
+        tau, alpha, beta, gamma, delta = (rng() % r or 1 for _ in range(5))
+        n, ell, m = r1cs.n, r1cs.ell, r1cs.m
+        N = r1cs.domain_size
+        log_n = N.bit_length() - 1
+        if log_n > cv.two_adicity:
+            raise SynthesisError("PolynomialDegreeTooLarge")
+        L, zt = _lagrange_at(cv, log_n, tau)
+        u = [0] * m
+        v = [0] * m
+        w = [0] * m
+        for i in range(ell):
+            u[i] = L[n + i]
+        for vec, k in ((u, 0), (v, 1), (w, 2)):
+            rp, col, ci = r1cs.row_ptr[k], r1cs.col[k], r1cs.coeff_int[k]
+            rp_l, col_l = rp.tolist(), col.tolist()
+            for i in range(n):
+                lk = L[i]
+                for t in range(rp_l[i], rp_l[i + 1]):
+                    j = col_l[t]
+                    c = ci[t]
+                    vec[j] = (vec[j] + (lk if c == 1 else lk * c)) % r
+        gi, di = pow(gamma, -1, r), pow(delta, -1, r)
+        abc = [(beta * u[i] + alpha * v[i] + w[i]) % r for i in range(m)]
+        gamma_abc_s = [abc[i] * gi % r for i in range(ell)]
+        l_s = [abc[i] * di % r for i in range(ell, m)]
+        h_s, t = [], zt * di % r
+        for _ in range(N - 1):
+            h_s.append(t)
+            t = t * tau % r
+        g1, g2 = cv.g1_gen_raw(), cv.g2_gen_raw()
+
+        def mul(group, scalars):
+            sb = b"".join(cv.fr_canon(s) for s in scalars)
+            return self.lib.fixed_base_mul(self.ctx, cv.curve_id, group, g1 if group == 1 else g2, sb, len(scalars),
+                                           self.sizes["g1"] if group == 1 else self.sizes["g2"])
+
+        singles1 = mul(1, [alpha, beta, delta])
+        singles2 = mul(2, [beta, gamma, delta])
+        s1, s2 = self.sizes["g1"], self.sizes["g2"]
+        vk = VerifyingKey(alpha_g1=singles1[:s1], beta_g2=singles2[:s2], gamma_g2=singles2[s2:2 * s2],
+                          delta_g2=singles2[2 * s2:], gamma_abc_g1=mul(1, gamma_abc_s))
+        pk = ProvingKey(vk=vk, beta_g1=singles1[s1:2 * s1], delta_g1=singles1[2 * s1:],
+                        a_query=mul(1, u), b_g1_query=mul(1, v), b_g2_query=mul(2, v),
+                        h_query=mul(1, h_s), l_query=mul(1, l_s), ell=ell, w=r1cs.w, N=N)
+        if keep_trapdoor:
+            pk.trapdoor = dict(tau=tau, alpha=alpha, beta=beta, gamma=gamma, delta=delta, u=u, v=v, w=w)
+        return pk, vk
+
+    # ---- device residency ---------------------------------------------------------------------------------
+    def load_pk(self, pk: ProvingKey):
+        key = ("pk", id(pk))
+        if key not in self._handles:
+            h = self.lib.pk_load(self.ctx, self.curve.curve_id, pk.ell, pk.w, pk.N, pk.a_query, pk.b_g1_query,
+                                 pk.b_g2_query, pk.h_query, pk.l_query, pk.vk.alpha_g1, pk.beta_g1, pk.delta_g1,
+                                 pk.vk.beta_g2, pk.vk.delta_g2)
+            self._handles[key] = ("pk", h)
+        return self._handles[key][1]
+
+    def load_r1cs(self, r1cs: R1CS):
+        key = ("r1cs", id(r1cs))
+        if key not in self._handles:
+            try:
+                h = self.lib.r1cs_load(self.ctx, self.curve.curve_id, r1cs.n, r1cs.ell, r1cs.w,
+                                       list(zip(r1cs.row_ptr, r1cs.col, r1cs.coeff)))
+            except Ark355Error as e:
+                raise SynthesisError(str(e)) from e
+            self._handles[key] = ("r1cs", h)
+        return self._handles[key][1]
+
+    # ---- SNARK::prove (snark/src/lib.rs:50-54) ---------------------------------------------------------------
+    def prove(self, pk: ProvingKey, r1cs: R1CS, z, rng=None, r: Optional[int] = None, s: Optional[int] = None,
+              z_device_ptr: Optional[int] = None) -> Proof:
+        """z: Montgomery bytes of the full assignment (or a list of ints).  r, s: the zero-knowledge
+        randomisers -- drawn from `rng` in the order r then s (as upstream `create_random_proof`) unless given."""
+        cv = self.curve
+        if r is None:
+            r = rng() % cv.r
+        if s is None:
+            s = rng() % cv.r
+        pkh, rh = self.load_pk(pk), self.load_r1cs(r1cs)
+        try:
+            if z_device_ptr is not None:
+                a, b, c = self.lib.prove(self.ctx, pkh, rh, z_device_ptr, r1cs.m, cv.fr_canon(r), cv.fr_canon(s),
+                                         self.sizes, z_is_device_ptr=True)
+            else:
+                if not isinstance(z, (bytes, bytearray, np.ndarray)):
+                    z = b"".join(cv.fr_mont(v) for v in z)
+                z_len = len(z) // 32
+                a, b, c = self.lib.prove(self.ctx, pkh, rh, z, z_len, cv.fr_canon(r), cv.fr_canon(s), self.sizes)
+        except Ark355Error as e:
+            raise SynthesisError(str(e)) from e
+        return Proof(a, b, c)
+
+    def is_satisfied(self, r1cs: R1CS, z) -> Optional[int]:
+        """None if satisfied, else the first failing constraint index (constraint_system.rs:661-687)."""
+        cv = self.curve
+        if not isinstance(z, (bytes, bytearray, np.ndarray)):
+            z = b"".join(cv.fr_mont(v) for v in z)
+        fb = self.lib.is_satisfied(self.ctx, self.load_r1cs(r1cs), z, len(z) // 32)
+        return None if fb < 0 else fb
+
+    # ---- closed form from a retained trapdoor (bench / tests: size-independent proof check) -----------------------
+    def prove_closed_form(self, pk: ProvingKey, z_ints: Sequence[int], r: int, s: int) -> Proof:
+        td = pk.trapdoor
+        if td is None:
+            raise ValueError("setup was not asked to keep the trapdoor")
+        cv, R = self.curve, self.curve.r
+        m, ell = len(z_ints), pk.ell
+        az = sum(z_ints[i] * td["u"][i] for i in range(m)) % R
+        bz = sum(z_ints[i] * td["v"][i] for i in range(m)) % R
+        cz = sum(z_ints[i] * td["w"][i] for i in range(m)) % R
+        a_exp = (td["alpha"] + az + r * td["delta"]) % R
+        b_exp = (td["beta"] + bz + s * td["delta"]) % R
+        di = pow(td["delta"], -1, R)
+        l_part = sum(z_ints[i] * (td["beta"] * td["u"][i] + td["alpha"] * td["v"][i] + td["w"][i])
+                     for i in range(ell, m)) % R
+        c_exp = ((l_part + az * bz - cz) * di + s * a_exp + r * b_exp - r * s % R * td["delta"]) % R
+        g1 = self.lib.fixed_base_mul(self.ctx, cv.curve_id, 1, cv.g1_gen_raw(),
+                                     cv.fr_canon(a_exp) + cv.fr_canon(c_exp), 2, self.sizes["g1"])
+        g2 = self.lib.fixed_base_mul(self.ctx, cv.curve_id, 2, cv.g2_gen_raw(), cv.fr_canon(b_exp), 1,
+                                     self.sizes["g2"])
+        s1 = self.sizes["g1"]
+        return Proof(g1[:s1], g2, g1[s1:])
+
+    # ---- not on the accelerated path ---------------------------------------------------------------------------------
+    def verify(self, *a, **k):
+        raise NotImplementedError("SNARK::verify stays on the arkworks host (CPU); proofs are byte-compatible")
+
+    process_vk = verify
+    verify_with_processed_vk = verify

@@ -1,0 +1,139 @@
+"""Parity cases shared by the CPU-emulator tier and the GPU tier: each drives the C ABI through
+`snark_amd._binding.Lib` and compares with the oracle on the same seeded inputs."""
+from __future__ import annotations
+
+import random
+
+from helpers import (fr_vec_from_mont, g1_vec_raw, g2_vec_raw, pk_load_from_oracle, r1cs_load_from_rows, z_bytes)
+from oracle import groth16 as G, r1cs as R, serialize as Z, synthetic as S
+from oracle.curves import g1, g2
+from oracle.ntt import Domain
+
+
+def ntt_case(lib, ctx, C, log_n, seed=1):
+    rnd = random.Random(seed + log_n)
+    n = 1 << log_n
+    xs = [rnd.randrange(C.r) for _ in range(n)]
+    d = Domain(C, log_n)
+    data = z_bytes(C, xs)
+    for inv, cos, ref in ((0, 0, d.fft), (1, 0, d.ifft), (0, 1, d.coset_fft), (1, 1, d.coset_ifft)):
+        out = lib.ntt(ctx, C.curve_id, data, log_n, inv, cos)
+        assert fr_vec_from_mont(C, out) == ref(xs), (C.name, log_n, inv, cos)
+
+
+def ntt_roundtrip_case(lib, ctx, C, log_n, seed=2):
+    """Size-independent properties: ifft(fft(x)) == x, coset likewise, and X[0] == sum x (linearity probe)."""
+    rnd = random.Random(seed)
+    n = 1 << log_n
+    xs = [rnd.getrandbits(250) % C.r for _ in range(n)]
+    data = z_bytes(C, xs)
+    f = lib.ntt(ctx, C.curve_id, data, log_n, 0, 0)
+    assert Z.fr_from_mont(C, f[:32]) == sum(xs) % C.r
+    # X[N/2] = sum (-1)^j x_j
+    half = n // 2
+    assert Z.fr_from_mont(C, f[32 * half:32 * half + 32]) == (sum(xs[0::2]) - sum(xs[1::2])) % C.r
+    assert lib.ntt(ctx, C.curve_id, f, log_n, 1, 0) == data
+    cf = lib.ntt(ctx, C.curve_id, data, log_n, 0, 1)
+    assert cf != f
+    assert lib.ntt(ctx, C.curve_id, cf, log_n, 1, 1) == data
+
+
+def msm_case(lib, ctx, C, group, n, seed=3, edge=True):
+    rnd = random.Random(seed * 1000 + n + group)
+    G_ = g1(C) if group == 1 else g2(C)
+    raw = Z.g1_raw if group == 1 else Z.g2_raw
+    fromraw = Z.g1_from_raw if group == 1 else Z.g2_from_raw
+    sz = lib.sizes(C.curve_id)
+    psz = sz["g1"] if group == 1 else sz["g2"]
+    ks = [rnd.randrange(C.r) for _ in range(n)]
+    pts = G_.fixed_base_muls(G_.gen, [rnd.randrange(C.r) for _ in range(n)]) if n else []
+    if edge and n >= 5:
+        ks[0], ks[1], ks[2] = 0, 1, C.r - 1
+        ks[3] = ks[4]
+    if edge and n >= 16:
+        pts[7] = None                                   # base at infinity
+        pts[8], ks[8] = pts[9], ks[9]                   # forces P + P in a bucket
+        pts[10], ks[10] = G_.neg(pts[11]), ks[11]       # forces P + (-P)
+        ks[12] = 1 << 200
+        ks[13] = (1 << 255) % C.r
+    out = lib.msm(ctx, C.curve_id, group, b"".join(raw(C, p) for p in pts),
+                  b"".join(Z.fr_canon(C, k) for k in ks), n, psz)
+    assert fromraw(C, out) == G_.msm(pts, ks), (C.name, group, n)
+
+
+def msm_known_dlog_case(lib, ctx, C, group, n, seed=4, skew=None):
+    """Any size: bases s_i*G made on the device (ark355_fixed_base_mul), so MSM == (sum k_i s_i) * G."""
+    rnd = random.Random(seed + n)
+    G_ = g1(C) if group == 1 else g2(C)
+    raw = Z.g1_raw if group == 1 else Z.g2_raw
+    fromraw = Z.g1_from_raw if group == 1 else Z.g2_from_raw
+    sz = lib.sizes(C.curve_id)
+    psz = sz["g1"] if group == 1 else sz["g2"]
+    ss = [rnd.getrandbits(64) + 1 for _ in range(n)]
+    bases = lib.fixed_base_mul(ctx, C.curve_id, group, raw(C, G_.gen), b"".join(Z.fr_canon(C, s) for s in ss), n, psz)
+    assert fromraw(C, bases[:psz]) == G_.mul(G_.gen, ss[0])
+    if skew == "equal":
+        k0 = rnd.randrange(C.r)
+        ks = [k0] * n
+    elif skew == "boolean":
+        ks = [rnd.randrange(2) if rnd.random() < 0.9 else rnd.randrange(C.r) for _ in range(n)]
+    else:
+        ks = [rnd.getrandbits(255) % C.r for _ in range(n)]
+    out = lib.msm(ctx, C.curve_id, group, bases, b"".join(Z.fr_canon(C, k) for k in ks), n, psz)
+    expect = G_.mul(G_.gen, sum(k * s for k, s in zip(ks, ss)) % C.r)
+    assert fromraw(C, out) == expect, (C.name, group, n, skew)
+
+
+def r1cs_case(lib, ctx, C, A, B, Cm, z, ell):
+    sz = lib.sizes(C.curve_id)
+    m = len(z)
+    r1 = r1cs_load_from_rows(lib, ctx, C, A, B, Cm, ell, m - ell)
+    try:
+        zb = z_bytes(C, z)
+        az, bz, cz = lib.mat_vec(ctx, r1, zb, m, len(A), sz["fr"])
+        assert fr_vec_from_mont(C, az) == R.mat_vec_mul(A, z, C.r)
+        assert fr_vec_from_mont(C, bz) == R.mat_vec_mul(B, z, C.r)
+        assert fr_vec_from_mont(C, cz) == R.mat_vec_mul(Cm, z, C.r)
+        assert lib.is_satisfied(ctx, r1, zb, m) == R.first_unsatisfied_r1cs(A, B, Cm, z, C.r)
+        for k in (ell, m - 1, m // 2):
+            zbad = list(z)
+            zbad[k] = (zbad[k] + 1) % C.r
+            assert lib.is_satisfied(ctx, r1, z_bytes(C, zbad), m) == R.first_unsatisfied_r1cs(A, B, Cm, zbad, C.r)
+        h = lib.witness_map(ctx, r1, zb, m, sz["fr"])
+        assert fr_vec_from_mont(C, h) == G.witness_map(C, A, B, Cm, z, ell)
+    finally:
+        lib.dll.ark355_r1cs_free(r1)
+
+
+def prove_case(lib, ctx, C, A, B, Cm, z, ell, td=None, rs=((0x1234567890abcdef, 0xfedcba0987654321aabbccdd),),
+               verify=False):
+    sz = lib.sizes(C.curve_id)
+    m = len(z)
+    w = m - ell
+    td = td or G.Trapdoor(tau=987654321, alpha=5, beta=7, gamma=11, delta=13)
+    pk = G.setup(C, A, B, Cm, ell, m, td)
+    N = 1 << pk.domain_log
+    r1 = r1cs_load_from_rows(lib, ctx, C, A, B, Cm, ell, w)
+    pkh = pk_load_from_oracle(lib, ctx, C, pk, ell, w, N)
+    try:
+        assert lib.dll.ark355_r1cs_domain_size(r1) == N
+        zb = z_bytes(C, z)
+        for r_, s_ in rs:
+            r_, s_ = r_ % C.r, s_ % C.r
+            a, b, c = lib.prove(ctx, pkh, r1, zb, m, Z.fr_canon(C, r_), Z.fr_canon(C, s_), sz)
+            got = G.Proof(Z.g1_from_raw(C, a), Z.g2_from_raw(C, b), Z.g1_from_raw(C, c))
+            exp = G.prove_closed_form(C, pk, z, ell, r_, s_)
+            assert got == exp, (C.name, len(A), r_, s_)
+            assert Z.proof_bytes(C, got) == Z.proof_bytes(C, exp)
+            if verify:
+                assert G.verify(C, pk.vk, z[1:ell], got)
+        # SynthesisError::AssignmentMissing for a short assignment
+        try:
+            lib.prove(ctx, pkh, r1, zb[:-32], m - 1, Z.fr_canon(C, 1), Z.fr_canon(C, 2), sz)
+            assert False, "short assignment must fail"
+        except Exception as e:
+            assert getattr(e, "code", None) == -16
+    finally:
+        lib.dll.ark355_pk_free(pkh)
+        lib.dll.ark355_r1cs_free(r1)
+    return pk

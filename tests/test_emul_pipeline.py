@@ -1,0 +1,80 @@
+"""CPU tier: the library's own kernel + orchestration sources, compiled against the HIP emulator in
+tests/emul (test infrastructure), checked against the oracle through the same C ABI the GPU tier uses.
+This does NOT stand in for the GPU parity tests (tests/test_gpu_parity.py); it catches indexing /
+barrier / buffer-size bugs before GPU minutes are spent."""
+import pytest
+
+import parity_cases as pc
+from oracle import groth16 as G, synthetic as S
+from oracle.fields import BLS12_381, BN254
+
+
+@pytest.mark.parametrize("C", [BLS12_381, BN254], ids=lambda c: c.name)
+@pytest.mark.parametrize("log_n", [1, 4, 9, 11])
+def test_ntt_all_modes(emul_lib, emul_ctx, C, log_n):
+    pc.ntt_case(emul_lib, emul_ctx, C, log_n)
+
+
+def test_ntt_two_adicity_error(emul_lib, emul_ctx):
+    import numpy as np
+    with pytest.raises(Exception) as e:
+        emul_lib.ntt(emul_ctx, BN254.curve_id, bytes(32), 41, 0, 0)
+    assert e.value.code == -18
+
+
+@pytest.mark.parametrize("C,group,n", [(BLS12_381, 1, 0), (BLS12_381, 1, 1), (BLS12_381, 1, 40), (BLS12_381, 2, 40),
+                                       (BN254, 1, 40), (BN254, 2, 17), (BLS12_381, 1, 600)],
+                         ids=lambda v: getattr(v, "name", str(v)))
+def test_msm_vs_naive(emul_lib, emul_ctx, C, group, n):
+    pc.msm_case(emul_lib, emul_ctx, C, group, n)
+
+
+@pytest.mark.parametrize("skew", ["equal", "boolean"])
+def test_msm_skewed_scalars(emul_lib, emul_ctx, skew):
+    # all-equal scalars: every term of a window lands in ONE bucket (long straddling runs);
+    # boolean witnesses: mostly 0/1 scalars (arkworks skips zeros)
+    pc.msm_known_dlog_case(emul_lib, emul_ctx, BLS12_381, 1, 200, skew=skew)
+
+
+@pytest.mark.parametrize("C", [BLS12_381, BN254], ids=lambda c: c.name)
+def test_r1cs_ops_and_witness_map(emul_lib, emul_ctx, C):
+    A, B, Cm, z, ell = S.cs_to_instance(S.bench_lc_cs(C.r, 20))     # general coefficients, repeated columns
+    pc.r1cs_case(emul_lib, emul_ctx, C, A, B, Cm, z, ell)
+    A, B, Cm, z, ell = S.cs_to_instance(S.dummy_cs(C.r, 16))         # empty rows, degenerate values
+    pc.r1cs_case(emul_lib, emul_ctx, C, A, B, Cm, z, ell)
+
+
+@pytest.mark.parametrize("C", [BLS12_381, BN254], ids=lambda c: c.name)
+def test_prove_bytes_equal_oracle(emul_lib, emul_ctx, C):
+    A, B, Cm, z, ell = S.mulchain_direct(C.r, 13)
+    pc.prove_case(emul_lib, emul_ctx, C, A, B, Cm, z, ell, rs=((0x1234567890abcdef, 0xfedcba0987654321aabbccdd), (0, 5)))
+
+
+def test_host_mirror_setup_prove_over_emulator(emul_lib):
+    """snark_amd.groth16.Groth16 (product host logic: setup scalars, key layout, closed form) driven over the
+    emulator build; the resulting proof must verify under the oracle's pairing check."""
+    from snark_amd.groth16 import Groth16
+    from snark_amd import synthetic, params
+    from oracle import serialize as Z
+    C = BLS12_381
+    cv = params.BLS12_381
+    r1, z = synthetic.mulchain(cv, 6)
+    A, B, Cm, z2, ell = S.mulchain_direct(C.r, 6)
+    assert z == z2
+    g = Groth16(cv, lib=emul_lib)
+    try:
+        seq = iter([11, 22, 33, 44, 55])
+        pk, vk = g.circuit_specific_setup(r1, lambda: next(seq), keep_trapdoor=True)
+        proof = g.prove(pk, r1, z, r=777, s=888)
+        assert proof == g.prove_closed_form(pk, z, 777, 888)
+        opk = G.setup(C, A, B, Cm, ell, len(z), G.Trapdoor(11, 22, 33, 44, 55))
+        assert Z.g1_from_raw(C, pk.a_query[:96]) == opk.a_query[0]
+        got = G.Proof(Z.g1_from_raw(C, proof.a), Z.g2_from_raw(C, proof.b), Z.g1_from_raw(C, proof.c))
+        assert got == G.prove_closed_form(C, opk, z, ell, 777, 888)
+        assert G.verify(C, opk.vk, z[1:ell], got)
+        assert g.is_satisfied(r1, z) is None
+        zb = list(z)
+        zb[4] += 1
+        assert g.is_satisfied(r1, zb) is not None
+    finally:
+        g.close()

@@ -1,0 +1,133 @@
+"""GPU tier (-m gpu): the HIP path through the C ABI against the oracle -- bit-exact.
+
+Small sizes: full comparison with the oracle's naive algorithms.  Large sizes (up to BASELINE.json's
+2^20): size-independent properties -- NTT round trips and DC/Nyquist bins, MSM over bases with known
+discrete logs, proofs against the trapdoor closed form and the pairing equation."""
+import random
+
+import pytest
+
+import parity_cases as pc
+from oracle import groth16 as G, serialize as Z, synthetic as S
+from oracle.fields import BLS12_381, BN254
+
+pytestmark = pytest.mark.gpu
+CURVES = [BLS12_381, BN254]
+
+
+def test_native_library_is_the_one_loaded(gpu_lib):
+    import snark_amd
+    assert gpu_lib.path == snark_amd.LIB_PATH and gpu_lib.path.endswith("libark355.so")
+    maps = open("/proc/self/maps").read()
+    assert "libark355.so" in maps and "libark355_emul" not in maps
+
+
+@pytest.mark.parametrize("C", CURVES, ids=lambda c: c.name)
+@pytest.mark.parametrize("log_n", [1, 2, 3, 7, 8, 9, 10, 11, 13])
+def test_ntt_vs_oracle(gpu_lib, gpu_ctx, C, log_n):
+    pc.ntt_case(gpu_lib, gpu_ctx, C, log_n)
+
+
+@pytest.mark.parametrize("C,log_n", [(BLS12_381, 16), (BLS12_381, 17), (BLS12_381, 21), (BN254, 20)],
+                         ids=lambda v: getattr(v, "name", str(v)))
+def test_ntt_roundtrip_large(gpu_lib, gpu_ctx, C, log_n):
+    pc.ntt_roundtrip_case(gpu_lib, gpu_ctx, C, log_n)
+
+
+def test_ntt_two_adicity_error(gpu_lib, gpu_ctx):
+    with pytest.raises(Exception) as e:
+        gpu_lib.ntt(gpu_ctx, BN254.curve_id, bytes(32), 41, 0, 0)
+    assert e.value.code == -18
+
+
+@pytest.mark.parametrize("C", CURVES, ids=lambda c: c.name)
+@pytest.mark.parametrize("group", [1, 2])
+@pytest.mark.parametrize("n", [0, 1, 2, 31, 33, 257, 1500])
+def test_msm_vs_naive(gpu_lib, gpu_ctx, C, group, n):
+    if group == 2 and n > 300:
+        n = 300
+    pc.msm_case(gpu_lib, gpu_ctx, C, group, n)
+
+
+@pytest.mark.parametrize("C,group,n,skew", [
+    (BLS12_381, 1, 1 << 14, None), (BLS12_381, 1, 1 << 14, "equal"), (BLS12_381, 1, 1 << 14, "boolean"),
+    (BLS12_381, 2, 1 << 12, None), (BN254, 1, 1 << 14, None), (BN254, 2, 1 << 12, "boolean"),
+    (BLS12_381, 1, 1 << 18, None), (BLS12_381, 1, (1 << 16) + 77, "boolean"),
+], ids=lambda v: getattr(v, "name", str(v)))
+def test_msm_known_dlog(gpu_lib, gpu_ctx, C, group, n, skew):
+    pc.msm_known_dlog_case(gpu_lib, gpu_ctx, C, group, n, skew=skew)
+
+
+@pytest.mark.parametrize("C", CURVES, ids=lambda c: c.name)
+def test_r1cs_ops_and_witness_map(gpu_lib, gpu_ctx, C):
+    for cs in (S.bench_lc_cs(C.r, 300), S.dummy_cs(C.r, 128), S.mulchain_cs(C.r, 1), S.mulchain_cs(C.r, 255)):
+        A, B, Cm, z, ell = S.cs_to_instance(cs)
+        pc.r1cs_case(gpu_lib, gpu_ctx, C, A, B, Cm, z, ell)
+
+
+@pytest.mark.parametrize("C", CURVES, ids=lambda c: c.name)
+def test_prove_small_vs_oracle_and_pairing(gpu_lib, gpu_ctx, C):
+    A, B, Cm, z, ell = S.mulchain_direct(C.r, 13)
+    pc.prove_case(gpu_lib, gpu_ctx, C, A, B, Cm, z, ell, verify=True,
+                  rs=((0x1234567890abcdef, 0xfedcba0987654321aabbccdd), (0, 5), (7, 0), (C.r - 1, C.r - 2)))
+    A, B, Cm, z, ell = S.cs_to_instance(S.bench_lc_cs(C.r, 100))
+    pc.prove_case(gpu_lib, gpu_ctx, C, A, B, Cm, z, ell)
+
+
+def test_prove_dummy_circuit_config1(gpu_lib, gpu_ctx):
+    """BASELINE.json configs[0]: the reference's DummyCircuit shape (sr1cs/mod.rs:276-319) at 2^10: all scalars
+    equal -- the worst case for bucket collisions."""
+    C = BLS12_381
+    A, B, Cm, z, ell = S.cs_to_instance(S.dummy_cs(C.r, 1 << 10))
+    pc.prove_case(gpu_lib, gpu_ctx, C, A, B, Cm, z, ell, verify=True)
+
+
+def _host_mirror_case(curve_name, n, seed):
+    """Product setup (host scalars + device fixed-base) + prove vs the closed form; oracle re-derives the
+    closed-form exponents independently from the same trapdoor and checks the pairing equation."""
+    from snark_amd import params, synthetic
+    from snark_amd.groth16 import Groth16
+    cv = params.CURVES[curve_name]
+    C = BLS12_381 if curve_name == "bls12_381" else BN254
+    r1, z = synthetic.mulchain(cv, n, seed=seed)
+    g = Groth16(cv)
+    try:
+        rnd = random.Random(seed)
+        pk, vk = g.circuit_specific_setup(r1, lambda: rnd.randrange(1, C.r), keep_trapdoor=True)
+        assert g.is_satisfied(r1, z) is None
+        r_, s_ = rnd.randrange(C.r), rnd.randrange(C.r)
+        proof = g.prove(pk, r1, synthetic.z_to_mont_bytes(cv, z), r=r_, s=s_)
+        assert proof == g.prove_closed_form(pk, z, r_, s_)
+        # independent re-derivation by the oracle from the same toxic waste
+        td = pk.trapdoor
+        A, B, Cm, z2, ell = S.mulchain_direct(C.r, n, seed=seed)
+        assert z2 == z
+        u, v, w, zt, dom = G.qap_scalars(C, A, B, Cm, n, ell, len(z), td["tau"])
+        assert (u, v, w) == (td["u"], td["v"], td["w"])
+        opk = G.ProvingKey(vk=None, beta_g1=None, delta_g1=None, a_query=[], b_g1_query=[], b_g2_query=[],
+                           h_query=[], l_query=[],
+                           trapdoor=G.Trapdoor(td["tau"], td["alpha"], td["beta"], td["gamma"], td["delta"]),
+                           u=u, v=v, w=w)
+        exp = G.prove_closed_form(C, opk, z, ell, r_, s_)
+        got = G.Proof(Z.g1_from_raw(C, proof.a), Z.g2_from_raw(C, proof.b), Z.g1_from_raw(C, proof.c))
+        assert got == exp
+        s1 = g.sizes["g1"]
+        ovk = G.VerifyingKey(alpha_g1=Z.g1_from_raw(C, vk.alpha_g1), beta_g2=Z.g2_from_raw(C, vk.beta_g2),
+                             gamma_g2=Z.g2_from_raw(C, vk.gamma_g2), delta_g2=Z.g2_from_raw(C, vk.delta_g2),
+                             gamma_abc_g1=[Z.g1_from_raw(C, vk.gamma_abc_g1[i * s1:(i + 1) * s1]) for i in range(ell)])
+        assert G.verify(C, ovk, z[1:ell], got)
+        # a wrong witness gives a different proof that must NOT verify
+        zb = list(z)
+        zb[5] = (zb[5] + 1) % C.r
+        from oracle import r1cs as R
+        assert g.is_satisfied(r1, zb) == R.first_unsatisfied_r1cs(A, B, Cm, zb, C.r) == 1
+        bad = g.prove(pk, r1, synthetic.z_to_mont_bytes(cv, zb), r=r_, s=s_)
+        badp = G.Proof(Z.g1_from_raw(C, bad.a), Z.g2_from_raw(C, bad.b), Z.g1_from_raw(C, bad.c))
+        assert not G.verify(C, ovk, z[1:ell], badp)
+    finally:
+        g.close()
+
+
+@pytest.mark.parametrize("curve_name,n", [("bls12_381", 1 << 12), ("bn254", 1 << 12), ("bls12_381", (1 << 16) - 100)])
+def test_host_mirror_setup_prove_closed_form(gpu_lib, curve_name, n):
+    _host_mirror_case(curve_name, n, seed=0x355)
