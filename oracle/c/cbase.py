@@ -1,0 +1,228 @@
+"""TEST INFRASTRUCTURE: ctypes wrapper + build recipe for the oracle's C restatement (cbase.c).
+
+Roles: (i) oracle at sizes the Python oracle cannot reach (cross-checked against it in
+tests/test_oracle_c.py), (ii) `cpu_baseline` of bench.py ("port": arkworks-algorithm CPU restatement --
+Pippenger with arkworks' window rule and per-window threads, radix-2 FFT, libsnark-style witness map --
+timed on the host cores of the GPU box).  Never imported by snark_amd.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+import time
+
+import numpy as np
+
+from ..fields import CURVES, CurveParams
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+BUILD_DIR = os.path.normpath(os.path.join(HERE, "..", "_build"))
+LIB = os.path.join(BUILD_DIR, "libcbase.so")
+_lib = None
+
+
+def build(force=False, verbose=False):
+    src = [os.path.join(HERE, f) for f in ("cbase.c", "fp_tmpl.h", "fp2_tmpl.h", "grp_tmpl.h")]
+    if not force and os.path.exists(LIB) and os.path.getmtime(LIB) >= max(os.path.getmtime(s) for s in src):
+        return LIB
+    os.makedirs(BUILD_DIR, exist_ok=True)
+    cmd = ["gcc", "-O3", "-march=native", "-fopenmp", "-shared", "-fPIC", "-o", LIB, src[0]]
+    if verbose:
+        print("[oracle.c]", " ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return LIB
+
+
+def _u64(v, n):
+    return (C.c_uint64 * n)(*[(v >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(n)])
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        path = build()
+        L = C.CDLL(path)
+        for cv in (CURVES["bls12_381"], CURVES["bn254"]):
+            nq = cv.fq_limbs64
+            Rr, Rq = 1 << 256, 1 << (64 * nq)
+            rho = pow(cv.fr_generator, (cv.r - 1) >> cv.two_adicity, cv.r)
+            L.cb_init(cv.curve_id, _u64(cv.r, 4), _u64(Rr % cv.r, 4), _u64(Rr * Rr % cv.r, 4),
+                      C.c_uint64((-pow(cv.r, -1, 1 << 64)) % (1 << 64)),
+                      _u64(cv.q, nq), _u64(Rq % cv.q, nq), _u64(Rq * Rq % cv.q, nq),
+                      C.c_uint64((-pow(cv.q, -1, 1 << 64)) % (1 << 64)),
+                      cv.r.bit_length(), cv.two_adicity, _u64(rho * Rr % cv.r, 4), _u64(cv.fr_generator * Rr % cv.r, 4))
+        L.cb_num_threads.restype = C.c_int
+        _lib = L
+    return _lib
+
+
+def _p(b):
+    a = np.frombuffer(b, dtype=np.uint8) if isinstance(b, (bytes, bytearray)) else np.ascontiguousarray(b)
+    return a.ctypes.data_as(C.c_void_p), a
+
+
+def ntt(curve: CurveParams, data: bytes, log_n, inverse=False, coset=False) -> bytes:
+    a = np.frombuffer(bytearray(data), dtype=np.uint8)
+    rc = lib().cb_ntt(curve.curve_id, a.ctypes.data_as(C.c_void_p), log_n, int(inverse), int(coset))
+    if rc:
+        raise ValueError(rc)
+    return a.tobytes()
+
+
+def msm(curve: CurveParams, group, bases: bytes, scalars: bytes, n) -> bytes:
+    psz = curve.fq_bytes * (2 if group == 1 else 4)
+    out = np.zeros(psz, dtype=np.uint8)
+    pb, k1 = _p(bases if n else b"\0")
+    ps, k2 = _p(scalars if n else b"\0")
+    lib().cb_msm(curve.curve_id, group, pb, ps, C.c_uint64(n), out.ctypes.data_as(C.c_void_p))
+    return out.tobytes()
+
+
+def fixed_base(curve: CurveParams, group, base: bytes, scalars: bytes, n) -> bytes:
+    psz = curve.fq_bytes * (2 if group == 1 else 4)
+    out = np.zeros(max(1, n * psz), dtype=np.uint8)
+    pb, k1 = _p(base)
+    ps, k2 = _p(scalars if n else b"\0")
+    lib().cb_fixed_base(curve.curve_id, group, pb, ps, C.c_uint64(n), out.ctypes.data_as(C.c_void_p))
+    return out.tobytes()[:n * psz]
+
+
+def _csr_args(mats):
+    args, keep = [], []
+    for rp, col, cf in mats:
+        a = np.ascontiguousarray(rp, dtype=np.uint64)
+        b = np.ascontiguousarray(col, dtype=np.uint32)
+        if b.size == 0:
+            b = np.zeros(1, dtype=np.uint32)
+        c = np.frombuffer(cf if len(cf) else bytes(32), dtype=np.uint8)
+        keep += [a, b, c]
+        args += [a.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p), c.ctypes.data_as(C.c_void_p)]
+    return args, keep
+
+
+def witness_map(curve: CurveParams, n, ell, w, mats, z: bytes) -> bytes:
+    need = n + ell
+    N = 1
+    while N < need:
+        N <<= 1
+    out = np.zeros(N * 32, dtype=np.uint8)
+    args, keep = _csr_args(mats)
+    pz, kz = _p(z)
+    rc = lib().cb_witness_map(curve.curve_id, C.c_uint64(n), C.c_uint64(ell), C.c_uint64(w), *args, pz,
+                              out.ctypes.data_as(C.c_void_p))
+    if rc:
+        raise ValueError(rc)
+    return out.tobytes()
+
+
+def prove(curve: CurveParams, n, ell, w, mats, z: bytes, pk_raw: dict, r: int, s: int, timings=None):
+    """pk_raw: dict of raw byte arrays with the names of ark355_pk_desc.  Returns (a, b, c) raw affine."""
+    g1, g2 = 2 * curve.fq_bytes, 4 * curve.fq_bytes
+    oa, ob, oc = (np.zeros(k, dtype=np.uint8) for k in (g1, g2, g1))
+    args, keep = _csr_args(mats)
+    ptrs = []
+    for name in ("a_query", "b_g1_query", "b_g2_query", "h_query", "l_query", "alpha_g1", "beta_g1", "delta_g1",
+                 "beta_g2", "delta_g2"):
+        p, k = _p(pk_raw[name] if len(pk_raw[name]) else b"\0")
+        keep.append(k)
+        ptrs.append(p)
+    pz, kz = _p(z)
+    tm = (C.c_double * 4)()
+    rc = lib().cb_prove(curve.curve_id, C.c_uint64(n), C.c_uint64(ell), C.c_uint64(w), *args, pz, *ptrs,
+                        _u64(r % curve.r, 4), _u64(s % curve.r, 4), oa.ctypes.data_as(C.c_void_p),
+                        ob.ctypes.data_as(C.c_void_p), oc.ctypes.data_as(C.c_void_p), tm)
+    if rc:
+        raise ValueError(rc)
+    if timings is not None:
+        timings.update(witness_map_s=tm[0], msm_s=tm[1], total_s=tm[2])
+    return oa.tobytes(), ob.tobytes(), oc.tobytes()
+
+
+# ---- setup with the C fixed-base routine (valid keys at sizes Python cannot reach) -----------------------------
+def setup_raw(curve: CurveParams, A, B, Cm, ell, m, td):
+    """Groth16 key as raw byte arrays (names of ark355_pk_desc) + the oracle-side scalars."""
+    from .. import groth16 as G, serialize as Z
+    from ..curves import g1 as G1of, g2 as G2of
+    r = curve.r
+    n = len(A)
+    u, v, w, zt, dom = G.qap_scalars(curve, A, B, Cm, n, ell, m, td.tau)
+    N = dom.n
+    gi, di = pow(td.gamma, -1, r), pow(td.delta, -1, r)
+    abc = [(td.beta * u[i] + td.alpha * v[i] + w[i]) % r for i in range(m)]
+    h_s, t = [], zt * di % r
+    for _ in range(N - 1):
+        h_s.append(t)
+        t = t * td.tau % r
+    G1, G2 = G1of(curve), G2of(curve)
+    b1 = Z.g1_raw(curve, G1.mul(curve.g1_gen, td.g1_k))
+    b2 = Z.g2_raw(curve, G2.mul(curve.g2_gen, td.g2_k))
+
+    def fb(group, ks):
+        sb = b"".join((k % r).to_bytes(32, "little") for k in ks)
+        return fixed_base(curve, group, b1 if group == 1 else b2, sb, len(ks))
+
+    s1, s2 = 2 * curve.fq_bytes, 4 * curve.fq_bytes
+    one1 = fb(1, [td.alpha, td.beta, td.delta])
+    one2 = fb(2, [td.beta, td.gamma, td.delta])
+    pk = dict(a_query=fb(1, u), b_g1_query=fb(1, v), b_g2_query=fb(2, v), h_query=fb(1, h_s),
+              l_query=fb(1, [abc[i] * di % r for i in range(ell, m)]),
+              alpha_g1=one1[:s1], beta_g1=one1[s1:2 * s1], delta_g1=one1[2 * s1:],
+              beta_g2=one2[:s2], gamma_g2=one2[s2:2 * s2], delta_g2=one2[2 * s2:],
+              gamma_abc_g1=fb(1, [abc[i] * gi % r for i in range(ell)]))
+    return pk, dict(u=u, v=v, w=w, N=N)
+
+
+def bench_prove(curve_name="bls12_381", log_n=None, budget_s=20.0):
+    """cpu_baseline for bench.py: the C restatement on all host cores on a bounded sample of the same
+    workload (S2 mulchain).  Bases are s_i*G made with the C fixed-base routine (their distribution does not
+    affect Pippenger's cost)."""
+    from .. import synthetic as S
+    import random
+    cv = CURVES[curve_name]
+    L = lib()
+    cores = L.cb_num_threads()
+    if log_n is None:
+        log_n = 16 if cores >= 16 else 14
+    n = 1 << log_n
+    A, B, Cm, z, ell = S.mulchain_direct(cv.r, n)
+    m = len(z)
+    w = m - ell
+    N = 1
+    while N < n + ell:
+        N <<= 1
+    rnd = random.Random(1)
+    from .. import serialize as Z
+
+    def rand_pts(group, k):
+        sb = b"".join(rnd.getrandbits(64).to_bytes(32, "little") for _ in range(k))
+        base = Z.g1_raw(cv, cv.g1_gen) if group == 1 else Z.g2_raw(cv, cv.g2_gen)
+        return fixed_base(cv, group, base, sb, k)
+
+    pk = dict(a_query=rand_pts(1, m), b_g1_query=rand_pts(1, m), b_g2_query=rand_pts(2, m),
+              h_query=rand_pts(1, N - 1), l_query=rand_pts(1, w))
+    one1, one2 = rand_pts(1, 3), rand_pts(2, 2)
+    s1, s2 = 2 * cv.fq_bytes, 4 * cv.fq_bytes
+    pk.update(alpha_g1=one1[:s1], beta_g1=one1[s1:2 * s1], delta_g1=one1[2 * s1:], beta_g2=one2[:s2], delta_g2=one2[s2:])
+    one = Z.fr_mont(cv, 1)
+    mats = []
+    for M in (A, B, Cm):
+        rp = np.zeros(len(M) + 1, dtype=np.uint64)
+        cols = []
+        for i, row in enumerate(M):
+            cols.extend(j for _, j in row)
+            rp[i + 1] = len(cols)
+        mats.append((rp, np.array(cols, dtype=np.uint32), one * len(cols)))
+    zb = b"".join(Z.fr_mont(cv, v) for v in z)
+    prove(cv, n, ell, w, mats, zb, pk, 3, 5)                      # warm-up
+    times, t_start = [], time.perf_counter()
+    while len(times) < 5 and (time.perf_counter() - t_start) < budget_s:
+        tm = {}
+        prove(cv, n, ell, w, mats, zb, pk, rnd.randrange(cv.r), rnd.randrange(cv.r), timings=tm)
+        times.append(tm["total_s"])
+    times.sort()
+    med = times[len(times) // 2]
+    return {"value": n / med, "unit": "constraints/s", "cores": cores, "kind": "port",
+            "sample": "oracle/c (arkworks-algorithm C restatement, OpenMP x%d): median of %d Groth16/%s proofs of a "
+                      "2^%d-constraint S2 mulchain R1CS (N=2^%d), %.3f s each"
+                      % (cores, len(times), curve_name, log_n, N.bit_length() - 1, med)}
