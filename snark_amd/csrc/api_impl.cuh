@@ -8,7 +8,7 @@ namespace ark355 {
 struct BasesDev {
   int curve = 0, group = 1;
   uint64_t n = 0;
-  DevBuf pts;
+  PrecompTable tab;      // per-window tables of the resident bases
 };
 
 // one lane per scalar: k * P by double-and-add, then affine (setup-time fixed-base multiplications)
@@ -42,7 +42,7 @@ struct Api {
     what[3] = sizeof(Affine<Fq2>);
   }
 
-  static PkDev* pk_load(const ark355_pk_desc* d) { return pk_upload<Curve>(d); }
+  static PkDev* pk_load(const ark355_pk_desc* d, hipStream_t st) { return pk_upload<Curve>(d, st); }
 
   static R1csDev* r1cs_load(uint64_t n, uint64_t ell, uint64_t w, const uint64_t* const rp[3],
                             const uint32_t* const col[3], const uint8_t* const coeff[3]) {
@@ -109,7 +109,7 @@ struct Api {
 
   template <class F>
   static void msm_generic(ark355_ctx* ctx, GenericScratch& g, const Affine<F>* d_bases, const void* d_scalars,
-                          uint64_t n, int mont, uint8_t* out, bool want_affine) {
+                          uint64_t n, int mont, uint8_t* out, bool want_affine, const PrecompTable* tab = nullptr) {
     hipStream_t st = ctx->stream;
     g.c.ensure(sizeof(XYZZ<F>) + sizeof(Affine<F>));
     XYZZ<F>* d_res = g.c.as<XYZZ<F>>();
@@ -118,7 +118,7 @@ struct Api {
     ARK_CHECK_HIP(hipEventCreate(&e0));
     ARK_CHECK_HIP(hipEventCreate(&e1));
     try {
-      msm_sort<Fr>(ctx, g.sort, d_scalars, n, mont, st);
+      msm_sort<Fr>(ctx, g.sort, d_scalars, n, mont, st, tab);
       msm_buckets<F>(ctx, g.sort, g.bk, d_bases, d_res, 0, st, n ? e0 : nullptr, n ? e1 : nullptr);
       if (want_affine) {
         ARK_LAUNCH((xyzz_to_affine_kernel<F>), dim3(1), dim3(64), 0, st, (const XYZZ<F>*)d_res, d_aff, 1u);
@@ -156,15 +156,17 @@ struct Api {
     else msm_generic<Fq2>(ctx, g, g.a.as<Affine<Fq2>>(), g.b.p, n, 0, out, true);
   }
 
-  static BasesDev* bases_load(int group, const uint8_t* bases, uint64_t n) {
+  static BasesDev* bases_load(int group, const uint8_t* bases, uint64_t n, hipStream_t st) {
     auto* b = new BasesDev();
     try {
       b->curve = Curve::ID;
       b->group = group;
       b->n = n;
       const size_t psz = group == 1 ? sizeof(Affine<Fq>) : sizeof(Affine<Fq2>);
-      b->pts.alloc(n * psz);
-      if (n) ARK_CHECK_HIP(hipMemcpy(b->pts.p, bases, n * psz, hipMemcpyHostToDevice));
+      DevBuf stage((n ? n : 1) * psz);
+      if (n) ARK_CHECK_HIP(hipMemcpy(stage.p, bases, n * psz, hipMemcpyHostToDevice));
+      if (group == 1) precomp_build<Fq, Fr>(b->tab, stage.p, n, st);
+      else precomp_build<Fq2, Fr>(b->tab, stage.p, n, st);
     } catch (...) {
       delete b;
       throw;
@@ -175,8 +177,8 @@ struct Api {
   static void msm_dev(ark355_ctx* ctx, GenericScratch& g, const BasesDev& b, const void* d_scalars, uint64_t n, int mont,
                       uint8_t* out, bool want_affine) {
     ARK_REQUIRE(n <= b.n, ARK355_EINVAL, "more scalars than bases");
-    if (b.group == 1) msm_generic<Fq>(ctx, g, b.pts.as<Affine<Fq>>(), d_scalars, n, mont, out, want_affine);
-    else msm_generic<Fq2>(ctx, g, b.pts.as<Affine<Fq2>>(), d_scalars, n, mont, out, want_affine);
+    if (b.group == 1) msm_generic<Fq>(ctx, g, b.tab.table.as<Affine<Fq>>(), d_scalars, n, mont, out, want_affine, &b.tab);
+    else msm_generic<Fq2>(ctx, g, b.tab.table.as<Affine<Fq2>>(), d_scalars, n, mont, out, want_affine, &b.tab);
   }
 
   template <class F>

@@ -125,7 +125,7 @@ int32_t ark355_pk_load(ark355_ctx* ctx, int32_t curve, const ark355_pk_desc* des
   *out = nullptr;
   return guarded(ctx, [&] {
     PkDev* d = nullptr;
-    CURVE_DISPATCH(curve, d = A::pk_load(desc));
+    CURVE_DISPATCH(curve, d = A::pk_load(desc, ctx->stream));
     *out = new ark355_pk{d};
   });
 }
@@ -248,7 +248,7 @@ int32_t ark355_bases_load(ark355_ctx* ctx, int32_t curve, int32_t group, const u
   *out = nullptr;
   return guarded(ctx, [&] {
     BasesDev* d = nullptr;
-    CURVE_DISPATCH(curve, d = A::bases_load(group, bases, n));
+    CURVE_DISPATCH(curve, d = A::bases_load(group, bases, n, ctx->stream));
     *out = new ark355_bases{d};
   });
 }

@@ -14,8 +14,11 @@
 // one gets  A = MSM(a_ext, zx), B1 = MSM(b1_ext, zx), B2 = MSM(b2_ext, zx) (ONE digit/sort pass shared
 // by the three), L' = MSM(l_ext, zx[ell..m+1)) = l_acc - r s delta_1, H = MSM(h_query, h[0..N-1)), and
 //     C = s*A + r*B1 + L' + H.
-// The only remaining sequential work is s*A and r*B1 (two 255-bit double-and-add chains, run in
-// parallel waves of the finalize kernel) and three affine normalisations.
+// The only remaining sequential work is s*A and r*B1 (two 255-bit double-and-add chains) and three affine
+// normalisations: O(1) work, independent of the circuit size.  A single GPU lane needs ~25 ms for it
+// (measured, round 1), the host ~1 ms, so by default the five XYZZ results (1 KiB) are copied back and the
+// library's own host-compiled field code finishes the proof; ARK355_DEVICE_FINALIZE=1 keeps it on the device
+// (groth16_finalize_kernel) and must give the same bytes.
 #pragma once
 #include "common.h"
 #include "msm_impl.cuh"
@@ -26,7 +29,8 @@ namespace ark355 {
 struct PkDev {
   int curve = 0;
   uint64_t ell = 0, w = 0, m = 0, N = 0;
-  DevBuf a_ext, b1_ext, b2_ext, h_query, l_ext;
+  // per-window tables T[w*n + i] = 2^(c*w) * P_i of the five (extended) query vectors, built at load
+  PrecompTable a_ext, b1_ext, b2_ext, h_query, l_ext;
 };
 
 struct ProverScratch {
@@ -90,7 +94,7 @@ groth16_finalize_kernel(const XYZZ<typename Curve::Fq>* __restrict__ g1res,   //
 }
 
 template <class Curve>
-static PkDev* pk_upload(const ark355_pk_desc* d) {
+static PkDev* pk_upload(const ark355_pk_desc* d, hipStream_t stream) {
   using Fq = typename Curve::Fq;
   using Fq2 = typename Curve::Fq2;
   constexpr size_t G1 = sizeof(Affine<Fq>), G2 = sizeof(Affine<Fq2>);
@@ -106,24 +110,32 @@ static PkDev* pk_upload(const ark355_pk_desc* d) {
                     d->alpha_g1 && d->beta_g1 && d->delta_g1 && d->beta_g2 && d->delta_g2,
                 ARK355_EINVAL, "null pointer in pk descriptor");
     const uint64_t m = pk->m;
-    auto ext = [&](DevBuf& dst, const uint8_t* query, size_t psz, const uint8_t* t1, const uint8_t* t2, const uint8_t* t3) {
+    using Fr = typename Curve::Fr;
+    DevBuf stage;
+    auto ext = [&](const uint8_t* query, size_t psz, const uint8_t* t1, const uint8_t* t2, const uint8_t* t3) {
       // [query (m), O, t1, t2, t3]; null tail pointers mean infinity
-      dst.alloc((m + 4) * psz);
-      ARK_CHECK_HIP(hipMemcpy(dst.p, query, m * psz, hipMemcpyHostToDevice));
+      stage.ensure((m + 4) * psz);
+      ARK_CHECK_HIP(hipMemcpy(stage.p, query, m * psz, hipMemcpyHostToDevice));
       std::vector<uint8_t> tail(4 * psz, 0);
       if (t1) memcpy(tail.data() + 1 * psz, t1, psz);
       if (t2) memcpy(tail.data() + 2 * psz, t2, psz);
       if (t3) memcpy(tail.data() + 3 * psz, t3, psz);
-      ARK_CHECK_HIP(hipMemcpy((uint8_t*)dst.p + m * psz, tail.data(), 4 * psz, hipMemcpyHostToDevice));
+      ARK_CHECK_HIP(hipMemcpy((uint8_t*)stage.p + m * psz, tail.data(), 4 * psz, hipMemcpyHostToDevice));
     };
-    ext(pk->a_ext, d->a_query, G1, d->alpha_g1, d->delta_g1, nullptr);
-    ext(pk->b1_ext, d->b_g1_query, G1, d->beta_g1, nullptr, d->delta_g1);
-    ext(pk->b2_ext, d->b_g2_query, G2, d->beta_g2, nullptr, d->delta_g2);
-    pk->h_query.alloc((pk->N ? pk->N - 1 : 0) * G1);
-    if (pk->N > 1) ARK_CHECK_HIP(hipMemcpy(pk->h_query.p, d->h_query, (pk->N - 1) * G1, hipMemcpyHostToDevice));
-    pk->l_ext.alloc((pk->w + 1) * G1);
-    if (pk->w) ARK_CHECK_HIP(hipMemcpy(pk->l_ext.p, d->l_query, pk->w * G1, hipMemcpyHostToDevice));
-    ARK_CHECK_HIP(hipMemcpy((uint8_t*)pk->l_ext.p + pk->w * G1, d->delta_g1, G1, hipMemcpyHostToDevice));
+    ext(d->a_query, G1, d->alpha_g1, d->delta_g1, nullptr);
+    precomp_build<Fq, Fr>(pk->a_ext, stage.p, m + 4, stream);
+    ext(d->b_g1_query, G1, d->beta_g1, nullptr, d->delta_g1);
+    precomp_build<Fq, Fr>(pk->b1_ext, stage.p, m + 4, stream);
+    ext(d->b_g2_query, G2, d->beta_g2, nullptr, d->delta_g2);
+    precomp_build<Fq2, Fr>(pk->b2_ext, stage.p, m + 4, stream);
+    const uint64_t hn = pk->N ? pk->N - 1 : 0;
+    stage.ensure((hn ? hn : 1) * G1);
+    if (hn) ARK_CHECK_HIP(hipMemcpy(stage.p, d->h_query, hn * G1, hipMemcpyHostToDevice));
+    precomp_build<Fq, Fr>(pk->h_query, stage.p, hn, stream);
+    stage.ensure((pk->w + 1) * G1);
+    if (pk->w) ARK_CHECK_HIP(hipMemcpy(stage.p, d->l_query, pk->w * G1, hipMemcpyHostToDevice));
+    ARK_CHECK_HIP(hipMemcpy((uint8_t*)stage.p + pk->w * G1, d->delta_g1, G1, hipMemcpyHostToDevice));
+    precomp_build<Fq, Fr>(pk->l_ext, stage.p, pk->w + 1, stream);
   } catch (...) {
     delete pk;
     throw;
@@ -173,33 +185,53 @@ static void prove_run(ark355_ctx* ctx, ProverScratch& sc, const PkDev& pk, const
     XYZZ<Fq>* g1res = sc.results.as<XYZZ<Fq>>();
     XYZZ<Fq2>* g2res = reinterpret_cast<XYZZ<Fq2>*>(g1res + 4);
     // H = MSM(h_query, h[0..N-1))
-    msm_sort<Fr>(ctx, sc.sort, d_h, pk.N - 1, /*mont=*/1, st);
-    msm_buckets<Fq>(ctx, sc.sort, sc.bk1, pk.h_query.as<Affine<Fq>>(), g1res + 3, 0, st, acc0[0], acc1[0]);
+    msm_sort<Fr>(ctx, sc.sort, d_h, pk.N - 1, /*mont=*/1, st, &pk.h_query);
+    msm_buckets<Fq>(ctx, sc.sort, sc.bk1, pk.h_query.table.as<Affine<Fq>>(), g1res + 3, 0, st, acc0[0], acc1[0]);
     uint64_t pts = (uint64_t)sc.sort.plan.windows * (pk.N - 1);
     ARK_CHECK_HIP(hipEventRecord(ev[3], st));
     // L' = MSM(l_ext, zx[ell .. m+1))
-    msm_sort<Fr>(ctx, sc.sort, (const uint8_t*)sc.zx.p + ell * sizeof(Fr), pk.w + 1, 1, st);
-    msm_buckets<Fq>(ctx, sc.sort, sc.bk1, pk.l_ext.as<Affine<Fq>>(), g1res + 2, 0, st, acc0[1], acc1[1]);
+    msm_sort<Fr>(ctx, sc.sort, (const uint8_t*)sc.zx.p + ell * sizeof(Fr), pk.w + 1, 1, st, &pk.l_ext);
+    msm_buckets<Fq>(ctx, sc.sort, sc.bk1, pk.l_ext.table.as<Affine<Fq>>(), g1res + 2, 0, st, acc0[1], acc1[1]);
     pts += (uint64_t)sc.sort.plan.windows * (pk.w + 1);
     ARK_CHECK_HIP(hipEventRecord(ev[4], st));
     // A, B1, B2 share one sort of zx[0 .. m+4)
-    msm_sort<Fr>(ctx, sc.sort, sc.zx.p, m + 4, 1, st);
-    msm_buckets<Fq>(ctx, sc.sort, sc.bk1, pk.a_ext.as<Affine<Fq>>(), g1res + 0, 0, st, acc0[2], acc1[2]);
-    msm_buckets<Fq>(ctx, sc.sort, sc.bk1, pk.b1_ext.as<Affine<Fq>>(), g1res + 1, 0, st, acc0[3], acc1[3]);
+    msm_sort<Fr>(ctx, sc.sort, sc.zx.p, m + 4, 1, st, &pk.a_ext);
+    msm_buckets<Fq>(ctx, sc.sort, sc.bk1, pk.a_ext.table.as<Affine<Fq>>(), g1res + 0, 0, st, acc0[2], acc1[2]);
+    msm_buckets<Fq>(ctx, sc.sort, sc.bk1, pk.b1_ext.table.as<Affine<Fq>>(), g1res + 1, 0, st, acc0[3], acc1[3]);
     pts += 2 * (uint64_t)sc.sort.plan.windows * (m + 4);
     ARK_CHECK_HIP(hipEventRecord(ev[5], st));
-    msm_buckets<Fq2>(ctx, sc.sort, sc.bk2, pk.b2_ext.as<Affine<Fq2>>(), g2res, 0, st, acc0[4], acc1[4]);
+    msm_buckets<Fq2>(ctx, sc.sort, sc.bk2, pk.b2_ext.table.as<Affine<Fq2>>(), g2res, 0, st, acc0[4], acc1[4]);
     pts += (uint64_t)sc.sort.plan.windows * (m + 4);
     ARK_CHECK_HIP(hipEventRecord(ev[6], st));
-    ARK_LAUNCH((groth16_finalize_kernel<Curve>), dim3(1), dim3(192), 0, st, (const XYZZ<Fq>*)g1res,
-               (const XYZZ<Fq2>*)g2res, sc.rs.as<Fr>(), sc.proof.as<unsigned char>());
-    ARK_CHECK_LAUNCH();
     memset(out, 0, sizeof(*out));
-    ARK_CHECK_HIP(hipMemcpyAsync(out->a, sc.proof.p, sizeof(Affine<Fq>), hipMemcpyDeviceToHost, st));
-    ARK_CHECK_HIP(hipMemcpyAsync(out->b, (uint8_t*)sc.proof.p + sizeof(Affine<Fq>), sizeof(Affine<Fq2>), hipMemcpyDeviceToHost, st));
-    ARK_CHECK_HIP(hipMemcpyAsync(out->c, (uint8_t*)sc.proof.p + sizeof(Affine<Fq>) + sizeof(Affine<Fq2>), sizeof(Affine<Fq>), hipMemcpyDeviceToHost, st));
-    ARK_CHECK_HIP(hipEventRecord(ev[7], st));
-    ARK_CHECK_HIP(hipStreamSynchronize(st));
+    const char* dev_fin = getenv("ARK355_DEVICE_FINALIZE");
+    if (dev_fin && dev_fin[0] == '1') {
+      ARK_LAUNCH((groth16_finalize_kernel<Curve>), dim3(1), dim3(192), 0, st, (const XYZZ<Fq>*)g1res,
+                 (const XYZZ<Fq2>*)g2res, sc.rs.as<Fr>(), sc.proof.as<unsigned char>());
+      ARK_CHECK_LAUNCH();
+      ARK_CHECK_HIP(hipMemcpyAsync(out->a, sc.proof.p, sizeof(Affine<Fq>), hipMemcpyDeviceToHost, st));
+      ARK_CHECK_HIP(hipMemcpyAsync(out->b, (uint8_t*)sc.proof.p + sizeof(Affine<Fq>), sizeof(Affine<Fq2>), hipMemcpyDeviceToHost, st));
+      ARK_CHECK_HIP(hipMemcpyAsync(out->c, (uint8_t*)sc.proof.p + sizeof(Affine<Fq>) + sizeof(Affine<Fq2>), sizeof(Affine<Fq>), hipMemcpyDeviceToHost, st));
+      ARK_CHECK_HIP(hipEventRecord(ev[7], st));
+      ARK_CHECK_HIP(hipStreamSynchronize(st));
+    } else {
+      XYZZ<Fq> h1[4];
+      XYZZ<Fq2> h2;
+      ARK_CHECK_HIP(hipMemcpyAsync(h1, g1res, sizeof(h1), hipMemcpyDeviceToHost, st));
+      ARK_CHECK_HIP(hipMemcpyAsync(&h2, g2res, sizeof(h2), hipMemcpyDeviceToHost, st));
+      ARK_CHECK_HIP(hipEventRecord(ev[7], st));
+      ARK_CHECK_HIP(hipStreamSynchronize(st));
+      // host tail: C = s*A + r*B1 + L' + H ; three affine normalisations
+      XYZZ<Fq> c = xyzz_add(xyzz_mul_scalar(h1[0], scn.l, Fr::N), xyzz_mul_scalar(h1[1], rc.l, Fr::N));
+      c = xyzz_add(c, h1[2]);
+      c = xyzz_add(c, h1[3]);
+      Affine<Fq> pa = xyzz_to_affine(h1[0]);
+      Affine<Fq2> pb = xyzz_to_affine(h2);
+      Affine<Fq> pc = xyzz_to_affine(c);
+      memcpy(out->a, &pa, sizeof(pa));
+      memcpy(out->b, &pb, sizeof(pb));
+      memcpy(out->c, &pc, sizeof(pc));
+    }
     auto el = [&](int a, int b) {
       float ms = 0;
       (void)hipEventElapsedTime(&ms, ev[a], ev[b]);

@@ -34,11 +34,17 @@ struct MsmPlan {
   uint64_t n = 0;
   uint32_t c = 0, windows = 0, buckets_per_window = 0, total_buckets = 0;
   uint32_t scalar_bits = 0;
+  // precomp: the bases come with per-window tables T[w*n + i] = 2^(c*w) * P_i (built once when a key is
+  // loaded; MI355X has the HBM for it), so every window shares ONE bucket set and the c*w doublings of the
+  // window combination disappear from the per-proof path.
+  bool precomp = false;
+  uint32_t key_windows = 0;     // bucket sets: 1 with precomp, `windows` without
 };
 
-inline MsmPlan msm_plan(uint64_t n, uint32_t scalar_bits, int force_c = 0) {
+inline MsmPlan msm_plan(uint64_t n, uint32_t scalar_bits, bool precomp = false, int force_c = 0) {
   MsmPlan p;
   p.n = n;
+  p.precomp = precomp;
   p.scalar_bits = scalar_bits;
   uint32_t lg = 0;
   while ((1ull << (lg + 1)) <= (n ? n : 1)) lg++;
@@ -50,14 +56,16 @@ inline MsmPlan msm_plan(uint64_t n, uint32_t scalar_bits, int force_c = 0) {
   // one extra bit so that the top window never produces a carry
   p.windows = (scalar_bits + 1 + p.c - 1) / p.c;
   p.buckets_per_window = 1u << (p.c - 1);
-  p.total_buckets = p.windows * p.buckets_per_window;
+  p.key_windows = precomp ? 1u : p.windows;
+  p.total_buckets = p.key_windows * p.buckets_per_window;
   return p;
 }
 
 // ---- K2: signed window digits + histogram ----------------------------------------------------------
 template <class Fr>
 __global__ void __launch_bounds__(MSM_THREADS)
-msm_digits_kernel(const Fr* __restrict__ scalars, uint32_t n, int mont, uint32_t c, uint32_t windows,
+msm_digits_kernel(const Fr* __restrict__ scalars, uint32_t n, int mont, uint32_t c, uint32_t windows, int precomp,
+                  uint32_t table_stride,
                   uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, uint32_t* __restrict__ counts) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -89,9 +97,10 @@ msm_digits_kernel(const Fr* __restrict__ scalars, uint32_t n, int mont, uint32_t
       keys[e] = MSM_INVALID;
       vals[e] = 0;
     } else {
-      const uint32_t key = w * B + d - 1;
+      // precomp: one shared bucket set, the value indexes the window's table row
+      const uint32_t key = precomp ? (d - 1) : (w * B + d - 1);
       keys[e] = key;
-      vals[e] = i | (neg << 31);
+      vals[e] = (precomp ? (w * table_stride + i) : i) | (neg << 31);
       atomicAdd(&counts[key], 1u);
     }
   }
@@ -162,7 +171,7 @@ ARK_D void msm_flush_run(uint32_t key, const XYZZ<F>& acc, bool first_run, uint3
   }
 }
 
-template <class F>
+template <class F, bool NI>
 __global__ void __launch_bounds__(MSM_THREADS)
 msm_accumulate_kernel(const Affine<F>* __restrict__ bases, const uint32_t* __restrict__ sorted_keys,
                       const uint32_t* __restrict__ sorted_vals, const uint32_t* __restrict__ total_ptr,
@@ -179,8 +188,18 @@ msm_accumulate_kernel(const Affine<F>* __restrict__ bases, const uint32_t* __res
   uint32_t run_start = start;
   bool first_run = true;
   XYZZ<F> acc = XYZZ<F>::inf();
+  // software prefetch: the next base (a random 96/192-byte gather from the window tables) is in flight
+  // while the current mixed addition runs
+  uint32_t v_next = sorted_vals[start];
+  Affine<F> p_next = bases[v_next & 0x7FFFFFFFu];
   for (uint32_t e = start; e < end; e++) {
     const uint32_t key = sorted_keys[e];
+    const uint32_t v = v_next;
+    Affine<F> p = p_next;
+    if (e + 1 < end) {
+      v_next = sorted_vals[e + 1];
+      p_next = bases[v_next & 0x7FFFFFFFu];
+    }
     if (key != cur_key) {
       msm_flush_run<F>(cur_key, acc, first_run, run_start, e, seg, offsets, counts, buckets, head, head_key, tail,
                        tail_key);
@@ -189,10 +208,9 @@ msm_accumulate_kernel(const Affine<F>* __restrict__ bases, const uint32_t* __res
       first_run = false;
       acc = XYZZ<F>::inf();
     }
-    const uint32_t v = sorted_vals[e];
-    Affine<F> p = bases[v & 0x7FFFFFFFu];
     if (v >> 31) p.y = F::neg(p.y);
-    xyzz_madd(acc, p);
+    if constexpr (NI) xyzz_madd_ni(acc, p);
+    else xyzz_madd(acc, p);
   }
   msm_flush_run<F>(cur_key, acc, first_run, run_start, end, seg, offsets, counts, buckets, head, head_key, tail,
                    tail_key);
@@ -325,6 +343,82 @@ xyzz_sum_kernel(const XYZZ<F>* __restrict__ in, uint32_t count, XYZZ<F>* __restr
   if (threadIdx.x == 0) *out = v;
 }
 
+// ---- per-window base tables (built once per key) --------------------------------------------------------------------
+// out[i] = 2^c * in[i]  (affine in, XYZZ out)
+template <class F>
+__global__ void __launch_bounds__(MSM_THREADS)
+precomp_shift_kernel(const Affine<F>* __restrict__ in, XYZZ<F>* __restrict__ out, uint32_t n, uint32_t c) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  XYZZ<F> p = xyzz_dbl_affine_t<true>(in[i]);
+  for (uint32_t k = 1; k < c; k++) p = xyzz_dbl(p);
+  out[i] = p;
+}
+
+// XYZZ -> affine for n points, PRE_K consecutive points per lane sharing ONE field inversion (Montgomery's trick)
+constexpr uint32_t PRE_K = 16;
+template <class F>
+__global__ void __launch_bounds__(MSM_THREADS)
+batch_to_affine_kernel(const XYZZ<F>* __restrict__ in, Affine<F>* __restrict__ out, uint32_t n) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t first64 = (uint64_t)t * PRE_K;
+  if (first64 >= n) return;
+  const uint32_t first = (uint32_t)first64;
+  const uint32_t cnt = (first + PRE_K <= n) ? PRE_K : (n - first);
+  F pref[PRE_K];
+  F acc = F::one();
+  for (uint32_t j = 0; j < cnt; j++) {
+    const XYZZ<F> p = in[first + j];
+    if (!p.is_inf()) acc = F::mul_ni(acc, p.zzz);
+    pref[j] = acc;
+  }
+  F inv = F::inv(acc);
+  for (uint32_t j = cnt; j-- > 0;) {
+    const XYZZ<F> p = in[first + j];
+    if (p.is_inf()) {
+      out[first + j] = Affine<F>::inf();
+      continue;
+    }
+    const F prev = (j > 0) ? pref[j - 1] : F::one();
+    const F i3 = F::mul_ni(inv, prev);      // 1 / zzz_j
+    inv = F::mul_ni(inv, p.zzz);
+    const F iz = F::mul_ni(p.zz, i3);
+    const F i2 = F::sqr_ni(iz);
+    out[first + j] = Affine<F>{F::mul_ni(p.x, i2), F::mul_ni(p.y, i3)};
+  }
+}
+
+// Window tables of a base vector: T[w*n + i] = 2^(c*w) * P_i, affine, for the plan the MSM of this length uses.
+struct PrecompTable {
+  MsmPlan plan;
+  DevBuf table;
+  uint64_t n = 0;
+};
+
+template <class F, class Fr>
+static void precomp_build(PrecompTable& t, const void* d_bases, uint64_t n, hipStream_t stream) {
+  t.n = n;
+  t.plan = msm_plan(n, Fr::Params::BITS, /*precomp=*/true);
+  const MsmPlan& p = t.plan;
+  ARK_REQUIRE((uint64_t)p.windows * n < (1ull << 31), ARK355_EINVAL, "window table too large for 31-bit indices");
+  t.table.alloc((size_t)p.windows * (n ? n : 1) * sizeof(Affine<F>));
+  if (n == 0) return;
+  ARK_CHECK_HIP(hipMemcpyAsync(t.table.p, d_bases, n * sizeof(Affine<F>), hipMemcpyDeviceToDevice, stream));
+  DevBuf tmp(n * sizeof(XYZZ<F>));
+  Affine<F>* T = t.table.as<Affine<F>>();
+  const uint32_t grid = (uint32_t)((n + MSM_THREADS - 1) / MSM_THREADS);
+  const uint32_t gridb = (uint32_t)(((n + PRE_K - 1) / PRE_K + MSM_THREADS - 1) / MSM_THREADS);
+  for (uint32_t w = 1; w < p.windows; w++) {
+    ARK_LAUNCH((precomp_shift_kernel<F>), dim3(grid), dim3(MSM_THREADS), 0, stream, (const Affine<F>*)(T + (size_t)(w - 1) * n),
+               tmp.as<XYZZ<F>>(), (uint32_t)n, p.c);
+    ARK_CHECK_LAUNCH();
+    ARK_LAUNCH((batch_to_affine_kernel<F>), dim3(gridb), dim3(MSM_THREADS), 0, stream, (const XYZZ<F>*)tmp.as<XYZZ<F>>(),
+               T + (size_t)w * n, (uint32_t)n);
+    ARK_CHECK_LAUNCH();
+  }
+  ARK_CHECK_HIP(hipStreamSynchronize(stream));     // tmp is freed on return
+}
+
 // ---- host driver ---------------------------------------------------------------------------------------------
 // Scratch for one MSM "sort" (shared by several accumulations over the same scalars).
 struct MsmSort {
@@ -335,12 +429,16 @@ struct MsmSort {
 
 template <class Fr>
 static void msm_sort(ark355_ctx* ctx, MsmSort& s, const void* d_scalars, uint64_t n, int mont, hipStream_t stream,
-                     int force_c = 0) {
+                     const PrecompTable* tab = nullptr) {
   ARK_REQUIRE(n < (1ull << 31), ARK355_EINVAL, "MSM size must be < 2^31");
-  s.plan = msm_plan(n, Fr::Params::BITS, force_c);
+  const bool precomp = tab != nullptr;
+  if (tab) ARK_REQUIRE(n <= tab->n, ARK355_EINVAL, "more scalars than table rows");
+  // with window tables the window size is the one the tables were built for
+  s.plan = msm_plan(n, Fr::Params::BITS, precomp, tab ? (int)tab->plan.c : 0);
+  const uint32_t stride = tab ? (uint32_t)tab->n : 0;
   const MsmPlan& p = s.plan;
   const uint64_t entries = (uint64_t)p.windows * n;
-  ARK_REQUIRE(entries < (1ull << 32), ARK355_EINVAL, "MSM entry count must be < 2^32");
+  ARK_REQUIRE(entries < (1ull << 31), ARK355_EINVAL, "MSM entry count must be < 2^31");
   s.keys.ensure(entries * 4);
   s.vals.ensure(entries * 4);
   s.sorted_keys.ensure(entries * 4 + 16);
@@ -360,7 +458,8 @@ static void msm_sort(ark355_ctx* ctx, MsmSort& s, const void* d_scalars, uint64_
   ARK_CHECK_HIP(hipMemsetAsync(s.cursor.p, 0, (size_t)p.total_buckets * 4, stream));
   const uint32_t grid_n = (uint32_t)((n + MSM_THREADS - 1) / MSM_THREADS);
   ARK_LAUNCH((msm_digits_kernel<Fr>), dim3(grid_n), dim3(MSM_THREADS), 0, stream, (const Fr*)d_scalars, (uint32_t)n,
-             mont, p.c, p.windows, s.keys.as<uint32_t>(), s.vals.as<uint32_t>(), s.counts.as<uint32_t>());
+             mont, p.c, p.windows, p.precomp ? 1 : 0, stride, s.keys.as<uint32_t>(), s.vals.as<uint32_t>(),
+             s.counts.as<uint32_t>());
   ARK_CHECK_LAUNCH();
   ARK_LAUNCH(scan_exclusive_kernel, dim3(1), dim3(1024), 0, stream, s.counts.as<uint32_t>(),
              s.offsets.as<uint32_t>(), p.total_buckets, s.total.as<uint32_t>());
@@ -397,7 +496,10 @@ static void msm_buckets(ark355_ctx* ctx, const MsmSort& s, MsmBuckets& b, const 
   ARK_CHECK_HIP(hipMemsetAsync(b.tail_key.p, 0xFF, (size_t)segs * 4, stream));
   const uint32_t grid_s = (segs + MSM_THREADS - 1) / MSM_THREADS;
   if (ev0) ARK_CHECK_HIP(hipEventRecord(ev0, stream));
-  ARK_LAUNCH((msm_accumulate_kernel<F>), dim3(grid_s), dim3(MSM_THREADS), 0, stream, d_bases,
+  // G2 (Fq2) runs the out-of-line mixed addition: inlining 30 Fq multiplications spills (measured 0.53 vs
+  // 0.73 Gadd/s on MI355X); G1 keeps it inlined (3.7 vs 2.8 Gadd/s)
+  constexpr bool NI = sizeof(F) > 64;
+  ARK_LAUNCH((msm_accumulate_kernel<F, NI>), dim3(grid_s), dim3(MSM_THREADS), 0, stream, d_bases,
              s.sorted_keys.as<uint32_t>(), s.sorted_vals.as<uint32_t>(), s.total.as<uint32_t>(),
              s.offsets.as<uint32_t>(), s.counts.as<uint32_t>(), b.buckets.as<XYZZ<F>>(), b.head.as<XYZZ<F>>(),
              b.head_key.as<uint32_t>(), b.tail.as<XYZZ<F>>(), b.tail_key.as<uint32_t>());
@@ -410,13 +512,13 @@ static void msm_buckets(ark355_ctx* ctx, const MsmSort& s, MsmBuckets& b, const 
   ARK_CHECK_LAUNCH();
   const uint32_t chunks = (p.buckets_per_window + MSM_RED_K - 1) / MSM_RED_K;
   const uint32_t blocks_per_window = (chunks + MSM_THREADS - 1) / MSM_THREADS;
-  b.partials.ensure((size_t)blocks_per_window * p.windows * sizeof(XYZZ<F>));
-  ARK_LAUNCH((msm_reduce_kernel<F>), dim3(blocks_per_window, p.windows), dim3(MSM_THREADS), 0, stream,
+  b.partials.ensure((size_t)blocks_per_window * p.key_windows * sizeof(XYZZ<F>));
+  ARK_LAUNCH((msm_reduce_kernel<F>), dim3(blocks_per_window, p.key_windows), dim3(MSM_THREADS), 0, stream,
              b.buckets.as<XYZZ<F>>(), p.buckets_per_window, b.partials.as<XYZZ<F>>());
   ARK_CHECK_LAUNCH();
-  ARK_REQUIRE(p.windows <= 64, ARK355_EINVAL, "window count exceeds one wave");
+  ARK_REQUIRE(p.key_windows <= 64, ARK355_EINVAL, "window count exceeds one wave");
   ARK_LAUNCH((msm_combine_kernel<F>), dim3(1), dim3(64), 0, stream, b.partials.as<XYZZ<F>>(), blocks_per_window,
-             p.windows, p.c, d_out, accumulate);
+             p.key_windows, p.c, d_out, accumulate);
   ARK_CHECK_LAUNCH();
 }
 

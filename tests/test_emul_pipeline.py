@@ -50,6 +50,43 @@ def test_prove_bytes_equal_oracle(emul_lib, emul_ctx, C):
     pc.prove_case(emul_lib, emul_ctx, C, A, B, Cm, z, ell, rs=((0x1234567890abcdef, 0xfedcba0987654321aabbccdd), (0, 5)))
 
 
+def test_prove_device_finalize_kernel_gives_same_bytes(emul_lib, emul_ctx, monkeypatch):
+    """ARK355_DEVICE_FINALIZE=1 keeps s*A + r*B1 and the normalisations in groth16_finalize_kernel."""
+    monkeypatch.setenv("ARK355_DEVICE_FINALIZE", "1")
+    C = BN254
+    A, B, Cm, z, ell = S.mulchain_direct(C.r, 5)
+    pc.prove_case(emul_lib, emul_ctx, C, A, B, Cm, z, ell)
+
+
+def test_resident_bases_partial_and_sum(emul_lib, emul_ctx):
+    """ark355_bases_load (window tables) + msm over a PREFIX of the rows + XYZZ partial / ark355_xyzz_sum:
+    the pieces the multi-GPU sharded MSM is made of."""
+    import numpy as np
+    from oracle import serialize as Z
+    from oracle.curves import g1
+    C = BLS12_381
+    G1 = g1(C)
+    import random
+    rnd = random.Random(9)
+    n = 50
+    pts = G1.fixed_base_muls(G1.gen, [rnd.randrange(C.r) for _ in range(n)])
+    ks = [rnd.randrange(C.r) for _ in range(n)]
+    raw = b"".join(Z.g1_raw(C, p) for p in pts)
+    sz = emul_lib.sizes(C.curve_id)
+    halves = []
+    for lo, hi in ((0, 20), (20, 50)):
+        bh = emul_lib.bases_load(emul_ctx, C.curve_id, 1, raw[lo * 96:hi * 96], hi - lo)
+        sc = np.frombuffer(b"".join(Z.fr_canon(C, k) for k in ks[lo:hi]), dtype=np.uint8).copy()
+        # emulator: "device" pointers are host pointers
+        halves.append(emul_lib.msm_dev(emul_ctx, bh, sc.ctypes.data, hi - lo, 0, 4 * 48, partial=True))
+        if lo == 0:   # prefix of the rows with the same handle
+            pre = emul_lib.msm_dev(emul_ctx, bh, sc.ctypes.data, 7, 0, sz["g1"])
+            assert Z.g1_from_raw(C, pre) == G1.msm(pts[:7], ks[:7])
+        emul_lib.dll.ark355_bases_free(bh)
+    out = emul_lib.xyzz_sum(emul_ctx, C.curve_id, 1, b"".join(halves), 2, sz["g1"])
+    assert Z.g1_from_raw(C, out) == G1.msm(pts, ks)
+
+
 def test_host_mirror_setup_prove_over_emulator(emul_lib):
     """snark_amd.groth16.Groth16 (product host logic: setup scalars, key layout, closed form) driven over the
     emulator build; the resulting proof must verify under the oracle's pairing check."""
