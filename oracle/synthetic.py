@@ -50,10 +50,10 @@ def mulchain_cs(p, n, seed=0x355):
     return cs
 
 
-def mulchain_direct(p, n, seed=0x355):
+def mulchain_direct(p, n, seed=0x355, start=None):
     """S2 built directly (fast path for large n): returns (A, B, C, z, ell)."""
     rng = SplitMix64(seed)
-    vals = [rng.next_fr(p), rng.next_fr(p)]
+    vals = [rng.next_fr(p), rng.next_fr(p)] if start is None else [start[0] % p, start[1] % p]
     for i in range(n - 1):
         vals.append((vals[i] + vals[i + 1]) * vals[i + 1] % p)
     ell = 2

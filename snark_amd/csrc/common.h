@@ -5,6 +5,7 @@
 #include <string.h>
 #include <stdlib.h>
 #include <cstring>
+#include <initializer_list>
 #include <map>
 #include <mutex>
 #include <string>

@@ -75,6 +75,13 @@ ARK_HD XYZZ<F> xyzz_dbl_t(const XYZZ<F>& p) {
   return XYZZ<F>{X3, Y3, fmul<NI>(V, p.zz), fmul<NI>(W, p.zzz)};
 }
 
+// by VALUE on purpose: a reference parameter would force the caller's point into a stack slot that hipcc
+// then keeps up to date in every iteration of the hot loop (6 scratch stores per mixed addition, round-1 ISA)
+template <class F>
+ARK_HD_NOINLINE XYZZ<F> xyzz_dbl_affine_ni(Affine<F> p) {
+  return xyzz_dbl_affine_t<true>(p);
+}
+
 // acc += P, P affine (madd-2008-s); handles every special case.
 template <bool NI, class F>
 ARK_HD void xyzz_madd_t(XYZZ<F>& acc, const Affine<F>& p) {
@@ -89,21 +96,24 @@ ARK_HD void xyzz_madd_t(XYZZ<F>& acc, const Affine<F>& p) {
   F R = F::sub(S2, acc.y);
   if (Pd.is_zero()) {
     if (R.is_zero()) {
-      acc = xyzz_dbl_affine_t<true>(p);     // rare: always the out-of-line flavour
+      // rare (P == acc): out-of-line doubling, argument passed by value (see xyzz_dbl_affine_ni)
+      acc = xyzz_dbl_affine_ni(p);
     } else {
       acc = XYZZ<F>::inf();
     }
     return;
   }
+  // ordered so that values die early (Pd after PPP, PP after ZZ3, PPP after X3): the G2 instantiation lives
+  // at the edge of the 512-register file
   F PP = fsqr<NI>(Pd);
   F PPP = fmul<NI>(Pd, PP);
   F Q = fmul<NI>(acc.x, PP);
-  F X3 = F::sub(F::sub(fsqr<NI>(R), PPP), F::mul2(Q));
-  F Y3 = F::sub(fmul<NI>(R, F::sub(Q, X3)), fmul<NI>(acc.y, PPP));
-  acc.x = X3;
-  acc.y = Y3;
   acc.zz = fmul<NI>(acc.zz, PP);
   acc.zzz = fmul<NI>(acc.zzz, PPP);
+  F T = fmul<NI>(acc.y, PPP);
+  F X3 = F::sub(F::sub(fsqr<NI>(R), PPP), F::mul2(Q));
+  acc.x = X3;
+  acc.y = F::sub(fmul<NI>(R, F::sub(Q, X3)), T);
 }
 
 // a + b (add-2008-s); handles every special case.

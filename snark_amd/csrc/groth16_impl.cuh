@@ -34,8 +34,15 @@ struct PkDev {
 };
 
 struct ProverScratch {
-  MsmSort sort;
-  MsmBuckets bk1, bk2;
+  // one sort per distinct scalar vector (zx, zx[ell..], h) and one bucket set per MSM: the five MSMs of a proof
+  // are in flight together on separate streams (sized for 288 GB of HBM, not for reuse)
+  MsmSort sortZ, sortL, sortH;
+  MsmBuckets bkA, bkB1, bkB2, bkL, bkH;
+  hipStream_t sW = nullptr, sS = nullptr, sA = nullptr, sR = nullptr;
+  ~ProverScratch() {
+    for (hipStream_t st : {sW, sS, sA, sR})
+      if (st) (void)hipStreamDestroy(st);
+  }
   WitnessScratch ws;
   DevBuf zx;        // extended scalar vector
   DevBuf results;   // XYZZ results: A, B1, L, H (G1) then B2 (G2)
@@ -144,6 +151,14 @@ static PkDev* pk_upload(const ark355_pk_desc* d, hipStream_t stream) {
 }
 
 // z_src: host or device pointer to m Fr (Montgomery); z_on_device selects the copy kind.
+//
+// Stream plan (MI355X: 256 CUs; the accumulation kernels fill the chip, everything else is small or
+// latency-bound and is tucked underneath them):
+//   sM (ctx stream)  H2D of z and the tail scalars                                  -> evZ
+//   sW               witness map: SpMV, 7 NTTs, pointwise                            -> evH
+//   sS               digits/scan/scatter of zx, zx[ell..], then (after evH) of h     -> evSort[0..2]
+//   sA               bucket accumulation + merge: A, B1, B2 (share sort 0), L', H    -> evAcc[0..4]
+//   sR               bucket reduction + combine per MSM as evAcc[i] fires; D2H of the five XYZZ results
 template <class Curve>
 static void prove_run(ark355_ctx* ctx, ProverScratch& sc, const PkDev& pk, const R1csDev& r1, const void* z_src,
                       bool z_on_device, const uint8_t r_canon[32], const uint8_t s_canon[32], ark355_proof_raw* out) {
@@ -153,17 +168,31 @@ static void prove_run(ark355_ctx* ctx, ProverScratch& sc, const PkDev& pk, const
   ARK_REQUIRE(pk.curve == Curve::ID && r1.curve == Curve::ID, ARK355_EINVAL, "curve mismatch");
   ARK_REQUIRE(pk.ell == r1.ell && pk.w == r1.w && pk.N == r1.N, ARK355_EINVAL,
               "proving key and R1CS dimensions differ");
-  hipStream_t st = ctx->stream;
+  hipStream_t sM = ctx->stream;
+  for (hipStream_t* st : {&sc.sW, &sc.sS, &sc.sA, &sc.sR})
+    if (!*st) ARK_CHECK_HIP(hipStreamCreate(st));
+  const char* serial = getenv("ARK355_SERIAL");
+  const bool one_stream = serial && serial[0] == '1';
+  hipStream_t sW = one_stream ? sM : sc.sW, sS = one_stream ? sM : sc.sS, sA = one_stream ? sM : sc.sA,
+              sR = one_stream ? sM : sc.sR;
   const uint64_t m = pk.m, ell = pk.ell;
-  hipEvent_t ev[8];
-  for (auto& e : ev) ARK_CHECK_HIP(hipEventCreate(&e));
+  enum { E_START, E_Z, E_H, E_SORT0, E_SORT1, E_SORT2, E_ACC_DONE0, E_END = E_ACC_DONE0 + 5, E_COUNT };
+  hipEvent_t ev[E_COUNT];
   hipEvent_t acc0[5], acc1[5];
+  for (auto& e : ev) ARK_CHECK_HIP(hipEventCreate(&e));
   for (int i = 0; i < 5; i++) {
     ARK_CHECK_HIP(hipEventCreate(&acc0[i]));
     ARK_CHECK_HIP(hipEventCreate(&acc1[i]));
   }
+  auto cleanup = [&] {
+    for (auto& e : ev) (void)hipEventDestroy(e);
+    for (int i = 0; i < 5; i++) {
+      (void)hipEventDestroy(acc0[i]);
+      (void)hipEventDestroy(acc1[i]);
+    }
+  };
   try {
-    // r, s -> Montgomery on the host (our own field code, not the oracle); tail = [-rs, 1, r, s]
+    // r, s -> Montgomery on the host (the library's own field code); tail = [-rs, 1, r, s]
     Fr rc, scn;
     memcpy(rc.l, r_canon, sizeof(Fr));
     memcpy(scn.l, s_canon, sizeof(Fr));
@@ -174,53 +203,76 @@ static void prove_run(ark355_ctx* ctx, ProverScratch& sc, const PkDev& pk, const
     sc.rs.ensure(2 * sizeof(Fr));
     sc.results.ensure(4 * sizeof(XYZZ<Fq>) + sizeof(XYZZ<Fq2>));
     sc.proof.ensure(2 * sizeof(Affine<Fq>) + sizeof(Affine<Fq2>));
-    ARK_CHECK_HIP(hipEventRecord(ev[0], st));
-    ARK_CHECK_HIP(hipMemcpyAsync(sc.zx.p, z_src, m * sizeof(Fr), z_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
-    ARK_CHECK_HIP(hipMemcpyAsync((uint8_t*)sc.zx.p + m * sizeof(Fr), tail, sizeof(tail), hipMemcpyHostToDevice, st));
-    ARK_CHECK_HIP(hipMemcpyAsync(sc.rs.p, rs_c, sizeof(rs_c), hipMemcpyHostToDevice, st));
-    ARK_CHECK_HIP(hipEventRecord(ev[1], st));
-    // witness map -> h
-    void* d_h = witness_map_run<Curve>(ctx, r1, sc.zx.p, sc.ws, st);
-    ARK_CHECK_HIP(hipEventRecord(ev[2], st));
     XYZZ<Fq>* g1res = sc.results.as<XYZZ<Fq>>();
     XYZZ<Fq2>* g2res = reinterpret_cast<XYZZ<Fq2>*>(g1res + 4);
-    // H = MSM(h_query, h[0..N-1))
-    msm_sort<Fr>(ctx, sc.sort, d_h, pk.N - 1, /*mont=*/1, st, &pk.h_query);
-    msm_buckets<Fq>(ctx, sc.sort, sc.bk1, pk.h_query.table.as<Affine<Fq>>(), g1res + 3, 0, st, acc0[0], acc1[0]);
-    uint64_t pts = (uint64_t)sc.sort.plan.windows * (pk.N - 1);
-    ARK_CHECK_HIP(hipEventRecord(ev[3], st));
-    // L' = MSM(l_ext, zx[ell .. m+1))
-    msm_sort<Fr>(ctx, sc.sort, (const uint8_t*)sc.zx.p + ell * sizeof(Fr), pk.w + 1, 1, st, &pk.l_ext);
-    msm_buckets<Fq>(ctx, sc.sort, sc.bk1, pk.l_ext.table.as<Affine<Fq>>(), g1res + 2, 0, st, acc0[1], acc1[1]);
-    pts += (uint64_t)sc.sort.plan.windows * (pk.w + 1);
-    ARK_CHECK_HIP(hipEventRecord(ev[4], st));
-    // A, B1, B2 share one sort of zx[0 .. m+4)
-    msm_sort<Fr>(ctx, sc.sort, sc.zx.p, m + 4, 1, st, &pk.a_ext);
-    msm_buckets<Fq>(ctx, sc.sort, sc.bk1, pk.a_ext.table.as<Affine<Fq>>(), g1res + 0, 0, st, acc0[2], acc1[2]);
-    msm_buckets<Fq>(ctx, sc.sort, sc.bk1, pk.b1_ext.table.as<Affine<Fq>>(), g1res + 1, 0, st, acc0[3], acc1[3]);
-    pts += 2 * (uint64_t)sc.sort.plan.windows * (m + 4);
-    ARK_CHECK_HIP(hipEventRecord(ev[5], st));
-    msm_buckets<Fq2>(ctx, sc.sort, sc.bk2, pk.b2_ext.table.as<Affine<Fq2>>(), g2res, 0, st, acc0[4], acc1[4]);
-    pts += (uint64_t)sc.sort.plan.windows * (m + 4);
-    ARK_CHECK_HIP(hipEventRecord(ev[6], st));
+
+    ARK_CHECK_HIP(hipEventRecord(ev[E_START], sM));
+    ARK_CHECK_HIP(hipMemcpyAsync(sc.zx.p, z_src, m * sizeof(Fr), z_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, sM));
+    ARK_CHECK_HIP(hipMemcpyAsync((uint8_t*)sc.zx.p + m * sizeof(Fr), tail, sizeof(tail), hipMemcpyHostToDevice, sM));
+    ARK_CHECK_HIP(hipMemcpyAsync(sc.rs.p, rs_c, sizeof(rs_c), hipMemcpyHostToDevice, sM));
+    ARK_CHECK_HIP(hipEventRecord(ev[E_Z], sM));
+
+    // witness map -> h
+    ARK_CHECK_HIP(hipStreamWaitEvent(sW, ev[E_Z], 0));
+    void* d_h = witness_map_run<Curve>(ctx, r1, sc.zx.p, sc.ws, sW);
+    ARK_CHECK_HIP(hipEventRecord(ev[E_H], sW));
+
+    // sorts
+    ARK_CHECK_HIP(hipStreamWaitEvent(sS, ev[E_Z], 0));
+    msm_sort<Fr>(ctx, sc.sortZ, sc.zx.p, m + 4, 1, sS, &pk.a_ext);
+    ARK_CHECK_HIP(hipEventRecord(ev[E_SORT0], sS));
+    msm_sort<Fr>(ctx, sc.sortL, (const uint8_t*)sc.zx.p + ell * sizeof(Fr), pk.w + 1, 1, sS, &pk.l_ext);
+    ARK_CHECK_HIP(hipEventRecord(ev[E_SORT1], sS));
+    ARK_CHECK_HIP(hipStreamWaitEvent(sS, ev[E_H], 0));
+    msm_sort<Fr>(ctx, sc.sortH, d_h, pk.N - 1, 1, sS, &pk.h_query);
+    ARK_CHECK_HIP(hipEventRecord(ev[E_SORT2], sS));
+
+    // accumulations (A, B1, B2 share the sort of zx) and, per MSM, its reduction on sR
+    struct Job {
+      int sort_ev;
+      const MsmSort* sort;
+      MsmBuckets* bk;
+      bool g2;
+      const void* table;
+      int res;
+    } jobs[5] = {
+        {E_SORT0, &sc.sortZ, &sc.bkA, false, pk.a_ext.table.p, 0},
+        {E_SORT0, &sc.sortZ, &sc.bkB1, false, pk.b1_ext.table.p, 1},
+        {E_SORT0, &sc.sortZ, &sc.bkB2, true, pk.b2_ext.table.p, 0},
+        {E_SORT1, &sc.sortL, &sc.bkL, false, pk.l_ext.table.p, 2},
+        {E_SORT2, &sc.sortH, &sc.bkH, false, pk.h_query.table.p, 3},
+    };
+    uint64_t pts = 0;
+    for (int j = 0; j < 5; j++) {
+      const Job& jb = jobs[j];
+      ARK_CHECK_HIP(hipStreamWaitEvent(sA, ev[jb.sort_ev], 0));
+      if (jb.g2) msm_accumulate_phase<Fq2>(ctx, *jb.sort, *jb.bk, (const Affine<Fq2>*)jb.table, sA, acc0[j], acc1[j]);
+      else msm_accumulate_phase<Fq>(ctx, *jb.sort, *jb.bk, (const Affine<Fq>*)jb.table, sA, acc0[j], acc1[j]);
+      ARK_CHECK_HIP(hipEventRecord(ev[E_ACC_DONE0 + j], sA));
+      ARK_CHECK_HIP(hipStreamWaitEvent(sR, ev[E_ACC_DONE0 + j], 0));
+      if (jb.g2) msm_reduce_phase<Fq2>(ctx, jb.sort->plan, *jb.bk, g2res, 0, sR);
+      else msm_reduce_phase<Fq>(ctx, jb.sort->plan, *jb.bk, g1res + jb.res, 0, sR);
+      pts += (uint64_t)jb.sort->plan.windows * jb.sort->plan.n;
+    }
+
     memset(out, 0, sizeof(*out));
     const char* dev_fin = getenv("ARK355_DEVICE_FINALIZE");
     if (dev_fin && dev_fin[0] == '1') {
-      ARK_LAUNCH((groth16_finalize_kernel<Curve>), dim3(1), dim3(192), 0, st, (const XYZZ<Fq>*)g1res,
+      ARK_LAUNCH((groth16_finalize_kernel<Curve>), dim3(1), dim3(192), 0, sR, (const XYZZ<Fq>*)g1res,
                  (const XYZZ<Fq2>*)g2res, sc.rs.as<Fr>(), sc.proof.as<unsigned char>());
       ARK_CHECK_LAUNCH();
-      ARK_CHECK_HIP(hipMemcpyAsync(out->a, sc.proof.p, sizeof(Affine<Fq>), hipMemcpyDeviceToHost, st));
-      ARK_CHECK_HIP(hipMemcpyAsync(out->b, (uint8_t*)sc.proof.p + sizeof(Affine<Fq>), sizeof(Affine<Fq2>), hipMemcpyDeviceToHost, st));
-      ARK_CHECK_HIP(hipMemcpyAsync(out->c, (uint8_t*)sc.proof.p + sizeof(Affine<Fq>) + sizeof(Affine<Fq2>), sizeof(Affine<Fq>), hipMemcpyDeviceToHost, st));
-      ARK_CHECK_HIP(hipEventRecord(ev[7], st));
-      ARK_CHECK_HIP(hipStreamSynchronize(st));
+      ARK_CHECK_HIP(hipMemcpyAsync(out->a, sc.proof.p, sizeof(Affine<Fq>), hipMemcpyDeviceToHost, sR));
+      ARK_CHECK_HIP(hipMemcpyAsync(out->b, (uint8_t*)sc.proof.p + sizeof(Affine<Fq>), sizeof(Affine<Fq2>), hipMemcpyDeviceToHost, sR));
+      ARK_CHECK_HIP(hipMemcpyAsync(out->c, (uint8_t*)sc.proof.p + sizeof(Affine<Fq>) + sizeof(Affine<Fq2>), sizeof(Affine<Fq>), hipMemcpyDeviceToHost, sR));
+      ARK_CHECK_HIP(hipEventRecord(ev[E_END], sR));
+      ARK_CHECK_HIP(hipStreamSynchronize(sR));
     } else {
       XYZZ<Fq> h1[4];
       XYZZ<Fq2> h2;
-      ARK_CHECK_HIP(hipMemcpyAsync(h1, g1res, sizeof(h1), hipMemcpyDeviceToHost, st));
-      ARK_CHECK_HIP(hipMemcpyAsync(&h2, g2res, sizeof(h2), hipMemcpyDeviceToHost, st));
-      ARK_CHECK_HIP(hipEventRecord(ev[7], st));
-      ARK_CHECK_HIP(hipStreamSynchronize(st));
+      ARK_CHECK_HIP(hipMemcpyAsync(h1, g1res, sizeof(h1), hipMemcpyDeviceToHost, sR));
+      ARK_CHECK_HIP(hipMemcpyAsync(&h2, g2res, sizeof(h2), hipMemcpyDeviceToHost, sR));
+      ARK_CHECK_HIP(hipEventRecord(ev[E_END], sR));
+      ARK_CHECK_HIP(hipStreamSynchronize(sR));
       // host tail: C = s*A + r*B1 + L' + H ; three affine normalisations
       XYZZ<Fq> c = xyzz_add(xyzz_mul_scalar(h1[0], scn.l, Fr::N), xyzz_mul_scalar(h1[1], rc.l, Fr::N));
       c = xyzz_add(c, h1[2]);
@@ -232,35 +284,34 @@ static void prove_run(ark355_ctx* ctx, ProverScratch& sc, const PkDev& pk, const
       memcpy(out->b, &pb, sizeof(pb));
       memcpy(out->c, &pc, sizeof(pc));
     }
-    auto el = [&](int a, int b) {
+    // every stream has drained into sR through the event chain; make the host view consistent
+    ARK_CHECK_HIP(hipStreamSynchronize(sA));
+    ARK_CHECK_HIP(hipStreamSynchronize(sS));
+    ARK_CHECK_HIP(hipStreamSynchronize(sW));
+    auto el = [&](hipEvent_t a, hipEvent_t b) {
       float ms = 0;
-      (void)hipEventElapsedTime(&ms, ev[a], ev[b]);
+      (void)hipEventElapsedTime(&ms, a, b);
       return ms;
     };
-    ctx->timings.total_ms = el(0, 7);
-    ctx->timings.h2d_ms = el(0, 1);
-    ctx->timings.witness_map_ms = el(1, 2);
-    ctx->timings.msm_h_ms = el(2, 3);
-    ctx->timings.msm_l_ms = el(3, 4);
-    ctx->timings.msm_ab_g1_ms = el(4, 5);
-    ctx->timings.msm_b_g2_ms = el(5, 6);
-    ctx->timings.finalize_ms = el(6, 7);
+    // phases overlap across streams: the entries are elapsed times of the respective stream segments
+    ctx->timings.total_ms = el(ev[E_START], ev[E_END]);
+    ctx->timings.h2d_ms = el(ev[E_START], ev[E_Z]);
+    ctx->timings.witness_map_ms = el(ev[E_Z], ev[E_H]);
+    ctx->timings.msm_ab_g1_ms = el(acc0[0], ev[E_ACC_DONE0 + 1]);
+    ctx->timings.msm_b_g2_ms = el(acc0[2], ev[E_ACC_DONE0 + 2]);
+    ctx->timings.msm_l_ms = el(acc0[3], ev[E_ACC_DONE0 + 3]);
+    ctx->timings.msm_h_ms = el(acc0[4], ev[E_ACC_DONE0 + 4]);
+    ctx->timings.finalize_ms = el(ev[E_ACC_DONE0 + 4], ev[E_END]);
     float acc_ms = 0;
-    for (int i = 0; i < 5; i++) {
-      float ms = 0;
-      (void)hipEventElapsedTime(&ms, acc0[i], acc1[i]);
-      acc_ms += ms;
-    }
+    for (int i = 0; i < 5; i++) acc_ms += el(acc0[i], acc1[i]);
     ctx->acc_ms = acc_ms;
     ctx->acc_launches = 5;
     ctx->acc_points = pts;
   } catch (...) {
-    for (auto& e : ev) (void)hipEventDestroy(e);
-    for (int i = 0; i < 5; i++) { (void)hipEventDestroy(acc0[i]); (void)hipEventDestroy(acc1[i]); }
+    cleanup();
     throw;
   }
-  for (auto& e : ev) (void)hipEventDestroy(e);
-  for (int i = 0; i < 5; i++) { (void)hipEventDestroy(acc0[i]); (void)hipEventDestroy(acc1[i]); }
+  cleanup();
 }
 
 }  // namespace ark355

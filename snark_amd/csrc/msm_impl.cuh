@@ -21,6 +21,7 @@
 //
 // Algorithmic bytes per term: 32 B scalar + affine base (G1 96 B / G2 192 B BLS12-381).
 #pragma once
+#include <type_traits>
 #include "common.h"
 
 namespace ark355 {
@@ -29,6 +30,9 @@ constexpr uint32_t MSM_INVALID = 0xFFFFFFFFu;
 constexpr uint32_t MSM_SEG = 32;          // entries per accumulate lane
 constexpr uint32_t MSM_RED_K = 16;        // buckets per reduce lane
 constexpr uint32_t MSM_THREADS = 256;
+#ifndef ARK_G2_INLINE_DEFAULT
+#define ARK_G2_INLINE_DEFAULT 1
+#endif
 
 struct MsmPlan {
   uint64_t n = 0;
@@ -188,17 +192,37 @@ msm_accumulate_kernel(const Affine<F>* __restrict__ bases, const uint32_t* __res
   uint32_t run_start = start;
   bool first_run = true;
   XYZZ<F> acc = XYZZ<F>::inf();
-  // software prefetch: the next base (a random 96/192-byte gather from the window tables) is in flight
-  // while the current mixed addition runs
+  // Software prefetch: the next base (a random 96/192-byte gather from the window tables) is in flight while the
+  // current mixed addition runs.  It is held in explicit 16-byte registers: a struct copy here was lowered by
+  // hipcc to scratch-to-scratch copies with a vmcnt(0) after every load (seen in the round-1 ISA).
+  constexpr int Q = sizeof(Affine<F>) / 16;
+  uint4 nx[Q];
   uint32_t v_next = sorted_vals[start];
-  Affine<F> p_next = bases[v_next & 0x7FFFFFFFu];
+  {
+    const uint4* src = reinterpret_cast<const uint4*>(bases + (v_next & 0x7FFFFFFFu));
+#pragma unroll
+    for (int k = 0; k < Q; k++) nx[k] = src[k];
+  }
   for (uint32_t e = start; e < end; e++) {
     const uint32_t key = sorted_keys[e];
     const uint32_t v = v_next;
-    Affine<F> p = p_next;
-    if (e + 1 < end) {
-      v_next = sorted_vals[e + 1];
-      p_next = bases[v_next & 0x7FFFFFFFu];
+    Affine<F> p;
+    {
+      uint32_t* d = reinterpret_cast<uint32_t*>(&p);
+#pragma unroll
+      for (int k = 0; k < Q; k++) {
+        d[4 * k + 0] = nx[k].x;
+        d[4 * k + 1] = nx[k].y;
+        d[4 * k + 2] = nx[k].z;
+        d[4 * k + 3] = nx[k].w;
+      }
+    }
+    {
+      const uint32_t en = (e + 1 < end) ? e + 1 : e;     // clamp: the last iteration re-reads its own entry
+      v_next = sorted_vals[en];
+      const uint4* src = reinterpret_cast<const uint4*>(bases + (v_next & 0x7FFFFFFFu));
+#pragma unroll
+      for (int k = 0; k < Q; k++) nx[k] = src[k];
     }
     if (key != cur_key) {
       msm_flush_run<F>(cur_key, acc, first_run, run_start, e, seg, offsets, counts, buckets, head, head_key, tail,
@@ -476,15 +500,12 @@ struct MsmBuckets {
   DevBuf buckets, head, tail, head_key, tail_key, partials;
 };
 
-// Accumulate + reduce over an existing sort; writes/accumulates the XYZZ result into d_out (device).
+// Phase 1 of the bucket method over an existing sort: bucket accumulation + straddling-run merge.
 template <class F>
-static void msm_buckets(ark355_ctx* ctx, const MsmSort& s, MsmBuckets& b, const Affine<F>* d_bases, XYZZ<F>* d_out,
-                        int accumulate, hipStream_t stream, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr) {
+static void msm_accumulate_phase(ark355_ctx* ctx, const MsmSort& s, MsmBuckets& b, const Affine<F>* d_bases,
+                                 hipStream_t stream, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr) {
   const MsmPlan& p = s.plan;
-  if (p.n == 0) {
-    if (!accumulate) ARK_CHECK_HIP(hipMemsetAsync(d_out, 0, sizeof(XYZZ<F>), stream));
-    return;
-  }
+  if (p.n == 0) return;
   const uint32_t segs = s.max_segments;
   b.buckets.ensure((size_t)p.total_buckets * sizeof(XYZZ<F>));
   b.head.ensure((size_t)segs * sizeof(XYZZ<F>));
@@ -496,13 +517,26 @@ static void msm_buckets(ark355_ctx* ctx, const MsmSort& s, MsmBuckets& b, const 
   ARK_CHECK_HIP(hipMemsetAsync(b.tail_key.p, 0xFF, (size_t)segs * 4, stream));
   const uint32_t grid_s = (segs + MSM_THREADS - 1) / MSM_THREADS;
   if (ev0) ARK_CHECK_HIP(hipEventRecord(ev0, stream));
-  // G2 (Fq2) runs the out-of-line mixed addition: inlining 30 Fq multiplications spills (measured 0.53 vs
-  // 0.73 Gadd/s on MI355X); G1 keeps it inlined (3.7 vs 2.8 Gadd/s)
-  constexpr bool NI = sizeof(F) > 64;
-  ARK_LAUNCH((msm_accumulate_kernel<F, NI>), dim3(grid_s), dim3(MSM_THREADS), 0, stream, d_bases,
-             s.sorted_keys.as<uint32_t>(), s.sorted_vals.as<uint32_t>(), s.total.as<uint32_t>(),
-             s.offsets.as<uint32_t>(), s.counts.as<uint32_t>(), b.buckets.as<XYZZ<F>>(), b.head.as<XYZZ<F>>(),
-             b.head_key.as<uint32_t>(), b.tail.as<XYZZ<F>>(), b.tail_key.as<uint32_t>());
+  // G2 (Fq2): inlining 30 Fq multiplications costs registers (256 VGPR + 256 AGPR, 1 wave/SIMD), the
+  // out-of-line flavour keeps acc in scratch across calls; measured on MI355X with the asm multiplier the
+  // inlined one wins (1.04 vs 0.85 Gadd/s).  ARK355_G2_INLINE=0|1 overrides.  G1 always inlines.
+  static const int g2_inline = [] {
+    const char* e = getenv("ARK355_G2_INLINE");
+    return e ? (e[0] == '1') : ARK_G2_INLINE_DEFAULT;
+  }();
+  auto launch = [&](auto ni_tag) {
+    constexpr bool NI = decltype(ni_tag)::value;
+    ARK_LAUNCH((msm_accumulate_kernel<F, NI>), dim3(grid_s), dim3(MSM_THREADS), 0, stream, d_bases,
+               s.sorted_keys.as<uint32_t>(), s.sorted_vals.as<uint32_t>(), s.total.as<uint32_t>(),
+               s.offsets.as<uint32_t>(), s.counts.as<uint32_t>(), b.buckets.as<XYZZ<F>>(), b.head.as<XYZZ<F>>(),
+               b.head_key.as<uint32_t>(), b.tail.as<XYZZ<F>>(), b.tail_key.as<uint32_t>());
+  };
+  if constexpr (sizeof(F) > 64) {
+    if (g2_inline) launch(std::false_type{});
+    else launch(std::true_type{});
+  } else {
+    launch(std::false_type{});
+  }
   ARK_CHECK_LAUNCH();
   if (ev1) ARK_CHECK_HIP(hipEventRecord(ev1, stream));
   const uint32_t grid_b = (p.total_buckets + MSM_THREADS - 1) / MSM_THREADS;
@@ -510,6 +544,18 @@ static void msm_buckets(ark355_ctx* ctx, const MsmSort& s, MsmBuckets& b, const 
              s.offsets.as<uint32_t>(), s.counts.as<uint32_t>(), b.buckets.as<XYZZ<F>>(), b.head.as<XYZZ<F>>(),
              b.head_key.as<uint32_t>(), b.tail.as<XYZZ<F>>(), b.tail_key.as<uint32_t>());
   ARK_CHECK_LAUNCH();
+}
+
+// Phase 2: weighted bucket reduction + window combination; writes/accumulates the XYZZ result into d_out.
+// Only a handful of workgroups and latency-bound, so the prover runs it on its own stream underneath the next
+// MSM's accumulation.
+template <class F>
+static void msm_reduce_phase(ark355_ctx* ctx, const MsmPlan& p, MsmBuckets& b, XYZZ<F>* d_out, int accumulate,
+                             hipStream_t stream) {
+  if (p.n == 0) {
+    if (!accumulate) ARK_CHECK_HIP(hipMemsetAsync(d_out, 0, sizeof(XYZZ<F>), stream));
+    return;
+  }
   const uint32_t chunks = (p.buckets_per_window + MSM_RED_K - 1) / MSM_RED_K;
   const uint32_t blocks_per_window = (chunks + MSM_THREADS - 1) / MSM_THREADS;
   b.partials.ensure((size_t)blocks_per_window * p.key_windows * sizeof(XYZZ<F>));
@@ -520,6 +566,14 @@ static void msm_buckets(ark355_ctx* ctx, const MsmSort& s, MsmBuckets& b, const 
   ARK_LAUNCH((msm_combine_kernel<F>), dim3(1), dim3(64), 0, stream, b.partials.as<XYZZ<F>>(), blocks_per_window,
              p.key_windows, p.c, d_out, accumulate);
   ARK_CHECK_LAUNCH();
+}
+
+// Both phases on one stream.
+template <class F>
+static void msm_buckets(ark355_ctx* ctx, const MsmSort& s, MsmBuckets& b, const Affine<F>* d_bases, XYZZ<F>* d_out,
+                        int accumulate, hipStream_t stream, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr) {
+  msm_accumulate_phase<F>(ctx, s, b, d_bases, stream, ev0, ev1);
+  msm_reduce_phase<F>(ctx, s.plan, b, d_out, accumulate, stream);
 }
 
 }  // namespace ark355

@@ -1,0 +1,352 @@
+// C++ host-side mirror of `ark_snark::SNARK` (/root/reference/snark/src/lib.rs:22-81) with ONE implementor,
+// Groth16<Curve>, whose `prove` calls the MI355X backend through the C ABI (include/ark355.h).
+//
+//   SNARK::circuit_specific_setup(circuit, rng) -> (ProvingKey, VerifyingKey)     lib.rs:43-46, :87-92
+//   SNARK::prove(&pk, circuit, rng) -> Proof                                       lib.rs:50-54
+//   SNARK::verify / process_vk / verify_with_processed_vk                          lib.rs:59-80: NOT on the
+//       accelerated path -- the arkworks host keeps its CPU verifier (proofs are byte-compatible).
+//
+// `prove` follows the un-vendored ark-groth16 `create_random_proof_with_reduction`: new constraint system,
+// OptimizationGoal::Constraints, generate_constraints, finalize, matrices + assignment, then r and s drawn
+// from the rng IN THAT ORDER, then the device call.  After the first proof of a circuit the CSR matrices are
+// resident and synthesis runs in the witness-only mode of SURVEY.md 3.2
+// (SynthesisMode::Prove{construct_matrices: false, generate_lc_assignments: false}).
+#pragma once
+#include <cstring>
+#include <functional>
+#include <memory>
+#include <stdexcept>
+#include <vector>
+
+#include "../../include/ark355.h"
+#include "../csrc/curve.cuh"
+#include "relations.hpp"
+
+namespace ark355 {
+template <class FP>
+inline FP fr_from_params_host(uint32_t (*f)(int)) {
+  FP r;
+  for (int i = 0; i < FP::N; i++) r.l[i] = f(i);
+  return r;
+}
+}  // namespace ark355
+
+namespace ark_snark {
+
+// Field element with value semantics over the library's Montgomery arithmetic (host instantiation).
+template <class FP>
+struct Field {
+  FP v;
+  static Field zero() { return Field{FP::zero()}; }
+  static Field one() { return Field{FP::one()}; }
+  static Field from_u64(uint64_t x) {
+    FP c = FP::zero();
+    c.l[0] = (uint32_t)x;
+    c.l[1] = (uint32_t)(x >> 32);
+    return Field{FP::to_mont(c)};
+  }
+  // canonical little-endian bytes -> element (value must be < modulus)
+  static Field from_canonical_bytes(const uint8_t* b) {
+    FP c;
+    memcpy(c.l, b, sizeof(FP));
+    return Field{FP::to_mont(c)};
+  }
+  void to_canonical_bytes(uint8_t* out) const {
+    FP c = FP::from_mont(v);
+    memcpy(out, c.l, sizeof(FP));
+  }
+  Field operator+(const Field& o) const { return Field{FP::add(v, o.v)}; }
+  Field operator-(const Field& o) const { return Field{FP::sub(v, o.v)}; }
+  Field operator-() const { return Field{FP::neg(v)}; }
+  Field operator*(const Field& o) const { return Field{FP::mul(v, o.v)}; }
+  bool operator==(const Field& o) const { return v == o.v; }
+  bool operator!=(const Field& o) const { return !(v == o.v); }
+  Field inverse() const { return Field{FP::inv(v)}; }
+  Field pow_u64(uint64_t e) const {
+    Field r = one(), b = *this;
+    while (e) {
+      if (e & 1) r = r * b;
+      b = b * b;
+      e >>= 1;
+    }
+    return r;
+  }
+};
+
+struct BlsCurveTag {
+  static constexpr int ID = ARK355_BLS12_381;
+  using FrP = ark355::BlsFr;
+  using FqP = ark355::BlsFq;
+  using Consts = ark355::BlsCurveConsts;
+  using FrParams = ark355::BlsFrParams;
+};
+struct BnCurveTag {
+  static constexpr int ID = ARK355_BN254;
+  using FrP = ark355::BnFr;
+  using FqP = ark355::BnFq;
+  using Consts = ark355::BnCurveConsts;
+  using FrParams = ark355::BnFrParams;
+};
+
+struct BackendError : std::runtime_error {
+  int code;
+  BackendError(int c, const std::string& m) : std::runtime_error(m), code(c) {}
+};
+
+// RAII device context shared by keys
+class Backend {
+ public:
+  explicit Backend(int device = 0) {
+    int rc = ark355_ctx_create(device, &ctx_);
+    if (rc != ARK355_OK) throw BackendError(rc, "ark355_ctx_create failed (no GPU? the backend has no CPU fallback)");
+  }
+  ~Backend() { ark355_ctx_destroy(ctx_); }
+  Backend(const Backend&) = delete;
+  ark355_ctx* ctx() const { return ctx_; }
+  void check(int rc) const {
+    if (rc == ARK355_OK) return;
+    if (rc == ARK355_E_ASSIGNMENT_MISSING) throw ark_relations::SynthesisError(ark_relations::SynthesisErrorKind::AssignmentMissing);
+    if (rc == ARK355_E_POLY_DEGREE_TOO_LARGE) throw ark_relations::SynthesisError(ark_relations::SynthesisErrorKind::PolynomialDegreeTooLarge);
+    if (rc == ARK355_E_UNSATISFIABLE) throw ark_relations::SynthesisError(ark_relations::SynthesisErrorKind::Unsatisfiable);
+    throw BackendError(rc, ark355_last_error(ctx_));
+  }
+
+ private:
+  ark355_ctx* ctx_ = nullptr;
+};
+
+template <class C>
+class Groth16 {
+ public:
+  using Fr = Field<typename C::FrP>;
+  using Rng = std::function<Fr()>;                      // uniform field elements (`Fr::rand(rng)`)
+  using Circuit = ark_relations::gr1cs::ConstraintSynthesizer<Fr>;
+  using CSRef = ark_relations::gr1cs::ConstraintSystemRef<Fr>;
+  static constexpr size_t FR = sizeof(typename C::FrP), G1 = 2 * sizeof(typename C::FqP), G2 = 4 * sizeof(typename C::FqP);
+
+  struct VerifyingKey {
+    std::vector<uint8_t> alpha_g1, beta_g2, gamma_g2, delta_g2, gamma_abc_g1;
+  };
+  struct ProvingKey {
+    VerifyingKey vk;
+    std::vector<uint8_t> beta_g1, delta_g1, a_query, b_g1_query, b_g2_query, h_query, l_query;
+    uint64_t ell = 0, w = 0, n = 0, N = 0;
+    // device residency (created on first prove; shared_ptr so that keys stay copyable like the Rust type)
+    struct Resident {
+      ark355_pk* pk = nullptr;
+      ark355_r1cs* r1cs = nullptr;
+      ~Resident() {
+        ark355_pk_free(pk);
+        ark355_r1cs_free(r1cs);
+      }
+    };
+    std::shared_ptr<Resident> resident;
+  };
+  struct Proof {
+    std::vector<uint8_t> a, b, c;      // raw affine points (Montgomery images)
+  };
+
+  explicit Groth16(std::shared_ptr<Backend> be) : be_(std::move(be)) {}
+
+  // ---- CSR of the R1CS matrices ---------------------------------------------------------------------------
+  struct Csr {
+    std::vector<uint64_t> row_ptr[3];
+    std::vector<uint32_t> col[3];
+    std::vector<uint8_t> coeff[3];
+  };
+  static Csr to_csr(const std::vector<ark_relations::Matrix<Fr>>& mats) {
+    Csr c;
+    for (int k = 0; k < 3; k++) {
+      c.row_ptr[k].push_back(0);
+      for (const auto& row : mats[k]) {
+        for (const auto& cj : row) {
+          c.col[k].push_back((uint32_t)cj.second);
+          const uint8_t* p = reinterpret_cast<const uint8_t*>(cj.first.v.l);
+          c.coeff[k].insert(c.coeff[k].end(), p, p + FR);
+        }
+        c.row_ptr[k].push_back(c.col[k].size());
+      }
+      if (c.col[k].empty()) c.col[k].push_back(0);
+      if (c.coeff[k].empty()) c.coeff[k].resize(FR);
+    }
+    return c;
+  }
+
+  // ---- SNARK::circuit_specific_setup ------------------------------------------------------------------------
+  std::pair<ProvingKey, VerifyingKey> circuit_specific_setup(Circuit& circuit, const Rng& rng) const {
+    namespace g = ark_relations::gr1cs;
+    CSRef cs = CSRef::new_ref();
+    cs.set_optimization_goal(g::OptimizationGoal::Constraints);
+    cs.set_mode(g::SynthesisMode::setup());
+    circuit.generate_constraints(cs);
+    cs.finalize();
+    auto mats = cs.to_matrices().at(g::R1CS_PREDICATE_LABEL);
+    const uint64_t n = cs.num_constraints(), ell = cs.num_instance_variables(), w = cs.num_witness_variables(), m = ell + w;
+    uint32_t lg = 0;
+    while ((1ull << lg) < n + ell) lg++;
+    if (lg > (uint32_t)C::FrParams::TWO_ADICITY)
+      throw ark_relations::SynthesisError(ark_relations::SynthesisErrorKind::PolynomialDegreeTooLarge);
+    const uint64_t N = 1ull << lg;
+    const Fr tau = rng(), alpha = rng(), beta = rng(), gamma = rng(), delta = rng();
+    // Lagrange coefficients L_k(tau) = Z(tau)/N * w^k / (tau - w^k)
+    Fr root{ark355::fr_from_params_host<typename C::FrP>(&C::FrParams::root)};
+    Fr omega = root;
+    for (uint32_t i = 0; i < (uint32_t)C::FrParams::TWO_ADICITY - lg; i++) omega = omega * omega;
+    Fr zt = tau.pow_u64(N) - Fr::one();
+    std::vector<Fr> wk(N), den(N), pref(N);
+    Fr cur = Fr::one(), acc = Fr::one();
+    for (uint64_t k = 0; k < N; k++) {
+      wk[k] = cur;
+      den[k] = tau - cur;
+      acc = acc * den[k];
+      pref[k] = acc;
+      cur = cur * omega;
+    }
+    Fr inv = acc.inverse();
+    Fr cN = zt * Fr::from_u64(N).inverse();
+    std::vector<Fr> L(N);
+    for (uint64_t k = N; k-- > 0;) {
+      Fr dinv = inv * (k ? pref[k - 1] : Fr::one());
+      inv = inv * den[k];
+      L[k] = cN * wk[k] * dinv;
+    }
+    std::vector<Fr> u(m, Fr::zero()), v(m, Fr::zero()), ww(m, Fr::zero());
+    for (uint64_t i = 0; i < ell; i++) u[i] = L[n + i];
+    std::vector<Fr>* tgt[3] = {&u, &v, &ww};
+    for (int k = 0; k < 3; k++)
+      for (uint64_t i = 0; i < n; i++)
+        for (const auto& cj : mats[k][i]) (*tgt[k])[cj.second] = (*tgt[k])[cj.second] + L[i] * cj.first;
+    const Fr gi = gamma.inverse(), di = delta.inverse();
+    std::vector<Fr> abc(m), gabc(ell), ls(w), hs(N ? N - 1 : 0);
+    for (uint64_t i = 0; i < m; i++) abc[i] = beta * u[i] + alpha * v[i] + ww[i];
+    for (uint64_t i = 0; i < ell; i++) gabc[i] = abc[i] * gi;
+    for (uint64_t i = 0; i < w; i++) ls[i] = abc[ell + i] * di;
+    Fr t = zt * di;
+    for (uint64_t i = 0; i + 1 < N; i++) {
+      hs[i] = t;
+      t = t * tau;
+    }
+    ProvingKey pk;
+    pk.ell = ell;
+    pk.w = w;
+    pk.n = n;
+    pk.N = N;
+    auto g1 = g1_generator(), g2 = g2_generator();
+    auto one1 = fixed_base(1, g1, {alpha, beta, delta});
+    auto one2 = fixed_base(2, g2, {beta, gamma, delta});
+    pk.vk.alpha_g1.assign(one1.begin(), one1.begin() + G1);
+    pk.beta_g1.assign(one1.begin() + G1, one1.begin() + 2 * G1);
+    pk.delta_g1.assign(one1.begin() + 2 * G1, one1.end());
+    pk.vk.beta_g2.assign(one2.begin(), one2.begin() + G2);
+    pk.vk.gamma_g2.assign(one2.begin() + G2, one2.begin() + 2 * G2);
+    pk.vk.delta_g2.assign(one2.begin() + 2 * G2, one2.end());
+    pk.vk.gamma_abc_g1 = fixed_base(1, g1, gabc);
+    pk.a_query = fixed_base(1, g1, u);
+    pk.b_g1_query = fixed_base(1, g1, v);
+    pk.b_g2_query = fixed_base(2, g2, v);
+    pk.h_query = fixed_base(1, g1, hs);
+    pk.l_query = fixed_base(1, g1, ls);
+    return {pk, pk.vk};
+  }
+
+  // ---- SNARK::prove -----------------------------------------------------------------------------------------------
+  Proof prove(ProvingKey& pk, Circuit& circuit, const Rng& rng) const {
+    namespace g = ark_relations::gr1cs;
+    CSRef cs = CSRef::new_ref();
+    cs.set_optimization_goal(g::OptimizationGoal::Constraints);
+    const bool resident = pk.resident && pk.resident->r1cs;
+    if (resident) cs.set_mode(g::SynthesisMode::prove(false, false));      // witness-only synthesis
+    circuit.generate_constraints(cs);
+    cs.finalize();
+    if (!resident) load(pk, cs);
+    std::vector<Fr> z = cs.borrow().full_assignment();
+    const Fr r = rng(), s = rng();
+    return create_proof_with_assignment(pk, z, r, s);
+  }
+
+  // upstream `create_proof_with_reduction_and_matrices` counterpart: explicit assignment and randomisers
+  Proof create_proof_with_assignment(ProvingKey& pk, const std::vector<Fr>& z, const Fr& r, const Fr& s) const {
+    if (!pk.resident || !pk.resident->pk || !pk.resident->r1cs) throw std::logic_error("proving key is not resident");
+    uint8_t rc[32] = {0}, sc[32] = {0};
+    r.to_canonical_bytes(rc);
+    s.to_canonical_bytes(sc);
+    ark355_proof_raw raw;
+    be_->check(ark355_prove(be_->ctx(), pk.resident->pk, pk.resident->r1cs, reinterpret_cast<const uint8_t*>(z.data()),
+                            z.size(), rc, sc, &raw));
+    Proof p;
+    p.a.assign(raw.a, raw.a + G1);
+    p.b.assign(raw.b, raw.b + G2);
+    p.c.assign(raw.c, raw.c + G1);
+    return p;
+  }
+
+  void load(ProvingKey& pk, const CSRef& cs) const {
+    namespace g = ark_relations::gr1cs;
+    auto res = std::make_shared<typename ProvingKey::Resident>();
+    Csr csr = to_csr(cs.to_matrices().at(g::R1CS_PREDICATE_LABEL));
+    const uint64_t* rp[3] = {csr.row_ptr[0].data(), csr.row_ptr[1].data(), csr.row_ptr[2].data()};
+    const uint32_t* cl[3] = {csr.col[0].data(), csr.col[1].data(), csr.col[2].data()};
+    const uint8_t* cf[3] = {csr.coeff[0].data(), csr.coeff[1].data(), csr.coeff[2].data()};
+    be_->check(ark355_r1cs_load(be_->ctx(), C::ID, cs.num_constraints(), cs.num_instance_variables(),
+                                cs.num_witness_variables(), rp, cl, cf, &res->r1cs));
+    ark355_pk_desc d;
+    d.num_instance = pk.ell;
+    d.num_witness = pk.w;
+    d.domain_size = pk.N;
+    d.a_query = pk.a_query.data();
+    d.b_g1_query = pk.b_g1_query.data();
+    d.b_g2_query = pk.b_g2_query.data();
+    d.h_query = pk.h_query.data();
+    d.l_query = pk.l_query.data();
+    d.alpha_g1 = pk.vk.alpha_g1.data();
+    d.beta_g1 = pk.beta_g1.data();
+    d.delta_g1 = pk.delta_g1.data();
+    d.beta_g2 = pk.vk.beta_g2.data();
+    d.delta_g2 = pk.vk.delta_g2.data();
+    be_->check(ark355_pk_load(be_->ctx(), C::ID, &d, &res->pk));
+    pk.resident = res;
+  }
+
+  // SNARK::verify family: outside the accelerated path
+  bool verify(const VerifyingKey&, const std::vector<Fr>&, const Proof&) const {
+    throw std::logic_error("SNARK::verify stays on the arkworks host (CPU); proofs are byte-compatible");
+  }
+
+  static std::vector<uint8_t> g1_generator() {
+    using Fq = typename C::FqP;
+    std::vector<uint8_t> out(G1);
+    Fq x, y;
+    for (int i = 0; i < Fq::N; i++) {
+      x.l[i] = C::Consts::g1_gen_x(i);
+      y.l[i] = C::Consts::g1_gen_y(i);
+    }
+    memcpy(out.data(), x.l, sizeof(Fq));
+    memcpy(out.data() + sizeof(Fq), y.l, sizeof(Fq));
+    return out;
+  }
+  static std::vector<uint8_t> g2_generator() {
+    using Fq = typename C::FqP;
+    std::vector<uint8_t> out(G2);
+    Fq c[4];
+    for (int i = 0; i < Fq::N; i++) {
+      c[0].l[i] = C::Consts::g2_gen_x0(i);
+      c[1].l[i] = C::Consts::g2_gen_x1(i);
+      c[2].l[i] = C::Consts::g2_gen_y0(i);
+      c[3].l[i] = C::Consts::g2_gen_y1(i);
+    }
+    for (int k = 0; k < 4; k++) memcpy(out.data() + k * sizeof(Fq), c[k].l, sizeof(Fq));
+    return out;
+  }
+
+ private:
+  std::vector<uint8_t> fixed_base(int group, const std::vector<uint8_t>& base, const std::vector<Fr>& scalars) const {
+    const size_t psz = group == 1 ? G1 : G2;
+    std::vector<uint8_t> sc(scalars.size() * FR), out(scalars.size() * psz);
+    for (size_t i = 0; i < scalars.size(); i++) scalars[i].to_canonical_bytes(sc.data() + i * FR);
+    be_->check(ark355_fixed_base_mul(be_->ctx(), C::ID, group, base.data(), sc.data(), scalars.size(), out.data()));
+    return out;
+  }
+  std::shared_ptr<Backend> be_;
+};
+
+}  // namespace ark_snark

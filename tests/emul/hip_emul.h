@@ -33,6 +33,10 @@ struct dim3 {
   dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
 };
 
+struct uint4 {
+  unsigned x, y, z, w;
+};
+
 namespace emu {
 enum State { RUN = 0, WAVE_WAIT = 1, BLOCK_WAIT = 2, DONE = 3 };
 struct Thread {

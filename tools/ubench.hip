@@ -50,6 +50,39 @@ __global__ void __launch_bounds__(256) k_madd(XYZZ<F>* out, const Affine<F>* in,
   out[t] = acc;
 }
 
+template <class F>
+__global__ void k_check(const uint32_t* in, int n, unsigned* bad) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  F a, b;
+  for (int i = 0; i < F::N; i++) { a.l[i] = in[(2 * t) * 16 + i]; b.l[i] = in[(2 * t + 1) * 16 + i]; }
+  F x = F::mul(a, b), y = F::mul_c(a, b);
+  F s1 = F::mul(a, a), s2 = F::mul_c(a, a);
+  if (x != y || s1 != s2) atomicAdd(bad, 1u);
+}
+
+template <class F>
+static int check_mul(const char* name) {
+  const int n = 1 << 16;
+  uint32_t* h = (uint32_t*)calloc((size_t)n * 2 * 16, 4);
+  uint64_t st = 88172645463325252ull;
+  for (int t = 0; t < 2 * n; t++) {
+    for (int i = 0; i < F::N; i++) { st ^= st << 13; st ^= st >> 7; st ^= st << 17; h[t * 16 + i] = (uint32_t)(st >> 16); }
+    h[t * 16 + F::N - 1] %= F::Params::mod(F::N - 1);                 // strictly below the modulus
+    if (t % 97 == 0) for (int i = 0; i < F::N; i++) h[t * 16 + i] = F::Params::mod(i) - (i == 0 ? 1 : 0);   // p - 1
+    if (t % 101 == 0) for (int i = 0; i < F::N; i++) h[t * 16 + i] = 0;
+    if (t % 103 == 0) for (int i = 0; i < F::N; i++) h[t * 16 + i] = (i < F::N - 1) ? 0xFFFFFFFFu : F::Params::mod(i) - 1;
+  }
+  uint32_t* d; unsigned* bad; unsigned hb = 0;
+  hipMalloc(&d, (size_t)n * 2 * 16 * 4); hipMalloc(&bad, 4); hipMemset(bad, 0, 4);
+  hipMemcpy(d, h, (size_t)n * 2 * 16 * 4, hipMemcpyHostToDevice);
+  hipLaunchKernelGGL((k_check<F>), dim3(n / 256), dim3(256), 0, 0, d, n, bad);
+  hipMemcpy(&hb, bad, 4, hipMemcpyDeviceToHost);
+  printf("asm-vs-C Montgomery mul check %-8s: %s (%u mismatches of %d)\n", name, hb ? "MISMATCH" : "MATCH", hb, n);
+  hipFree(d); hipFree(bad); free(h);
+  return hb != 0;
+}
+
 static float time_it(void (*launch)(void*), void* ctx, int reps) {
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   launch(ctx); hipDeviceSynchronize();
@@ -68,6 +101,8 @@ template <class F, bool NI> static void l_madd(void* c) { Ctx* x = (Ctx*)c; hipL
 int main() {
   hipDeviceProp_t prop; CHECK(hipGetDeviceProperties(&prop, 0));
   printf("device: %s  CUs=%d  clock=%d MHz  LDS/block=%zu  regs/block=%d\n", prop.name, prop.multiProcessorCount, prop.clockRate / 1000, prop.sharedMemPerBlock, prop.regsPerBlock);
+  int bad = check_mul<BlsFq>("BlsFq") | check_mul<BlsFr>("BlsFr") | check_mul<BnFq>("BnFq") | check_mul<BnFr>("BnFr");
+  if (bad) printf("!!! asm multiplication is WRONG\n");
   Ctx c; c.blocks = prop.multiProcessorCount * 8; c.iters = 2000;
   CHECK(hipMalloc(&c.out, (size_t)c.blocks * 256 * 1024)); CHECK(hipMalloc(&c.in, 1024 * 512));
   // fill inputs with valid-ish field elements: small integers (valid residues)
