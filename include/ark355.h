@@ -106,6 +106,20 @@ int32_t ark355_prove(ark355_ctx* ctx, const ark355_pk* pk, const ark355_r1cs* r1
 int32_t ark355_prove_dev(ark355_ctx* ctx, const ark355_pk* pk, const ark355_r1cs* r1cs, const void* d_z,
                          uint64_t z_len, const uint8_t r[32], const uint8_t s[32], ark355_proof_raw* out);
 
+/* ---- one proof, MSM term ranges sharded over several GPUs (BASELINE.json configs[2]) ----------
+ * Every rank loads shard `shard_index` of `shard_count` of the SAME key descriptor (terms
+ * [T*i/G, T*(i+1)/G) of each query vector), computes the witness map redundantly, and returns the five
+ * partial sums (A, B1, L', H as G1 XYZZ, then B2 as G2 XYZZ; ark355_partial_size() bytes).  The ranks
+ * exchange the partials (an all-gather of <1 KiB per rank: RCCL has no elliptic-curve reduction operator) and
+ * each calls ark355_prove_combine, which adds them and finishes the proof -- byte-identical to ark355_prove. */
+int32_t ark355_pk_load_shard(ark355_ctx* ctx, int32_t curve, const ark355_pk_desc* desc, uint32_t shard_index,
+                             uint32_t shard_count, ark355_pk** out);
+uint64_t ark355_partial_size(int32_t curve);
+int32_t ark355_prove_shard(ark355_ctx* ctx, const ark355_pk* pk_shard, const ark355_r1cs* r1cs, const uint8_t* z,
+                           uint64_t z_len, const uint8_t r[32], const uint8_t s[32], uint8_t* out_partials);
+int32_t ark355_prove_combine(ark355_ctx* ctx, int32_t curve, const uint8_t* partials, uint64_t count,
+                             const uint8_t r[32], const uint8_t s[32], ark355_proof_raw* out);
+
 /* ---- building blocks ---------------------------------------------------------------------- */
 /* R1CS -> QAP witness map h[0..N) (Montgomery), SURVEY Appendix A steps 1-5 */
 int32_t ark355_witness_map(ark355_ctx* ctx, const ark355_r1cs* r1cs, const uint8_t* z, uint64_t z_len,

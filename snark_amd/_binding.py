@@ -38,7 +38,8 @@ SYMBOLS = [
     "ark355_is_satisfied", "ark355_r1cs_mat_vec", "ark355_ntt_fr", "ark355_ntt_fr_dev",
     "ark355_msm_g1", "ark355_msm_g2", "ark355_bases_load", "ark355_bases_free", "ark355_msm_dev",
     "ark355_msm_dev_partial", "ark355_xyzz_sum", "ark355_fixed_base_mul", "ark355_get_timings",
-    "ark355_get_kernel_stats",
+    "ark355_get_kernel_stats", "ark355_pk_load_shard", "ark355_partial_size", "ark355_prove_shard",
+    "ark355_prove_combine",
 ]
 
 
@@ -123,6 +124,11 @@ class Lib:
         d.ark355_msm_dev_partial.argtypes = [vp, vp, vp, u64, i32, vp]
         d.ark355_xyzz_sum.argtypes = [vp, i32, i32, vp, u64, vp]
         d.ark355_fixed_base_mul.argtypes = [vp, i32, i32, vp, vp, u64, vp]
+        d.ark355_pk_load_shard.argtypes = [vp, i32, P(PkDesc), u32, u32, P(vp)]
+        d.ark355_partial_size.argtypes = [i32]
+        d.ark355_partial_size.restype = u64
+        d.ark355_prove_shard.argtypes = [vp, vp, vp, vp, u64, vp, vp, vp]
+        d.ark355_prove_combine.argtypes = [vp, i32, vp, u64, vp, vp, P(ProofRaw)]
         d.ark355_get_timings.argtypes = [vp, P(Timings)]
         d.ark355_get_kernel_stats.argtypes = [vp, P(C.c_float), P(u64), P(u64)]
         for name in SYMBOLS:
@@ -155,7 +161,7 @@ class Lib:
         self.dll.ark355_ctx_destroy(ctx)
 
     def pk_load(self, ctx, curve, ell, w, N, a_query, b_g1_query, b_g2_query, h_query, l_query,
-                alpha_g1, beta_g1, delta_g1, beta_g2, delta_g2):
+                alpha_g1, beta_g1, delta_g1, beta_g2, delta_g2, shard=None):
         keep = []
         d = PkDesc()
         d.num_instance, d.num_witness, d.domain_size = ell, w, N
@@ -167,7 +173,10 @@ class Lib:
             keep.append(k)
             setattr(d, name, p.value if p is not None else None)
         h = C.c_void_p()
-        self.check(ctx, self.dll.ark355_pk_load(ctx, curve, C.byref(d), C.byref(h)))
+        if shard is None:
+            self.check(ctx, self.dll.ark355_pk_load(ctx, curve, C.byref(d), C.byref(h)))
+        else:
+            self.check(ctx, self.dll.ark355_pk_load_shard(ctx, curve, C.byref(d), shard[0], shard[1], C.byref(h)))
         return h
 
     def r1cs_load(self, ctx, curve, n, ell, w, mats):
@@ -199,6 +208,22 @@ class Lib:
             zb, k3 = _buf(z)
             rc = self.dll.ark355_prove(ctx, pk, r1cs, zb, z_len, rb, sb, C.byref(out))
         self.check(ctx, rc)
+        return bytes(out.a)[:sizes["g1"]], bytes(out.b)[:sizes["g2"]], bytes(out.c)[:sizes["g1"]]
+
+    def prove_shard(self, ctx, curve, pk_shard, r1cs, z, z_len, r: bytes, s: bytes):
+        out = np.zeros(self.dll.ark355_partial_size(curve), dtype=np.uint8)
+        zb, k1 = _buf(z)
+        rb, k2 = _buf(r)
+        sb, k3 = _buf(s)
+        self.check(ctx, self.dll.ark355_prove_shard(ctx, pk_shard, r1cs, zb, z_len, rb, sb, out.ctypes.data_as(C.c_void_p)))
+        return out.tobytes()
+
+    def prove_combine(self, ctx, curve, partials: bytes, count, r: bytes, s: bytes, sizes):
+        out = ProofRaw()
+        pb, k1 = _buf(partials)
+        rb, k2 = _buf(r)
+        sb, k3 = _buf(s)
+        self.check(ctx, self.dll.ark355_prove_combine(ctx, curve, pb, count, rb, sb, C.byref(out)))
         return bytes(out.a)[:sizes["g1"]], bytes(out.b)[:sizes["g2"]], bytes(out.c)[:sizes["g1"]]
 
     def witness_map(self, ctx, r1cs, z, z_len, fr_size):

@@ -42,7 +42,9 @@ struct Api {
     what[3] = sizeof(Affine<Fq2>);
   }
 
-  static PkDev* pk_load(const ark355_pk_desc* d, hipStream_t st) { return pk_upload<Curve>(d, st); }
+  static PkDev* pk_load(const ark355_pk_desc* d, hipStream_t st, uint32_t shard_index = 0, uint32_t shard_count = 1) {
+    return pk_upload<Curve>(d, st, shard_index, shard_count);
+  }
 
   static R1csDev* r1cs_load(uint64_t n, uint64_t ell, uint64_t w, const uint64_t* const rp[3],
                             const uint32_t* const col[3], const uint8_t* const coeff[3]) {
@@ -50,9 +52,13 @@ struct Api {
   }
 
   static void prove(ark355_ctx* ctx, ProverScratch& sc, const PkDev& pk, const R1csDev& r1, const void* z,
-                    bool on_dev, const uint8_t* r, const uint8_t* s, ark355_proof_raw* out) {
-    prove_run<Curve>(ctx, sc, pk, r1, z, on_dev, r, s, out);
+                    bool on_dev, const uint8_t* r, const uint8_t* s, ark355_proof_raw* out, uint8_t* partials = nullptr) {
+    prove_run<Curve>(ctx, sc, pk, r1, z, on_dev, r, s, out, partials);
   }
+  static void combine(const uint8_t* partials, uint64_t count, const uint8_t* r, const uint8_t* s, ark355_proof_raw* out) {
+    combine_partials_host<Curve>(partials, count, r, s, out);
+  }
+  static size_t partial_size() { return 4 * sizeof(XYZZ<Fq>) + sizeof(XYZZ<Fq2>); }
 
   static void witness_map(ark355_ctx* ctx, ProverScratch& sc, const R1csDev& r1, const uint8_t* z, uint8_t* h_out) {
     hipStream_t st = ctx->stream;

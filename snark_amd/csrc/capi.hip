@@ -129,6 +129,16 @@ int32_t ark355_pk_load(ark355_ctx* ctx, int32_t curve, const ark355_pk_desc* des
     *out = new ark355_pk{d};
   });
 }
+int32_t ark355_pk_load_shard(ark355_ctx* ctx, int32_t curve, const ark355_pk_desc* desc, uint32_t shard_index,
+                             uint32_t shard_count, ark355_pk** out) {
+  if (!ctx || !desc || !out) return ARK355_EINVAL;
+  *out = nullptr;
+  return guarded(ctx, [&] {
+    PkDev* d = nullptr;
+    CURVE_DISPATCH(curve, d = A::pk_load(desc, ctx->stream, shard_index, shard_count));
+    *out = new ark355_pk{d};
+  });
+}
 void ark355_pk_free(ark355_pk* pk) {
   if (!pk) return;
   delete pk->d;
@@ -162,6 +172,10 @@ static int32_t prove_common(ark355_ctx* ctx, const ark355_pk* pk, const ark355_r
     ctx->last_error = "assignment shorter than num_instance + num_witness";
     return ARK355_E_ASSIGNMENT_MISSING;
   }
+  if (pk->d->shard_count != 1) {
+    ctx->last_error = "this key handle is an MSM shard: use ark355_prove_shard + ark355_prove_combine";
+    return ARK355_EINVAL;
+  }
   return guarded(ctx, [&] {
     CtxExtra& ex = extra(ctx);
     CURVE_DISPATCH(pk->d->curve, A::prove(ctx, ex.prover, *pk->d, *r1->d, z, on_dev, r, s, out));
@@ -175,6 +189,32 @@ int32_t ark355_prove(ark355_ctx* ctx, const ark355_pk* pk, const ark355_r1cs* r1
 int32_t ark355_prove_dev(ark355_ctx* ctx, const ark355_pk* pk, const ark355_r1cs* r1, const void* d_z, uint64_t z_len,
                          const uint8_t r[32], const uint8_t s[32], ark355_proof_raw* out) {
   return prove_common(ctx, pk, r1, d_z, z_len, true, r, s, out);
+}
+
+uint64_t ark355_partial_size(int32_t curve) {
+  size_t n = 0;
+  try {
+    CURVE_DISPATCH(curve, n = A::partial_size());
+  } catch (...) {
+    return 0;
+  }
+  return n;
+}
+
+int32_t ark355_prove_shard(ark355_ctx* ctx, const ark355_pk* pk, const ark355_r1cs* r1, const uint8_t* z, uint64_t z_len,
+                           const uint8_t r[32], const uint8_t s[32], uint8_t* out_partials) {
+  if (!ctx || !pk || !r1 || !z || !r || !s || !out_partials) return ARK355_EINVAL;
+  if (z_len < r1->d->m) return ARK355_E_ASSIGNMENT_MISSING;
+  return guarded(ctx, [&] {
+    CtxExtra& ex = extra(ctx);
+    CURVE_DISPATCH(pk->d->curve, A::prove(ctx, ex.prover, *pk->d, *r1->d, z, false, r, s, nullptr, out_partials));
+  });
+}
+
+int32_t ark355_prove_combine(ark355_ctx* ctx, int32_t curve, const uint8_t* partials, uint64_t count,
+                             const uint8_t r[32], const uint8_t s[32], ark355_proof_raw* out) {
+  if (!ctx || !partials || !count || !r || !s || !out) return ARK355_EINVAL;
+  return guarded(ctx, [&] { CURVE_DISPATCH(curve, A::combine(partials, count, r, s, out)); });
 }
 
 int32_t ark355_witness_map(ark355_ctx* ctx, const ark355_r1cs* r1, const uint8_t* z, uint64_t z_len, uint8_t* h_out) {

@@ -31,7 +31,19 @@ struct PkDev {
   uint64_t ell = 0, w = 0, m = 0, N = 0;
   // per-window tables T[w*n + i] = 2^(c*w) * P_i of the five (extended) query vectors, built at load
   PrecompTable a_ext, b1_ext, b2_ext, h_query, l_ext;
+  // MSM term-range sharding across GPUs: this handle holds terms [lo, lo+cnt) of each
+  // (extended) query vector; shard_count == 1 is the whole key
+  uint32_t shard_index = 0, shard_count = 1;
+  uint64_t z_lo = 0, z_cnt = 0;     // of the m+4 extended a/b terms
+  uint64_t l_lo = 0, l_cnt = 0;     // of the w+1 extended l terms
+  uint64_t h_lo = 0, h_cnt = 0;     // of the N-1 h terms
 };
+
+static inline void shard_range(uint64_t total, uint32_t idx, uint32_t cnt, uint64_t* lo, uint64_t* n) {
+  const uint64_t a = total * idx / cnt, b = total * (idx + 1) / cnt;
+  *lo = a;
+  *n = b - a;
+}
 
 struct ProverScratch {
   // one sort per distinct scalar vector (zx, zx[ell..], h) and one bucket set per MSM: the five MSMs of a proof
@@ -100,8 +112,52 @@ groth16_finalize_kernel(const XYZZ<typename Curve::Fq>* __restrict__ g1res,   //
   }
 }
 
+// host tail: C = s*A + r*B1 + L' + H ; three affine normalisations (O(1) work, library's own host field code)
 template <class Curve>
-static PkDev* pk_upload(const ark355_pk_desc* d, hipStream_t stream) {
+static void finalize_host(const XYZZ<typename Curve::Fq> g1[4], const XYZZ<typename Curve::Fq2>& g2,
+                          const typename Curve::Fr& r_canon, const typename Curve::Fr& s_canon, ark355_proof_raw* out) {
+  using Fq = typename Curve::Fq;
+  using Fq2 = typename Curve::Fq2;
+  using Fr = typename Curve::Fr;
+  XYZZ<Fq> c = xyzz_add(xyzz_mul_scalar(g1[0], s_canon.l, Fr::N), xyzz_mul_scalar(g1[1], r_canon.l, Fr::N));
+  c = xyzz_add(c, g1[2]);
+  c = xyzz_add(c, g1[3]);
+  Affine<Fq> pa = xyzz_to_affine(g1[0]);
+  Affine<Fq2> pb = xyzz_to_affine(g2);
+  Affine<Fq> pc = xyzz_to_affine(c);
+  memset(out, 0, sizeof(*out));
+  memcpy(out->a, &pa, sizeof(pa));
+  memcpy(out->b, &pb, sizeof(pb));
+  memcpy(out->c, &pc, sizeof(pc));
+}
+
+// sum `count` shard partials (each: 4 G1 XYZZ + 1 G2 XYZZ, as prove_run hands back) and finish the proof
+template <class Curve>
+static void combine_partials_host(const uint8_t* partials, uint64_t count, const uint8_t r_canon[32],
+                                  const uint8_t s_canon[32], ark355_proof_raw* out) {
+  using Fq = typename Curve::Fq;
+  using Fq2 = typename Curve::Fq2;
+  using Fr = typename Curve::Fr;
+  const size_t stride = 4 * sizeof(XYZZ<Fq>) + sizeof(XYZZ<Fq2>);
+  XYZZ<Fq> g1[4];
+  XYZZ<Fq2> g2 = XYZZ<Fq2>::inf();
+  for (auto& p : g1) p = XYZZ<Fq>::inf();
+  for (uint64_t k = 0; k < count; k++) {
+    XYZZ<Fq> t1[4];
+    XYZZ<Fq2> t2;
+    memcpy(t1, partials + k * stride, sizeof(t1));
+    memcpy(&t2, partials + k * stride + sizeof(t1), sizeof(t2));
+    for (int i = 0; i < 4; i++) g1[i] = xyzz_add(g1[i], t1[i]);
+    g2 = xyzz_add(g2, t2);
+  }
+  Fr rc, sc;
+  memcpy(rc.l, r_canon, sizeof(Fr));
+  memcpy(sc.l, s_canon, sizeof(Fr));
+  finalize_host<Curve>(g1, g2, rc, sc, out);
+}
+
+template <class Curve>
+static PkDev* pk_upload(const ark355_pk_desc* d, hipStream_t stream, uint32_t shard_index = 0, uint32_t shard_count = 1) {
   using Fq = typename Curve::Fq;
   using Fq2 = typename Curve::Fq2;
   constexpr size_t G1 = sizeof(Affine<Fq>), G2 = sizeof(Affine<Fq2>);
@@ -129,20 +185,26 @@ static PkDev* pk_upload(const ark355_pk_desc* d, hipStream_t stream) {
       if (t3) memcpy(tail.data() + 3 * psz, t3, psz);
       ARK_CHECK_HIP(hipMemcpy((uint8_t*)stage.p + m * psz, tail.data(), 4 * psz, hipMemcpyHostToDevice));
     };
-    ext(d->a_query, G1, d->alpha_g1, d->delta_g1, nullptr);
-    precomp_build<Fq, Fr>(pk->a_ext, stage.p, m + 4, stream);
-    ext(d->b_g1_query, G1, d->beta_g1, nullptr, d->delta_g1);
-    precomp_build<Fq, Fr>(pk->b1_ext, stage.p, m + 4, stream);
-    ext(d->b_g2_query, G2, d->beta_g2, nullptr, d->delta_g2);
-    precomp_build<Fq2, Fr>(pk->b2_ext, stage.p, m + 4, stream);
+    ARK_REQUIRE(shard_count >= 1 && shard_index < shard_count, ARK355_EINVAL, "bad shard index");
+    pk->shard_index = shard_index;
+    pk->shard_count = shard_count;
     const uint64_t hn = pk->N ? pk->N - 1 : 0;
-    stage.ensure((hn ? hn : 1) * G1);
-    if (hn) ARK_CHECK_HIP(hipMemcpy(stage.p, d->h_query, hn * G1, hipMemcpyHostToDevice));
-    precomp_build<Fq, Fr>(pk->h_query, stage.p, hn, stream);
+    shard_range(m + 4, shard_index, shard_count, &pk->z_lo, &pk->z_cnt);
+    shard_range(pk->w + 1, shard_index, shard_count, &pk->l_lo, &pk->l_cnt);
+    shard_range(hn, shard_index, shard_count, &pk->h_lo, &pk->h_cnt);
+    ext(d->a_query, G1, d->alpha_g1, d->delta_g1, nullptr);
+    precomp_build<Fq, Fr>(pk->a_ext, (uint8_t*)stage.p + pk->z_lo * G1, pk->z_cnt, stream);
+    ext(d->b_g1_query, G1, d->beta_g1, nullptr, d->delta_g1);
+    precomp_build<Fq, Fr>(pk->b1_ext, (uint8_t*)stage.p + pk->z_lo * G1, pk->z_cnt, stream);
+    ext(d->b_g2_query, G2, d->beta_g2, nullptr, d->delta_g2);
+    precomp_build<Fq2, Fr>(pk->b2_ext, (uint8_t*)stage.p + pk->z_lo * G2, pk->z_cnt, stream);
+    stage.ensure((pk->h_cnt ? pk->h_cnt : 1) * G1);
+    if (pk->h_cnt) ARK_CHECK_HIP(hipMemcpy(stage.p, d->h_query + pk->h_lo * G1, pk->h_cnt * G1, hipMemcpyHostToDevice));
+    precomp_build<Fq, Fr>(pk->h_query, stage.p, pk->h_cnt, stream);
     stage.ensure((pk->w + 1) * G1);
     if (pk->w) ARK_CHECK_HIP(hipMemcpy(stage.p, d->l_query, pk->w * G1, hipMemcpyHostToDevice));
     ARK_CHECK_HIP(hipMemcpy((uint8_t*)stage.p + pk->w * G1, d->delta_g1, G1, hipMemcpyHostToDevice));
-    precomp_build<Fq, Fr>(pk->l_ext, stage.p, pk->w + 1, stream);
+    precomp_build<Fq, Fr>(pk->l_ext, (uint8_t*)stage.p + pk->l_lo * G1, pk->l_cnt, stream);
   } catch (...) {
     delete pk;
     throw;
@@ -161,7 +223,8 @@ static PkDev* pk_upload(const ark355_pk_desc* d, hipStream_t stream) {
 //   sR               bucket reduction + combine per MSM as evAcc[i] fires; D2H of the five XYZZ results
 template <class Curve>
 static void prove_run(ark355_ctx* ctx, ProverScratch& sc, const PkDev& pk, const R1csDev& r1, const void* z_src,
-                      bool z_on_device, const uint8_t r_canon[32], const uint8_t s_canon[32], ark355_proof_raw* out) {
+                      bool z_on_device, const uint8_t r_canon[32], const uint8_t s_canon[32], ark355_proof_raw* out,
+                      uint8_t* partials_out = nullptr) {
   using Fr = typename Curve::Fr;
   using Fq = typename Curve::Fq;
   using Fq2 = typename Curve::Fq2;
@@ -219,12 +282,12 @@ static void prove_run(ark355_ctx* ctx, ProverScratch& sc, const PkDev& pk, const
 
     // sorts
     ARK_CHECK_HIP(hipStreamWaitEvent(sS, ev[E_Z], 0));
-    msm_sort<Fr>(ctx, sc.sortZ, sc.zx.p, m + 4, 1, sS, &pk.a_ext);
+    msm_sort<Fr>(ctx, sc.sortZ, (const uint8_t*)sc.zx.p + pk.z_lo * sizeof(Fr), pk.z_cnt, 1, sS, &pk.a_ext);
     ARK_CHECK_HIP(hipEventRecord(ev[E_SORT0], sS));
-    msm_sort<Fr>(ctx, sc.sortL, (const uint8_t*)sc.zx.p + ell * sizeof(Fr), pk.w + 1, 1, sS, &pk.l_ext);
+    msm_sort<Fr>(ctx, sc.sortL, (const uint8_t*)sc.zx.p + (ell + pk.l_lo) * sizeof(Fr), pk.l_cnt, 1, sS, &pk.l_ext);
     ARK_CHECK_HIP(hipEventRecord(ev[E_SORT1], sS));
     ARK_CHECK_HIP(hipStreamWaitEvent(sS, ev[E_H], 0));
-    msm_sort<Fr>(ctx, sc.sortH, d_h, pk.N - 1, 1, sS, &pk.h_query);
+    msm_sort<Fr>(ctx, sc.sortH, (const uint8_t*)d_h + pk.h_lo * sizeof(Fr), pk.h_cnt, 1, sS, &pk.h_query);
     ARK_CHECK_HIP(hipEventRecord(ev[E_SORT2], sS));
 
     // accumulations (A, B1, B2 share the sort of zx) and, per MSM, its reduction on sR
@@ -255,9 +318,14 @@ static void prove_run(ark355_ctx* ctx, ProverScratch& sc, const PkDev& pk, const
       pts += (uint64_t)jb.sort->plan.windows * jb.sort->plan.n;
     }
 
-    memset(out, 0, sizeof(*out));
+    if (out) memset(out, 0, sizeof(*out));
     const char* dev_fin = getenv("ARK355_DEVICE_FINALIZE");
-    if (dev_fin && dev_fin[0] == '1') {
+    if (partials_out) {
+      // sharded prove: hand back the five XYZZ partial sums (A, B1, L', H in G1, then B2 in G2)
+      ARK_CHECK_HIP(hipMemcpyAsync(partials_out, g1res, 4 * sizeof(XYZZ<Fq>) + sizeof(XYZZ<Fq2>), hipMemcpyDeviceToHost, sR));
+      ARK_CHECK_HIP(hipEventRecord(ev[E_END], sR));
+      ARK_CHECK_HIP(hipStreamSynchronize(sR));
+    } else if (dev_fin && dev_fin[0] == '1') {
       ARK_LAUNCH((groth16_finalize_kernel<Curve>), dim3(1), dim3(192), 0, sR, (const XYZZ<Fq>*)g1res,
                  (const XYZZ<Fq2>*)g2res, sc.rs.as<Fr>(), sc.proof.as<unsigned char>());
       ARK_CHECK_LAUNCH();
@@ -273,16 +341,7 @@ static void prove_run(ark355_ctx* ctx, ProverScratch& sc, const PkDev& pk, const
       ARK_CHECK_HIP(hipMemcpyAsync(&h2, g2res, sizeof(h2), hipMemcpyDeviceToHost, sR));
       ARK_CHECK_HIP(hipEventRecord(ev[E_END], sR));
       ARK_CHECK_HIP(hipStreamSynchronize(sR));
-      // host tail: C = s*A + r*B1 + L' + H ; three affine normalisations
-      XYZZ<Fq> c = xyzz_add(xyzz_mul_scalar(h1[0], scn.l, Fr::N), xyzz_mul_scalar(h1[1], rc.l, Fr::N));
-      c = xyzz_add(c, h1[2]);
-      c = xyzz_add(c, h1[3]);
-      Affine<Fq> pa = xyzz_to_affine(h1[0]);
-      Affine<Fq2> pb = xyzz_to_affine(h2);
-      Affine<Fq> pc = xyzz_to_affine(c);
-      memcpy(out->a, &pa, sizeof(pa));
-      memcpy(out->b, &pb, sizeof(pb));
-      memcpy(out->c, &pc, sizeof(pc));
+      finalize_host<Curve>(h1, h2, rc, scn, out);
     }
     // every stream has drained into sR through the event chain; make the host view consistent
     ARK_CHECK_HIP(hipStreamSynchronize(sA));
