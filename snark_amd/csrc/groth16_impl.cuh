@@ -219,8 +219,8 @@ static PkDev* pk_upload(const ark355_pk_desc* d, hipStream_t stream, uint32_t sh
 //   sM (ctx stream)  H2D of z and the tail scalars                                  -> evZ
 //   sW               witness map: SpMV, 7 NTTs, pointwise                            -> evH
 //   sS               digits/scan/scatter of zx, zx[ell..], then (after evH) of h     -> evSort[0..2]
-//   sA               bucket accumulation + merge: A, B1, B2 (share sort 0), L', H    -> evAcc[0..4]
-//   sR               bucket reduction + combine per MSM as evAcc[i] fires; D2H of the five XYZZ results
+//   sA               bucket accumulation: A, B1, B2 (share sort 0), L', H            -> evAcc[0..4]
+//   sR               merge + bucket reduction + combine per MSM as evAcc[i] fires; D2H of the five XYZZ results
 template <class Curve>
 static void prove_run(ark355_ctx* ctx, ProverScratch& sc, const PkDev& pk, const R1csDev& r1, const void* z_src,
                       bool z_on_device, const uint8_t r_canon[32], const uint8_t s_canon[32], ark355_proof_raw* out,
@@ -313,8 +313,8 @@ static void prove_run(ark355_ctx* ctx, ProverScratch& sc, const PkDev& pk, const
       else msm_accumulate_phase<Fq>(ctx, *jb.sort, *jb.bk, (const Affine<Fq>*)jb.table, sA, acc0[j], acc1[j]);
       ARK_CHECK_HIP(hipEventRecord(ev[E_ACC_DONE0 + j], sA));
       ARK_CHECK_HIP(hipStreamWaitEvent(sR, ev[E_ACC_DONE0 + j], 0));
-      if (jb.g2) msm_reduce_phase<Fq2>(ctx, jb.sort->plan, *jb.bk, g2res, 0, sR);
-      else msm_reduce_phase<Fq>(ctx, jb.sort->plan, *jb.bk, g1res + jb.res, 0, sR);
+      if (jb.g2) msm_reduce_phase<Fq2>(ctx, *jb.sort, *jb.bk, g2res, 0, sR);
+      else msm_reduce_phase<Fq>(ctx, *jb.sort, *jb.bk, g1res + jb.res, 0, sR);
       pts += (uint64_t)jb.sort->plan.windows * jb.sort->plan.n;
     }
 

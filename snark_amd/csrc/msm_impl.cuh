@@ -55,6 +55,14 @@ inline MsmPlan msm_plan(uint64_t n, uint32_t scalar_bits, bool precomp = false, 
   int c = (int)lg - 4;
   if (c < 4) c = 4;
   if (c > 16) c = 16;
+  if (precomp && !force_c) {
+    // tuning knob for resident keys (window tables): ARK355_MSM_C=<bits>
+    static const int env_c = [] {
+      const char* e = getenv("ARK355_MSM_C");
+      return e ? atoi(e) : 0;
+    }();
+    if (env_c >= 4 && env_c <= 24 && n >= 1024) c = env_c;
+  }
   if (force_c) c = force_c;
   p.c = (uint32_t)c;
   // one extra bit so that the top window never produces a carry
@@ -65,6 +73,37 @@ inline MsmPlan msm_plan(uint64_t n, uint32_t scalar_bits, bool precomp = false, 
   return p;
 }
 
+// Wave-aggregated "fetch-and-add 1" on counter[key]: returns this lane's slot, i.e. what
+// atomicAdd(&counter[key], 1) would have returned, but lanes of a wave that share a key are served by ONE atomic.
+// Skewed scalar distributions (boolean witnesses, the all-equal DummyCircuit, a short top window) put most lanes
+// of a wave on the same bucket; un-aggregated, those same-address L2 atomics serialise (a degenerate window cost
+// ~10 ms per sort at n = 2^20 in round 1).  MSM_AGG_ROUNDS leader rounds peel off the largest groups with
+// __ballot/__shfl, the remaining lanes fall back to individual atomics.  Must be called by every lane of the
+// wave (inactive lanes pass valid = false).
+constexpr int MSM_AGG_ROUNDS = 3;
+ARK_D uint32_t wave_agg_inc(uint32_t* counter, uint32_t key, bool valid) {
+  const uint32_t lane = threadIdx.x & 63;
+  uint32_t slot = 0;
+  bool pending = valid;
+  for (int round = 0; round < MSM_AGG_ROUNDS; round++) {
+    const unsigned long long live = __ballot(pending);
+    if (live == 0) break;                                    // wave-uniform
+    const int leader = __ffsll((long long)live) - 1;
+    const uint32_t lkey = (uint32_t)__shfl((int)key, leader, 64);
+    const bool mine = pending && key == lkey;
+    const unsigned long long group = __ballot(mine);
+    uint32_t base = 0;
+    if ((int)lane == leader) base = atomicAdd(&counter[lkey], (uint32_t)__popcll(group));
+    base = (uint32_t)__shfl((int)base, leader, 64);
+    if (mine) {
+      slot = base + (uint32_t)__popcll(group & ((1ull << lane) - 1ull));
+      pending = false;
+    }
+  }
+  if (pending) slot = atomicAdd(&counter[key], 1u);
+  return slot;
+}
+
 // ---- K2: signed window digits + histogram ----------------------------------------------------------
 template <class Fr>
 __global__ void __launch_bounds__(MSM_THREADS)
@@ -72,8 +111,8 @@ msm_digits_kernel(const Fr* __restrict__ scalars, uint32_t n, int mont, uint32_t
                   uint32_t table_stride,
                   uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, uint32_t* __restrict__ counts) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  Fr k = scalars[i];
+  const bool in_range = i < n;                     // no early return: the wave-level primitives need every lane
+  Fr k = in_range ? scalars[i] : Fr::zero();
   if (mont) k = Fr::from_mont(k);
   const uint32_t B = 1u << (c - 1);
   const uint32_t full = 1u << c;
@@ -97,16 +136,14 @@ msm_digits_kernel(const Fr* __restrict__ scalars, uint32_t n, int mont, uint32_t
       carry = 0;
     }
     const uint64_t e = (uint64_t)w * n + i;
-    if (d == 0) {
-      keys[e] = MSM_INVALID;
-      vals[e] = 0;
-    } else {
-      // precomp: one shared bucket set, the value indexes the window's table row
-      const uint32_t key = precomp ? (d - 1) : (w * B + d - 1);
+    const bool valid = in_range && d != 0;
+    // precomp: one shared bucket set, the value indexes the window's table row
+    const uint32_t key = valid ? (precomp ? (d - 1) : (w * B + d - 1)) : MSM_INVALID;
+    if (in_range) {
       keys[e] = key;
-      vals[e] = (precomp ? (w * table_stride + i) : i) | (neg << 31);
-      atomicAdd(&counts[key], 1u);
+      vals[e] = valid ? ((precomp ? (w * table_stride + i) : i) | (neg << 31)) : 0u;
     }
+    (void)wave_agg_inc(counts, valid ? key : 0u, valid);
   }
 }
 
@@ -144,12 +181,14 @@ msm_scatter_kernel(const uint32_t* __restrict__ keys, const uint32_t* __restrict
                    const uint32_t* __restrict__ offsets, uint32_t* __restrict__ cursor,
                    uint32_t* __restrict__ sorted_keys, uint32_t* __restrict__ sorted_vals) {
   const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= entries) return;
-  const uint32_t key = keys[e];
-  if (key == MSM_INVALID) return;
-  const uint32_t pos = offsets[key] + atomicAdd(&cursor[key], 1u);
-  sorted_keys[pos] = key;
-  sorted_vals[pos] = vals[e];
+  const uint32_t key = (e < entries) ? keys[e] : MSM_INVALID;
+  const bool valid = key != MSM_INVALID;
+  const uint32_t slot = wave_agg_inc(cursor, valid ? key : 0u, valid);
+  if (valid) {
+    const uint32_t pos = offsets[key] + slot;
+    sorted_keys[pos] = key;
+    sorted_vals[pos] = vals[e];
+  }
 }
 
 // ---- K4: bucket accumulation -----------------------------------------------------------------------------
@@ -240,12 +279,19 @@ msm_accumulate_kernel(const Affine<F>* __restrict__ bases, const uint32_t* __res
                    tail_key);
 }
 
-// buckets whose entries straddle segment boundaries: add their partial runs
+// buckets whose entries straddle segment boundaries: add their partial runs.  Buckets spread over more than
+// MSM_HEAVY_SPAN segments (skewed scalars: boolean witnesses, the all-equal DummyCircuit, a short top window) are
+// only recorded here and summed by a whole workgroup each in msm_merge_heavy_kernel.
+#ifndef ARK_MSM_HEAVY_SPAN
+#define ARK_MSM_HEAVY_SPAN 48   // tests shrink it so that tiny cases take the heavy path
+#endif
+constexpr uint32_t MSM_HEAVY_SPAN = ARK_MSM_HEAVY_SPAN;
 template <class F>
 __global__ void __launch_bounds__(MSM_THREADS)
 msm_merge_kernel(uint32_t total_buckets, const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ counts,
                  XYZZ<F>* __restrict__ buckets, const XYZZ<F>* __restrict__ head, const uint32_t* __restrict__ head_key,
-                 const XYZZ<F>* __restrict__ tail, const uint32_t* __restrict__ tail_key) {
+                 const XYZZ<F>* __restrict__ tail, const uint32_t* __restrict__ tail_key,
+                 uint32_t* __restrict__ heavy_count, uint32_t* __restrict__ heavy_list) {
   const uint32_t key = blockIdx.x * blockDim.x + threadIdx.x;
   if (key >= total_buckets) return;
   const uint32_t cnt = counts[key];
@@ -253,6 +299,10 @@ msm_merge_kernel(uint32_t total_buckets, const uint32_t* __restrict__ offsets, c
   const uint32_t o = offsets[key];
   const uint32_t t0 = o / MSM_SEG, t1 = (o + cnt - 1) / MSM_SEG;
   if (t0 == t1) return;   // the single run was complete and already written
+  if (t1 - t0 > MSM_HEAVY_SPAN) {
+    heavy_list[atomicAdd(heavy_count, 1u)] = key;
+    return;
+  }
   XYZZ<F> sum = XYZZ<F>::inf();
   for (uint32_t t = t0; t <= t1; t++) {
     if (head_key[t] == key) sum = xyzz_add(sum, head[t]);
@@ -280,6 +330,47 @@ ARK_D XYZZ<F> wave_reduce_sum(XYZZ<F> v) {
     v = xyzz_add(v, o);
   }
   return v;
+}
+
+// one workgroup per heavy bucket: lanes stride over the bucket's segments, wave butterfly, 4 waves through LDS
+template <class F>
+__global__ void __launch_bounds__(MSM_THREADS)
+msm_merge_heavy_kernel(const uint32_t* __restrict__ heavy_count, const uint32_t* __restrict__ heavy_list,
+                       const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ counts,
+                       XYZZ<F>* __restrict__ buckets, const XYZZ<F>* __restrict__ head,
+                       const uint32_t* __restrict__ head_key, const XYZZ<F>* __restrict__ tail,
+                       const uint32_t* __restrict__ tail_key) {
+  __shared__ uint32_t wave_out[(MSM_THREADS / 64) * (sizeof(XYZZ<F>) / 4)];
+  constexpr int WORDS = sizeof(XYZZ<F>) / 4;
+  const uint32_t nheavy = *heavy_count;
+  for (uint32_t h = blockIdx.x; h < nheavy; h += gridDim.x) {
+    const uint32_t key = heavy_list[h];
+    const uint32_t o = offsets[key], cnt = counts[key];
+    const uint32_t t0 = o / MSM_SEG, t1 = (o + cnt - 1) / MSM_SEG;
+    XYZZ<F> sum = XYZZ<F>::inf();
+    for (uint32_t t = t0 + threadIdx.x; t <= t1; t += blockDim.x) {
+      if (head_key[t] == key) sum = xyzz_add(sum, head[t]);
+      if (tail_key[t] == key) sum = xyzz_add(sum, tail[t]);
+    }
+    sum = wave_reduce_sum(sum);
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) {
+      const uint32_t* src = reinterpret_cast<const uint32_t*>(&sum);
+      for (int i = 0; i < WORDS; i++) wave_out[wave * WORDS + i] = src[i];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      XYZZ<F> tot = XYZZ<F>::inf();
+      for (uint32_t v = 0; v < blockDim.x / 64; v++) {
+        XYZZ<F> t;
+        uint32_t* dst = reinterpret_cast<uint32_t*>(&t);
+        for (int i = 0; i < WORDS; i++) dst[i] = wave_out[v * WORDS + i];
+        tot = xyzz_add(tot, t);
+      }
+      buckets[key] = tot;
+    }
+    __syncthreads();
+  }
 }
 
 // ---- K5: bucket reduction: per window sum_{b} (b+1) * bucket[b] -----------------------------------------------
@@ -328,14 +419,18 @@ msm_reduce_kernel(const XYZZ<F>* __restrict__ buckets, uint32_t buckets_per_wind
   }
 }
 
-// one wave: lane w -> 2^(c*w) * (sum of window w's partials); butterfly over lanes; lane 0 accumulates into *out
+// one wave.  Several bucket sets (no window tables): lane w -> 2^(c*w) * (sum of window w's partials), butterfly
+// over lanes.  One bucket set (window tables): the lanes share the partials of the single set.  Lane 0
+// writes / accumulates into *out.
 template <class F>
 __global__ void __launch_bounds__(64)
 msm_combine_kernel(const XYZZ<F>* __restrict__ partials, uint32_t per_window, uint32_t windows, uint32_t c,
                    XYZZ<F>* __restrict__ out, int accumulate) {
   const uint32_t w = threadIdx.x;
   XYZZ<F> v = XYZZ<F>::inf();
-  if (w < windows) {
+  if (windows == 1) {
+    for (uint32_t i = w; i < per_window; i += 64) v = xyzz_add(v, partials[i]);
+  } else if (w < windows) {
     for (uint32_t i = 0; i < per_window; i++) v = xyzz_add(v, partials[w * per_window + i]);
     if (!v.is_inf()) {
       const uint32_t dbl = c * w;
@@ -497,10 +592,10 @@ static void msm_sort(ark355_ctx* ctx, MsmSort& s, const void* d_scalars, uint64_
 
 // Scratch for the bucket phase of one group type.
 struct MsmBuckets {
-  DevBuf buckets, head, tail, head_key, tail_key, partials;
+  DevBuf buckets, head, tail, head_key, tail_key, partials, heavy_count, heavy_list;
 };
 
-// Phase 1 of the bucket method over an existing sort: bucket accumulation + straddling-run merge.
+// Phase 1 of the bucket method over an existing sort: bucket accumulation (the chip-filling kernel).
 template <class F>
 static void msm_accumulate_phase(ark355_ctx* ctx, const MsmSort& s, MsmBuckets& b, const Affine<F>* d_bases,
                                  hipStream_t stream, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr) {
@@ -539,23 +634,37 @@ static void msm_accumulate_phase(ark355_ctx* ctx, const MsmSort& s, MsmBuckets& 
   }
   ARK_CHECK_LAUNCH();
   if (ev1) ARK_CHECK_HIP(hipEventRecord(ev1, stream));
-  const uint32_t grid_b = (p.total_buckets + MSM_THREADS - 1) / MSM_THREADS;
-  ARK_LAUNCH((msm_merge_kernel<F>), dim3(grid_b), dim3(MSM_THREADS), 0, stream, p.total_buckets,
-             s.offsets.as<uint32_t>(), s.counts.as<uint32_t>(), b.buckets.as<XYZZ<F>>(), b.head.as<XYZZ<F>>(),
-             b.head_key.as<uint32_t>(), b.tail.as<XYZZ<F>>(), b.tail_key.as<uint32_t>());
-  ARK_CHECK_LAUNCH();
 }
 
-// Phase 2: weighted bucket reduction + window combination; writes/accumulates the XYZZ result into d_out.
-// Only a handful of workgroups and latency-bound, so the prover runs it on its own stream underneath the next
-// MSM's accumulation.
+// Phase 2: straddling-run merge, weighted bucket reduction, window combination; writes/accumulates the XYZZ
+// result into d_out.  Only a handful of workgroups and latency-bound, so the prover runs it on its own stream
+// underneath the next MSM's accumulation.
 template <class F>
-static void msm_reduce_phase(ark355_ctx* ctx, const MsmPlan& p, MsmBuckets& b, XYZZ<F>* d_out, int accumulate,
+static void msm_reduce_phase(ark355_ctx* ctx, const MsmSort& s, MsmBuckets& b, XYZZ<F>* d_out, int accumulate,
                              hipStream_t stream) {
+  const MsmPlan& p = s.plan;
   if (p.n == 0) {
     if (!accumulate) ARK_CHECK_HIP(hipMemsetAsync(d_out, 0, sizeof(XYZZ<F>), stream));
     return;
   }
+  const uint32_t segs = s.max_segments;
+  const uint32_t grid_b = (p.total_buckets + MSM_THREADS - 1) / MSM_THREADS;
+  // at most entries / (MSM_HEAVY_SPAN * MSM_SEG) buckets can be heavy
+  const uint32_t max_heavy = segs / MSM_HEAVY_SPAN + 1;
+  b.heavy_count.ensure(16);
+  b.heavy_list.ensure((size_t)max_heavy * 4);
+  ARK_CHECK_HIP(hipMemsetAsync(b.heavy_count.p, 0, 4, stream));
+  ARK_LAUNCH((msm_merge_kernel<F>), dim3(grid_b), dim3(MSM_THREADS), 0, stream, p.total_buckets,
+             s.offsets.as<uint32_t>(), s.counts.as<uint32_t>(), b.buckets.as<XYZZ<F>>(), b.head.as<XYZZ<F>>(),
+             b.head_key.as<uint32_t>(), b.tail.as<XYZZ<F>>(), b.tail_key.as<uint32_t>(),
+             b.heavy_count.as<uint32_t>(), b.heavy_list.as<uint32_t>());
+  ARK_CHECK_LAUNCH();
+  const uint32_t grid_h = max_heavy < 1024u ? max_heavy : 1024u;
+  ARK_LAUNCH((msm_merge_heavy_kernel<F>), dim3(grid_h), dim3(MSM_THREADS), 0, stream, b.heavy_count.as<uint32_t>(),
+             b.heavy_list.as<uint32_t>(), s.offsets.as<uint32_t>(), s.counts.as<uint32_t>(), b.buckets.as<XYZZ<F>>(),
+             b.head.as<XYZZ<F>>(), b.head_key.as<uint32_t>(), b.tail.as<XYZZ<F>>(), b.tail_key.as<uint32_t>());
+  ARK_CHECK_LAUNCH();
+
   const uint32_t chunks = (p.buckets_per_window + MSM_RED_K - 1) / MSM_RED_K;
   const uint32_t blocks_per_window = (chunks + MSM_THREADS - 1) / MSM_THREADS;
   b.partials.ensure((size_t)blocks_per_window * p.key_windows * sizeof(XYZZ<F>));
@@ -573,7 +682,7 @@ template <class F>
 static void msm_buckets(ark355_ctx* ctx, const MsmSort& s, MsmBuckets& b, const Affine<F>* d_bases, XYZZ<F>* d_out,
                         int accumulate, hipStream_t stream, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr) {
   msm_accumulate_phase<F>(ctx, s, b, d_bases, stream, ev0, ev1);
-  msm_reduce_phase<F>(ctx, s.plan, b, d_out, accumulate, stream);
+  msm_reduce_phase<F>(ctx, s, b, d_out, accumulate, stream);
 }
 
 }  // namespace ark355

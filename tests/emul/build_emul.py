@@ -28,7 +28,7 @@ def build(force=False):
     if not force and os.path.exists(OUT) and os.path.getmtime(OUT) >= newest_src():
         return OUT
     objs = []
-    flags = ["-O1", "-g", "-std=c++17", "-fPIC", "-DARK_EMUL", "-I", HERE, "-I", CSRC, "-w"]
+    flags = ["-O1", "-g", "-std=c++17", "-fPIC", "-DARK_EMUL", "-DARK_MSM_HEAVY_SPAN=2", "-I", HERE, "-I", CSRC, "-w"]
 
     def cc(src):
         obj = os.path.join(HERE, os.path.basename(src) + ".emul.o")
