@@ -38,6 +38,8 @@ def parse_args():
     ap.add_argument("--tight", action="store_true", help="domain-tight variant n = 2^k - 100 (N = 2^k)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true", help="skip the closed-form proof check")
+    ap.add_argument("--inflight", type=int, default=2,
+                    help="proofs in flight per GPU (independent contexts sharing the resident key; 1 = strictly serial)")
     return ap.parse_args()
 
 
@@ -59,6 +61,20 @@ def cpu_baseline(curve_name, log_n_sample=None):
     dt = time.perf_counter() - t0
     return {"value": n / dt, "unit": "constraints/s", "cores": 1, "kind": "port",
             "sample": "pure-Python oracle (scalar, naive MSM), 2^7-constraint mulchain, 1 proof"}
+
+
+def pmc_traffic(n, curve):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (FETCH_SIZE and
+    WRITE_SIZE, separate runs; profiles/README.md).  None when no profile of this workload is on file."""
+    path = os.path.join(ROOT, "profiles", "pmc_latest.json")
+    try:
+        rec = json.load(open(path))
+        if rec.get("workload") != "%s:n=%d" % (curve, n):
+            return None
+        k = rec["msm_accumulate_kernel"]
+        return k["fetch_bytes_per_launch"] + k["write_bytes_per_launch"]
+    except Exception:
+        return None
 
 
 def main():
@@ -92,27 +108,60 @@ def main():
     torch.cuda.synchronize()
     prep_s = time.perf_counter() - t_prep
 
-    def step():
-        r_, s_ = rnd.randrange(cv.r), rnd.randrange(cv.r)
-        return g.prove(pk, r1, None, r=r_, s=s_, z_device_ptr=z_dev.data_ptr()), r_, s_
+    # Throughput mode: `inflight` independent proving contexts (own streams and scratch) share the resident key and
+    # CSR handles; while one proof is in its serial head (sort) or tail (last bucket reduction, O(1) host finish)
+    # the other keeps the CUs busy.  Every step is still one complete, independently randomised proof.
+    import threading
+    from snark_amd.groth16 import Proof
+    pkh, rh = g.load_pk(pk), g.load_r1cs(r1)
+    ctxs = [g.ctx] + [g.lib.ctx_create(local_rank) for _ in range(max(1, args.inflight) - 1)]
+    lock = threading.Lock()
 
-    for _ in range(args.warmup):
-        step()
-    acc_ms_sum, acc_launches, tim = 0.0, 0, None
+    def prove_on(ctx, r_, s_):
+        a, b, c = g.lib.prove(ctx, pkh, rh, z_dev.data_ptr(), r1.m, cv.fr_canon(r_), cv.fr_canon(s_), g.sizes,
+                              z_is_device_ptr=True)
+        return Proof(a, b, c)
+
+    def run(nsteps, record, per_worker=False):
+        # per_worker: every context proves `nsteps` times (warm-up must touch each context's scratch and streams)
+        todo = [(rnd.randrange(cv.r), rnd.randrange(cv.r)) for _ in range(nsteps * (len(ctxs) if per_worker else 1))]
+        quota = {id(c): nsteps for c in ctxs}
+        results = []
+
+        def worker(ctx):
+            while True:
+                with lock:
+                    if not todo or (per_worker and quota[id(ctx)] == 0):
+                        return
+                    quota[id(ctx)] -= 1
+                    r_, s_ = todo.pop()
+                p = prove_on(ctx, r_, s_)          # the C call releases the GIL; it returns after its streams drained
+                ks = g.lib.kernel_stats(ctx)
+                with lock:
+                    results.append((p, r_, s_))
+                    if record is not None:
+                        record[0] += ks["accumulate_ms"]
+                        record[1] += ks["launches"]
+        ths = [threading.Thread(target=worker, args=(c,)) for c in ctxs]
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+        return results
+
+    run(max(1, -(-args.warmup // len(ctxs))) if args.warmup else 0, None, per_worker=True)
+    rec = [0.0, 0]
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    last = None
-    for _ in range(args.steps):
-        last = step()                       # ark355_prove_dev synchronises its stream before returning
-        ks = g.lib.kernel_stats(g.ctx)
-        acc_ms_sum += ks["accumulate_ms"]
-        acc_launches += ks["launches"]
+    results = run(args.steps, rec)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
+    acc_ms_sum, acc_launches = rec
+    last = results[-1]
     tim = g.lib.timings(g.ctx)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
@@ -121,8 +170,7 @@ def main():
 
     parity = "skipped"
     if not args.no_check:
-        proof, r_, s_ = last
-        ok = proof == g.prove_closed_form(pk, z, r_, s_)
+        ok = all(proof == g.prove_closed_form(pk, z, r_, s_) for proof, r_, s_ in results)
         parity = "proof == trapdoor closed form" if ok else "MISMATCH"
         if world > 1:
             f = torch.tensor([0 if ok else 1], device="cuda")
@@ -154,9 +202,10 @@ def main():
             "dtype": "u32", "data": "synthetic",
             "config": {"workload": "S2 mulchain R1CS, n=%d constraints (N=2^%d), Groth16/%s, one independent proof "
                                    "stream per GPU, pk+CSR+z resident in HBM" % (n, N.bit_length() - 1, args.curve),
-                       "parallelism": "replicas x%d (independent proofs, no collective)" % world},
+                       "parallelism": "replicas x%d (independent proofs, no collective), %d proofs in flight per GPU"
+                                      % (world, len(ctxs))},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(n, args.curve),
                          "kernel": "msm_accumulate_kernel (bucket accumulation, 4 G1 + 1 G2 launches per proof)",
                          "alg_bytes_per_launch": alg_bytes_per_launch, "avg_launch_ms": avg_launch_ms,
                          "note": "integer-ALU bound by construction (~10 Fq mul per 128 B term); see DESIGN.md"},
@@ -170,6 +219,8 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.curve)
         print(json.dumps(out), flush=True)
+    for c in ctxs[1:]:
+        g.lib.ctx_destroy(c)
     g.close()
     if world > 1:
         dist.destroy_process_group()

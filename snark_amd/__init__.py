@@ -14,7 +14,8 @@ from ._binding import (BLS12_381, BN254, Ark355Error, Lib, OK, EINVAL, ENOMEM, E
                        E_ASSIGNMENT_MISSING, E_UNSATISFIABLE, E_POLY_DEGREE_TOO_LARGE)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libark355.so")
+# ARK355_LIB: developer override to A/B-test another BUILD OF THE SAME HIP LIBRARY (still no fallback of any kind)
+LIB_PATH = os.environ.get("ARK355_LIB") or os.path.join(_HERE, "libark355.so")
 _lib = None
 
 

@@ -89,7 +89,7 @@ class Lib:
         if not os.path.exists(path):
             raise FileNotFoundError(path)
         self.path = path
-        self.dll = C.CDLL(path, mode=C.RTLD_GLOBAL)
+        self.dll = C.CDLL(path)          # RTLD_LOCAL: the emulator test build exports the same symbol names
         d = self.dll
         vp, u64, u32, i32, i64 = C.c_void_p, C.c_uint64, C.c_uint32, C.c_int32, C.c_int64
         P = C.POINTER

@@ -19,6 +19,7 @@ OBJDIR = os.path.join(HERE, "build")
 SOURCES = ["capi.hip", "ark355_bls.hip", "ark355_bn.hip"]
 ARCH = "gfx950"
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-DNDEBUG", "-Wno-unused-result"]
+FLAGS += os.environ.get("ARK355_EXTRA_FLAGS", "").split()      # dev: e.g. -DARK_MSM_SEG=64
 
 
 def hipcc():
@@ -64,7 +65,7 @@ def build(force=False, verbose=True, resource_log=False):
 
     with ThreadPoolExecutor(len(SOURCES)) as ex:
         objs = list(ex.map(compile_one, SOURCES))
-    cmd = [cc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", OUT, *objs]
+    cmd = [cc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-Wl,-Bsymbolic", "-o", OUT, *objs]
     if verbose:
         print("[snark_amd.build]", " ".join(cmd), flush=True)
     subprocess.check_call(cmd)

@@ -27,9 +27,20 @@
 namespace ark355 {
 
 constexpr uint32_t MSM_INVALID = 0xFFFFFFFFu;
-constexpr uint32_t MSM_SEG = 32;          // entries per accumulate lane
+// entries per accumulate lane = 2^seg_log, chosen per MSM (MsmPlan::seg_log): 32 keeps small MSMs wide enough to
+// fill the chip, 64 halves the partial runs (merge work, tail latency) of the 2^24-entry MSMs of a 2^20 proof
+// (measured on MI355X: 53.7 / 52.6 / 52.3 ms per proof for 32 / 64 / 128)
+#ifndef ARK_MSM_SEG_LOG_SMALL
+#define ARK_MSM_SEG_LOG_SMALL 5
+#endif
+#ifndef ARK_MSM_SEG_LOG_LARGE
+#define ARK_MSM_SEG_LOG_LARGE 6
+#endif
 constexpr uint32_t MSM_RED_K = 16;        // buckets per reduce lane
 constexpr uint32_t MSM_THREADS = 256;
+#ifndef ARK_G1_PREFETCH
+#define ARK_G1_PREFETCH 1   // measured neutral on MI355X (7.75 vs 7.79 ms for A+B1); kept for small-n latency
+#endif
 #ifndef ARK_G2_INLINE_DEFAULT
 #define ARK_G2_INLINE_DEFAULT 1
 #endif
@@ -43,6 +54,7 @@ struct MsmPlan {
   // window combination disappear from the per-proof path.
   bool precomp = false;
   uint32_t key_windows = 0;     // bucket sets: 1 with precomp, `windows` without
+  uint32_t seg_log = ARK_MSM_SEG_LOG_SMALL;
 };
 
 inline MsmPlan msm_plan(uint64_t n, uint32_t scalar_bits, bool precomp = false, int force_c = 0) {
@@ -70,6 +82,7 @@ inline MsmPlan msm_plan(uint64_t n, uint32_t scalar_bits, bool precomp = false, 
   p.buckets_per_window = 1u << (p.c - 1);
   p.key_windows = precomp ? 1u : p.windows;
   p.total_buckets = p.key_windows * p.buckets_per_window;
+  p.seg_log = ((uint64_t)p.windows * n >= (1ull << 23)) ? ARK_MSM_SEG_LOG_LARGE : ARK_MSM_SEG_LOG_SMALL;
   return p;
 }
 
@@ -220,10 +233,11 @@ msm_accumulate_kernel(const Affine<F>* __restrict__ bases, const uint32_t* __res
                       const uint32_t* __restrict__ sorted_vals, const uint32_t* __restrict__ total_ptr,
                       const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ counts,
                       XYZZ<F>* __restrict__ buckets, XYZZ<F>* __restrict__ head, uint32_t* __restrict__ head_key,
-                      XYZZ<F>* __restrict__ tail, uint32_t* __restrict__ tail_key) {
+                      XYZZ<F>* __restrict__ tail, uint32_t* __restrict__ tail_key, uint32_t seg_log) {
   const uint32_t seg = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t total = *total_ptr;
-  const uint64_t start64 = (uint64_t)seg * MSM_SEG;
+  const uint32_t MSM_SEG = 1u << seg_log;
+  const uint64_t start64 = (uint64_t)seg << seg_log;
   if (start64 >= total) return;
   const uint32_t start = (uint32_t)start64;
   const uint32_t end = (start + MSM_SEG < total) ? start + MSM_SEG : total;
@@ -235,18 +249,21 @@ msm_accumulate_kernel(const Affine<F>* __restrict__ bases, const uint32_t* __res
   // current mixed addition runs.  It is held in explicit 16-byte registers: a struct copy here was lowered by
   // hipcc to scratch-to-scratch copies with a vmcnt(0) after every load (seen in the round-1 ISA).
   constexpr int Q = sizeof(Affine<F>) / 16;
+  // G2 lives at the edge of the 512-register file: holding the prefetched point (48 more registers) costs more
+  // in spills than the gather latency it hides (one ~2 us gather per ~60 us mixed addition)
+  constexpr bool PREFETCH = ARK_G1_PREFETCH && sizeof(F) <= 64;
   uint4 nx[Q];
   uint32_t v_next = sorted_vals[start];
-  {
+  if constexpr (PREFETCH) {
     const uint4* src = reinterpret_cast<const uint4*>(bases + (v_next & 0x7FFFFFFFu));
 #pragma unroll
     for (int k = 0; k < Q; k++) nx[k] = src[k];
   }
   for (uint32_t e = start; e < end; e++) {
     const uint32_t key = sorted_keys[e];
-    const uint32_t v = v_next;
+    uint32_t v = v_next;
     Affine<F> p;
-    {
+    if constexpr (PREFETCH) {
       uint32_t* d = reinterpret_cast<uint32_t*>(&p);
 #pragma unroll
       for (int k = 0; k < Q; k++) {
@@ -255,13 +272,14 @@ msm_accumulate_kernel(const Affine<F>* __restrict__ bases, const uint32_t* __res
         d[4 * k + 2] = nx[k].z;
         d[4 * k + 3] = nx[k].w;
       }
-    }
-    {
       const uint32_t en = (e + 1 < end) ? e + 1 : e;     // clamp: the last iteration re-reads its own entry
       v_next = sorted_vals[en];
       const uint4* src = reinterpret_cast<const uint4*>(bases + (v_next & 0x7FFFFFFFu));
 #pragma unroll
       for (int k = 0; k < Q; k++) nx[k] = src[k];
+    } else {
+      v = sorted_vals[e];
+      p = bases[v & 0x7FFFFFFFu];
     }
     if (key != cur_key) {
       msm_flush_run<F>(cur_key, acc, first_run, run_start, e, seg, offsets, counts, buckets, head, head_key, tail,
@@ -286,18 +304,21 @@ msm_accumulate_kernel(const Affine<F>* __restrict__ bases, const uint32_t* __res
 #define ARK_MSM_HEAVY_SPAN 48   // tests shrink it so that tiny cases take the heavy path
 #endif
 constexpr uint32_t MSM_HEAVY_SPAN = ARK_MSM_HEAVY_SPAN;
+#ifndef ARK_MSM_HEAVY_GRID
+#define ARK_MSM_HEAVY_GRID 1024u
+#endif
 template <class F>
 __global__ void __launch_bounds__(MSM_THREADS)
 msm_merge_kernel(uint32_t total_buckets, const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ counts,
                  XYZZ<F>* __restrict__ buckets, const XYZZ<F>* __restrict__ head, const uint32_t* __restrict__ head_key,
                  const XYZZ<F>* __restrict__ tail, const uint32_t* __restrict__ tail_key,
-                 uint32_t* __restrict__ heavy_count, uint32_t* __restrict__ heavy_list) {
+                 uint32_t* __restrict__ heavy_count, uint32_t* __restrict__ heavy_list, uint32_t seg_log) {
   const uint32_t key = blockIdx.x * blockDim.x + threadIdx.x;
   if (key >= total_buckets) return;
   const uint32_t cnt = counts[key];
   if (cnt == 0) return;
   const uint32_t o = offsets[key];
-  const uint32_t t0 = o / MSM_SEG, t1 = (o + cnt - 1) / MSM_SEG;
+  const uint32_t t0 = o >> seg_log, t1 = (o + cnt - 1) >> seg_log;
   if (t0 == t1) return;   // the single run was complete and already written
   if (t1 - t0 > MSM_HEAVY_SPAN) {
     heavy_list[atomicAdd(heavy_count, 1u)] = key;
@@ -339,14 +360,14 @@ msm_merge_heavy_kernel(const uint32_t* __restrict__ heavy_count, const uint32_t*
                        const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ counts,
                        XYZZ<F>* __restrict__ buckets, const XYZZ<F>* __restrict__ head,
                        const uint32_t* __restrict__ head_key, const XYZZ<F>* __restrict__ tail,
-                       const uint32_t* __restrict__ tail_key) {
+                       const uint32_t* __restrict__ tail_key, uint32_t seg_log) {
   __shared__ uint32_t wave_out[(MSM_THREADS / 64) * (sizeof(XYZZ<F>) / 4)];
   constexpr int WORDS = sizeof(XYZZ<F>) / 4;
   const uint32_t nheavy = *heavy_count;
   for (uint32_t h = blockIdx.x; h < nheavy; h += gridDim.x) {
     const uint32_t key = heavy_list[h];
     const uint32_t o = offsets[key], cnt = counts[key];
-    const uint32_t t0 = o / MSM_SEG, t1 = (o + cnt - 1) / MSM_SEG;
+    const uint32_t t0 = o >> seg_log, t1 = (o + cnt - 1) >> seg_log;
     XYZZ<F> sum = XYZZ<F>::inf();
     for (uint32_t t = t0 + threadIdx.x; t <= t1; t += blockDim.x) {
       if (head_key[t] == key) sum = xyzz_add(sum, head[t]);
@@ -566,7 +587,7 @@ static void msm_sort(ark355_ctx* ctx, MsmSort& s, const void* d_scalars, uint64_
   s.offsets.ensure((size_t)p.total_buckets * 4);
   s.cursor.ensure((size_t)p.total_buckets * 4);
   s.total.ensure(16);
-  s.max_segments = (uint32_t)((entries + MSM_SEG - 1) / MSM_SEG);
+  s.max_segments = (uint32_t)((entries + (1u << p.seg_log) - 1) >> p.seg_log);
   if (n == 0) {
     ARK_CHECK_HIP(hipMemsetAsync(s.total.p, 0, 4, stream));
     ARK_CHECK_HIP(hipMemsetAsync(s.counts.p, 0, (size_t)p.total_buckets * 4, stream));
@@ -624,7 +645,7 @@ static void msm_accumulate_phase(ark355_ctx* ctx, const MsmSort& s, MsmBuckets& 
     ARK_LAUNCH((msm_accumulate_kernel<F, NI>), dim3(grid_s), dim3(MSM_THREADS), 0, stream, d_bases,
                s.sorted_keys.as<uint32_t>(), s.sorted_vals.as<uint32_t>(), s.total.as<uint32_t>(),
                s.offsets.as<uint32_t>(), s.counts.as<uint32_t>(), b.buckets.as<XYZZ<F>>(), b.head.as<XYZZ<F>>(),
-               b.head_key.as<uint32_t>(), b.tail.as<XYZZ<F>>(), b.tail_key.as<uint32_t>());
+               b.head_key.as<uint32_t>(), b.tail.as<XYZZ<F>>(), b.tail_key.as<uint32_t>(), p.seg_log);
   };
   if constexpr (sizeof(F) > 64) {
     if (g2_inline) launch(std::false_type{});
@@ -649,7 +670,7 @@ static void msm_reduce_phase(ark355_ctx* ctx, const MsmSort& s, MsmBuckets& b, X
   }
   const uint32_t segs = s.max_segments;
   const uint32_t grid_b = (p.total_buckets + MSM_THREADS - 1) / MSM_THREADS;
-  // at most entries / (MSM_HEAVY_SPAN * MSM_SEG) buckets can be heavy
+  // at most entries / (MSM_HEAVY_SPAN * segment length) buckets can be heavy
   const uint32_t max_heavy = segs / MSM_HEAVY_SPAN + 1;
   b.heavy_count.ensure(16);
   b.heavy_list.ensure((size_t)max_heavy * 4);
@@ -657,12 +678,12 @@ static void msm_reduce_phase(ark355_ctx* ctx, const MsmSort& s, MsmBuckets& b, X
   ARK_LAUNCH((msm_merge_kernel<F>), dim3(grid_b), dim3(MSM_THREADS), 0, stream, p.total_buckets,
              s.offsets.as<uint32_t>(), s.counts.as<uint32_t>(), b.buckets.as<XYZZ<F>>(), b.head.as<XYZZ<F>>(),
              b.head_key.as<uint32_t>(), b.tail.as<XYZZ<F>>(), b.tail_key.as<uint32_t>(),
-             b.heavy_count.as<uint32_t>(), b.heavy_list.as<uint32_t>());
+             b.heavy_count.as<uint32_t>(), b.heavy_list.as<uint32_t>(), p.seg_log);
   ARK_CHECK_LAUNCH();
-  const uint32_t grid_h = max_heavy < 1024u ? max_heavy : 1024u;
+  const uint32_t grid_h = max_heavy < ARK_MSM_HEAVY_GRID ? max_heavy : ARK_MSM_HEAVY_GRID;
   ARK_LAUNCH((msm_merge_heavy_kernel<F>), dim3(grid_h), dim3(MSM_THREADS), 0, stream, b.heavy_count.as<uint32_t>(),
              b.heavy_list.as<uint32_t>(), s.offsets.as<uint32_t>(), s.counts.as<uint32_t>(), b.buckets.as<XYZZ<F>>(),
-             b.head.as<XYZZ<F>>(), b.head_key.as<uint32_t>(), b.tail.as<XYZZ<F>>(), b.tail_key.as<uint32_t>());
+             b.head.as<XYZZ<F>>(), b.head_key.as<uint32_t>(), b.tail.as<XYZZ<F>>(), b.tail_key.as<uint32_t>(), p.seg_log);
   ARK_CHECK_LAUNCH();
 
   const uint32_t chunks = (p.buckets_per_window + MSM_RED_K - 1) / MSM_RED_K;

@@ -7,6 +7,7 @@ Thread* g_cur = nullptr;
 ucontext_t g_sched;
 uint64_t g_xchg[64];
 unsigned char* g_dyn_smem = nullptr;
+PairBox g_pairbox[1024];
 
 static const std::function<void()>* g_body = nullptr;
 static const size_t STACK = 1 << 20;
@@ -56,21 +57,37 @@ void launch(dim3 grid, dim3 block, size_t smem, const std::function<void()>& bod
               makecontext(&t.ctx, trampoline, 0);
               t.state = RUN;
               t.tid = dim3(tx, ty, tz);
+              g_pairbox[k % 1024] = PairBox();
             }
         const unsigned nwaves = (nthreads + 63) / 64;
         for (;;) {
+          bool any_run = false;
           for (unsigned w = 0; w < nwaves; w++) {
             const unsigned lo = w * 64, hi = (lo + 64 < nthreads) ? lo + 64 : nthreads;
             for (;;) {
+              bool ran = false;
               for (unsigned i = lo; i < hi; i++)
-                if (th[i].state == RUN) resume(th[i]);
-              bool any_wave_wait = false;
-              for (unsigned i = lo; i < hi; i++) any_wave_wait |= (th[i].state == WAVE_WAIT);
+                if (th[i].state == RUN) {
+                  resume(th[i]);
+                  ran = true;
+                }
+              // lanes that yielded with RUN (pair exchange polling) are simply resumed on the next pass
+              bool any_running = false, any_wave_wait = false;
+              for (unsigned i = lo; i < hi; i++) {
+                any_running |= (th[i].state == RUN);
+                any_wave_wait |= (th[i].state == WAVE_WAIT);
+              }
+              if (any_running) {
+                if (!ran) break;
+                continue;
+              }
               if (!any_wave_wait) break;
               for (unsigned i = lo; i < hi; i++)
                 if (th[i].state == WAVE_WAIT) th[i].state = RUN;
             }
+            for (unsigned i = lo; i < hi; i++) any_run |= (th[i].state == RUN);
           }
+          if (any_run) continue;
           bool any_block_wait = false;
           for (unsigned i = 0; i < nthreads; i++) any_block_wait |= (th[i].state == BLOCK_WAIT);
           if (!any_block_wait) break;

@@ -49,6 +49,12 @@ extern Thread* g_cur;
 extern ucontext_t g_sched;
 extern uint64_t g_xchg[64];
 extern unsigned char* g_dyn_smem;
+// mailbox of the lane-pair exchange (models a DPP quad_perm [1,0,3,2] move): 2-deep ring indexed by sequence parity
+struct PairBox {
+  uint32_t val[2] = {0, 0};
+  uint64_t seq = 0;
+};
+extern PairBox g_pairbox[1024];
 void yield(int st);
 void launch(dim3 grid, dim3 block, size_t smem, const std::function<void()>& body);
 }  // namespace emu
@@ -102,6 +108,19 @@ static inline T __shfl_up(T v, unsigned d, int width = 64) {
   if (src < (lane & ~(width - 1))) src = lane;
   return __emu_xchg(v, src);
 }
+// value of lane (lane ^ 1); unlike the wave shuffles this pairs exactly the two lanes of a pair, whatever the
+// other lanes of the wave are doing (on hardware: v_mov_b32_dpp quad_perm:[1,0,3,2])
+static inline uint32_t __emu_pair_xchg(uint32_t v) {
+  const unsigned me = emu::g_threadIdx.x & 1023u, other = me ^ 1u;
+  emu::PairBox& mine = emu::g_pairbox[me];
+  emu::PairBox& theirs = emu::g_pairbox[other];
+  const uint64_t k = mine.seq + 1;
+  mine.val[k & 1] = v;
+  mine.seq = k;
+  while (theirs.seq < k) emu::yield(emu::RUN);
+  return theirs.val[k & 1];
+}
+
 static inline unsigned long long __ballot(int pred) {
   int lane = (int)(emu::g_threadIdx.x & 63);
   // lanes that exited or are not participating contribute 0: clear, barrier, set, barrier, read

@@ -1,0 +1,71 @@
+"""O3: the oracle's C restatement of the arkworks CPU algorithms (oracle/c) against the Python oracle (O1/O2).
+It is the checker at sizes Python cannot reach and the timed `cpu_baseline` of bench.py."""
+import random
+
+import pytest
+
+from helpers import csr_from_rows, fr_vec_from_mont, g1_vec_raw, g2_vec_raw, z_bytes
+from oracle import groth16 as G, serialize as Z, synthetic as S
+from oracle.c import cbase
+from oracle.curves import g1, g2
+from oracle.fields import BLS12_381, BN254
+from oracle.ntt import Domain
+
+CURVES = [BLS12_381, BN254]
+
+
+@pytest.mark.parametrize("C", CURVES, ids=lambda c: c.name)
+def test_c_ntt_matches_python(C):
+    rnd = random.Random(1)
+    for lg in (0, 1, 4, 10):
+        xs = [rnd.randrange(C.r) for _ in range(1 << lg)]
+        d = Domain(C, lg)
+        for inv, cos, ref in ((0, 0, d.fft), (1, 0, d.ifft), (0, 1, d.coset_fft), (1, 1, d.coset_ifft)):
+            assert fr_vec_from_mont(C, cbase.ntt(C, z_bytes(C, xs), lg, inv, cos)) == ref(xs)
+
+
+@pytest.mark.parametrize("C", CURVES, ids=lambda c: c.name)
+@pytest.mark.parametrize("group", [1, 2])
+def test_c_pippenger_and_fixed_base(C, group):
+    rnd = random.Random(2)
+    G_ = g1(C) if group == 1 else g2(C)
+    raw = Z.g1_raw if group == 1 else Z.g2_raw
+    fromraw = Z.g1_from_raw if group == 1 else Z.g2_from_raw
+    psz = len(raw(C, G_.gen))
+    for n in (0, 1, 31, 32, 200):
+        ks = [rnd.randrange(C.r) for _ in range(n)]
+        ss = [rnd.randrange(C.r) for _ in range(n)]
+        if n >= 31:
+            ks[0], ks[1], ks[2], ss[3] = 0, 1, C.r - 1, 0
+        bases = cbase.fixed_base(C, group, raw(C, G_.gen), b"".join(Z.fr_canon(C, s) for s in ss), n)
+        if n:
+            assert fromraw(C, bases[:psz]) == G_.mul(G_.gen, ss[0])
+        out = cbase.msm(C, group, bases, b"".join(Z.fr_canon(C, k) for k in ks), n)
+        assert fromraw(C, out) == G_.mul(G_.gen, sum(k * s for k, s in zip(ks, ss)) % C.r)
+
+
+@pytest.mark.parametrize("C", CURVES, ids=lambda c: c.name)
+def test_c_prover_equals_closed_form(C):
+    A, B, Cm, z, ell = S.cs_to_instance(S.bench_lc_cs(C.r, 60))
+    m, w = len(z), len(z) - ell
+    td = G.Trapdoor(tau=1234567, alpha=3, beta=5, gamma=7, delta=11)
+    pk = G.setup(C, A, B, Cm, ell, m, td)
+    mats = [csr_from_rows(C, M) for M in (A, B, Cm)]
+    h = cbase.witness_map(C, len(A), ell, w, mats, z_bytes(C, z))
+    assert fr_vec_from_mont(C, h) == G.witness_map(C, A, B, Cm, z, ell)
+    raw = dict(a_query=g1_vec_raw(C, pk.a_query), b_g1_query=g1_vec_raw(C, pk.b_g1_query),
+               b_g2_query=g2_vec_raw(C, pk.b_g2_query), h_query=g1_vec_raw(C, pk.h_query),
+               l_query=g1_vec_raw(C, pk.l_query), alpha_g1=Z.g1_raw(C, pk.vk.alpha_g1), beta_g1=Z.g1_raw(C, pk.beta_g1),
+               delta_g1=Z.g1_raw(C, pk.delta_g1), beta_g2=Z.g2_raw(C, pk.vk.beta_g2), delta_g2=Z.g2_raw(C, pk.vk.delta_g2))
+    for r_, s_ in ((123456789, 987654321), (0, 7), (C.r - 1, 1)):
+        a, b, c = cbase.prove(C, len(A), ell, w, mats, z_bytes(C, z), raw, r_, s_)
+        exp = G.prove_closed_form(C, pk, z, ell, r_, s_)
+        assert (Z.g1_from_raw(C, a), Z.g2_from_raw(C, b), Z.g1_from_raw(C, c)) == (exp.a, exp.b, exp.c)
+    pk2, _ = cbase.setup_raw(C, A, B, Cm, ell, m, td)
+    for k in ("a_query", "b_g1_query", "b_g2_query", "h_query", "l_query", "alpha_g1", "delta_g2"):
+        assert pk2[k] == raw[k], k
+
+
+def test_cpu_baseline_record_shape():
+    rec = cbase.bench_prove("bls12_381", log_n=8, budget_s=2.0)
+    assert rec["kind"] == "port" and rec["unit"] == "constraints/s" and rec["value"] > 0 and rec["cores"] >= 1

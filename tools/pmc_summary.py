@@ -1,17 +1,44 @@
 #!/usr/bin/env python3
-"""Aggregate rocprofv3 --pmc counter_collection CSVs per kernel (dev tool; run on the GPU box)."""
+"""Aggregate rocprofv3 --pmc counter_collection CSVs per kernel (dev tool; run on the GPU box).
+
+usage: pmc_summary.py [--json OUT.json] [--workload TEXT]
+Reads gpurun_out/prof_fetch and gpurun_out/prof_write (two separate passes: FETCH_SIZE, WRITE_SIZE).
+Counter unit: KiB.  With --json also writes the per-launch figures of the dominant kernel
+(msm_accumulate_kernel) that bench.py reports as `roofline.traffic`."""
 import collections
 import csv
 import glob
+import json
 import re
+import sys
 
+agg = collections.defaultdict(lambda: [0, 0.0])
 for kind in ("fetch", "write"):
     for f in glob.glob("gpurun_out/prof_%s/**/*counter_collection.csv" % kind, recursive=True):
-        agg = collections.defaultdict(lambda: [0, 0.0])
         for row in csv.DictReader(open(f)):
             k = re.sub(r"\(.*", "", row.get("Kernel_Name", ""))
             k = k.replace("ark355::", "")[:70]
             agg[(k, row.get("Counter_Name"))][0] += 1
             agg[(k, row.get("Counter_Name"))][1] += float(row.get("Counter_Value", 0))
-        for (k, c), (n, v) in sorted(agg.items(), key=lambda x: -x[1][1])[:30]:
-            print("%s %-70s dispatches=%d sum_KiB=%.1f avg_KiB=%.1f" % (c, k, n, v, v / n))
+for (k, c), (n, v) in sorted(agg.items(), key=lambda x: (x[0][1], -x[1][1])):
+    print("%s %-70s dispatches=%d sum_KiB=%.1f avg_KiB=%.1f" % (c, k, n, v, v / n))
+
+if "--json" in sys.argv:
+    out = sys.argv[sys.argv.index("--json") + 1]
+    wl = sys.argv[sys.argv.index("--workload") + 1] if "--workload" in sys.argv else ""
+    rec = {"workload": wl, "unit": "KiB", "kernels": {}}
+    for (k, c), (n, v) in agg.items():
+        rec["kernels"].setdefault(k, {})[c] = {"dispatches": n, "sum_kib": v}
+    acc = {c: [0, 0.0] for c in ("FETCH_SIZE", "WRITE_SIZE")}
+    for (k, c), (n, v) in agg.items():
+        if "msm_accumulate_kernel" in k and c in acc:
+            acc[c][0] += n
+            acc[c][1] += v
+    rec["msm_accumulate_kernel"] = {
+        "launches": acc["FETCH_SIZE"][0],
+        "fetch_bytes_per_launch": acc["FETCH_SIZE"][1] * 1024 / max(1, acc["FETCH_SIZE"][0]),
+        "write_bytes_per_launch": acc["WRITE_SIZE"][1] * 1024 / max(1, acc["WRITE_SIZE"][0]),
+        "note": "FETCH_SIZE/WRITE_SIZE as counted (KiB->B); random 96/192-B gathers: no gfx950 doubling applied "
+                "(calibration in DESIGN.md section 3)",
+    }
+    json.dump(rec, open(out, "w"), indent=1)
