@@ -207,8 +207,49 @@ struct Fp {
     r.l[N - 1] = (uint32_t)acc;
     return reduce_once(r, (uint32_t)(acc >> 32));
   }
+  // (x1*y1 + x2*y2) * R^-1 mod p in ONE product-scanning pass (one Montgomery reduction for two products):
+  // the lane-split Fq2 multiplication of the G2 bucket kernel.  (x1 y1 + x2 y2 + m p)/R < p (1 + 2p/R) < 2p.
+  ARK_D static void macc_pair_vv(uint64_t& acc, uint32_t& top, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1) {
+    asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
+        "v_mad_u64_u32 %0, vcc, %4, %5, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc"
+        : "+v"(acc), "+v"(top) : "v"(x0), "v"(y0), "v"(x1), "v"(y1) : "vcc");
+  }
+  ARK_D static Fp mul2sum(const Fp& x1, const Fp& y1, const Fp& x2, const Fp& y2) {
+    static_assert(P::BITS <= 32 * N - 2, "needs two spare top bits");
+    uint32_t m[N];
+    Fp r;
+    uint64_t acc = 0;
+    uint32_t top = 0;
+#pragma unroll
+    for (int k = 0; k < N; k++) {
+#pragma unroll
+      for (int i = 0; i <= k; i++) macc_pair_vv(acc, top, x1.l[i], y1.l[k - i], x2.l[i], y2.l[k - i]);
+#pragma unroll
+      for (int i = 0; i < k; i++) macc_vs(acc, top, m[i], P::mod(k - i));
+      m[k] = (uint32_t)acc * P::INV;
+      macc_vs(acc, top, m[k], P::mod(0));
+      acc = (acc >> 32) | ((uint64_t)top << 32);
+      top = 0;
+    }
+#pragma unroll
+    for (int k = N; k < 2 * N - 1; k++) {
+#pragma unroll
+      for (int i = k - N + 1; i < N; i++) {
+        macc_pair_vv(acc, top, x1.l[i], y1.l[k - i], x2.l[i], y2.l[k - i]);
+        macc_vs(acc, top, m[i], P::mod(k - i));
+      }
+      r.l[k - N] = (uint32_t)acc;
+      acc = (acc >> 32) | ((uint64_t)top << 32);
+      top = 0;
+    }
+    r.l[N - 1] = (uint32_t)acc;
+    return reduce_once(r, (uint32_t)(acc >> 32));
+  }
 #else
   ARK_HD static Fp mul(const Fp& a, const Fp& b) { return mul_c(a, b); }
+  ARK_HD static Fp mul2sum(const Fp& x1, const Fp& y1, const Fp& x2, const Fp& y2) {
+    return add(mul_c(x1, y1), mul_c(x2, y2));
+  }
 #endif
 
   ARK_HD static Fp sqr(const Fp& a) { return mul(a, a); }
@@ -294,6 +335,66 @@ struct Fp2 {
     Base ni = Base::inv(n);
     return Fp2{Base::mul_ni(a.c0, ni), Base::neg(Base::mul_ni(a.c1, ni))};
   }
+};
+
+// Lane-split Fq2: the two lanes of a pair (lane ^ 1) hold c0 and c1 of the SAME element.  Used by the G2 bucket
+// accumulation so that a G2 mixed addition needs G1-like registers per lane (the whole-element version sits at
+// 256 VGPR + 253 AGPR, one wave per SIMD).  Additions are component-wise; a multiplication exchanges the two
+// operands with the partner lane (DPP) and is ONE fused dual-product Montgomery pass per lane:
+//   lane 0:  c0 = a0*b0 + (-a1)*b1        lane 1:  c1 = a0*b1 + a1*b0
+// Every predicate (is_zero, ==) is pair-wide, so control flow stays uniform inside a pair.
+template <class P>
+struct Fp2L {
+  using Base = Fp<P>;
+  using Params = P;
+  static constexpr int N = Base::N;
+  Base c;     // c0 on even lanes, c1 on odd lanes
+
+  ARK_D static uint32_t parity() { return threadIdx.x & 1u; }
+  ARK_D static Base xchg(const Base& v) {
+    Base r;
+#pragma unroll
+    for (int i = 0; i < N; i++) r.l[i] = ark_pair_xchg(v.l[i]);
+    return r;
+  }
+  ARK_D static Fp2L zero() { return Fp2L{Base::zero()}; }
+  ARK_D static Fp2L one() { return Fp2L{parity() ? Base::zero() : Base::one()}; }
+  ARK_D bool is_zero() const {
+    uint32_t accw = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) accw |= c.l[i];
+    const uint32_t other = ark_pair_xchg(accw);
+    return (accw | other) == 0;
+  }
+  ARK_D bool operator==(const Fp2L& o) const {
+    uint32_t accw = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) accw |= (c.l[i] ^ o.c.l[i]);
+    const uint32_t other = ark_pair_xchg(accw);
+    return (accw | other) == 0;
+  }
+  ARK_D bool operator!=(const Fp2L& o) const { return !(*this == o); }
+  ARK_D static Fp2L add(const Fp2L& a, const Fp2L& b) { return Fp2L{Base::add(a.c, b.c)}; }
+  ARK_D static Fp2L sub(const Fp2L& a, const Fp2L& b) { return Fp2L{Base::sub(a.c, b.c)}; }
+  ARK_D static Fp2L neg(const Fp2L& a) { return Fp2L{Base::neg(a.c)}; }
+  ARK_D static Fp2L dbl(const Fp2L& a) { return add(a, a); }
+  ARK_D static Fp2L mul2(const Fp2L& a) { return add(a, a); }
+  ARK_D static Fp2L mul3(const Fp2L& a) { return add(add(a, a), a); }
+  ARK_D static Fp2L mul(const Fp2L& a, const Fp2L& b) {
+    const Base pa = xchg(a.c), pb = xchg(b.c);
+    const Base npa = Base::neg(pa);
+    const bool odd = parity() != 0;
+    Base x1, x2;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+      x1.l[i] = odd ? pa.l[i] : a.c.l[i];
+      x2.l[i] = odd ? a.c.l[i] : npa.l[i];
+    }
+    return Fp2L{Base::mul2sum(x1, b.c, x2, pb)};
+  }
+  ARK_D static Fp2L sqr(const Fp2L& a) { return mul(a, a); }
+  ARK_D static Fp2L mul_ni(const Fp2L& a, const Fp2L& b) { return mul(a, b); }
+  ARK_D static Fp2L sqr_ni(const Fp2L& a) { return mul(a, a); }
 };
 
 using BlsFq = Fp<BlsFqParams>;

@@ -13,6 +13,8 @@
 #define ARK_LAUNCH(kernel, grid, block, smem, stream, ...) \
   emu::launch((grid), (block), (smem), [&]() { kernel(__VA_ARGS__); })
 #define ARK_DYN_SMEM(T, name) T* name = reinterpret_cast<T*>(emu::g_dyn_smem)
+// value held by the other lane of this lane's pair (lane ^ 1)
+static inline uint32_t ark_pair_xchg(uint32_t v) { return __emu_pair_xchg(v); }
 #elif defined(__HIPCC__)
 #include <hip/hip_runtime.h>
 #define ARK_HD __host__ __device__ __forceinline__
@@ -23,6 +25,14 @@
 #define ARK_DYN_SMEM(T, name)                                  \
   extern __shared__ __align__(16) unsigned char _ark_smem[];   \
   T* name = reinterpret_cast<T*>(_ark_smem)
+// value held by the other lane of this lane's pair (lane ^ 1): one v_mov_b32_dpp quad_perm:[1,0,3,2]
+__device__ __forceinline__ uint32_t ark_pair_xchg(uint32_t v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false);
+#else
+  return v;   // never executed on the host pass
+#endif
+}
 #else
 // plain host translation unit (no kernels): arithmetic headers only
 #define ARK_HD inline

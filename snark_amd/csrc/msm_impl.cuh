@@ -62,11 +62,32 @@ inline MsmPlan msm_plan(uint64_t n, uint32_t scalar_bits, bool precomp = false, 
   p.n = n;
   p.precomp = precomp;
   p.scalar_bits = scalar_bits;
+  // target window: ceil(log2 n) - 4, clamped to [4, 16]; then the nearest window size whose TOP window is still
+  // well populated.  With c not dividing the scalar width the last window only sees a few bits, every term of
+  // that window lands in a handful of buckets, and the sort/merge degenerate (measured: c = 15 -> 138 ms instead
+  // of 62 ms per 2^20 proof).  For 255/254-bit scalars the good sizes are 4, 8, 13, 16 (19, 20).
   uint32_t lg = 0;
-  while ((1ull << (lg + 1)) <= (n ? n : 1)) lg++;
-  int c = (int)lg - 4;
-  if (c < 4) c = 4;
-  if (c > 16) c = 16;
+  while ((1ull << lg) < (n ? n : 1)) lg++;
+  int target = (int)lg - 4;
+  if (target < 4) target = 4;
+  if (target > 16) target = 16;
+  auto top_bits = [&](int cc) {
+    const int w = ((int)scalar_bits + 1 + cc - 1) / cc;
+    return (int)scalar_bits + 1 - (w - 1) * cc;
+  };
+  int c = target;
+  for (int d = 0; d <= 16; d++) {
+    bool found = false;
+    for (int cand : {target + d, target - d}) {
+      if (cand < 4 || cand > 16) continue;
+      if (top_bits(cand) >= (cand < 7 ? cand : 7)) {
+        c = cand;
+        found = true;
+        break;
+      }
+    }
+    if (found) break;
+  }
   if (precomp && !force_c) {
     // tuning knob for resident keys (window tables): ARK355_MSM_C=<bits>
     static const int env_c = [] {
@@ -75,7 +96,7 @@ inline MsmPlan msm_plan(uint64_t n, uint32_t scalar_bits, bool precomp = false, 
     }();
     if (env_c >= 4 && env_c <= 24 && n >= 1024) c = env_c;
   }
-  if (force_c) c = force_c;
+  if (force_c) c = force_c;     // an MSM over window tables must use the window size the tables were built for
   p.c = (uint32_t)c;
   // one extra bit so that the top window never produces a carry
   p.windows = (scalar_bits + 1 + p.c - 1) / p.c;
@@ -295,6 +316,121 @@ msm_accumulate_kernel(const Affine<F>* __restrict__ bases, const uint32_t* __res
   }
   msm_flush_run<F>(cur_key, acc, first_run, run_start, end, seg, offsets, counts, buckets, head, head_key, tail,
                    tail_key);
+}
+
+// ---- K4 for G2: lane-split accumulation -------------------------------------------------------------------------
+// Two lanes per segment: even lanes carry the c0 components, odd lanes the c1 components of every Fq2 value
+// (field.cuh Fp2L).  Same segment/run logic as msm_accumulate_kernel; loads and stores touch this lane's half
+// of each Fq2 coordinate.
+template <class P>
+struct is_fp2 {
+  static constexpr bool value = false;
+};
+template <class P>
+struct is_fp2<Fp2<P>> {
+  static constexpr bool value = true;
+};
+
+template <class P>
+ARK_D void g2l_store(XYZZ<Fp2<P>>* dst, const XYZZ<Fp2L<P>>& v, uint32_t par) {
+  Fp<P>* d = reinterpret_cast<Fp<P>*>(dst);
+  d[0 + par] = v.x.c;
+  d[2 + par] = v.y.c;
+  d[4 + par] = v.zz.c;
+  d[6 + par] = v.zzz.c;
+}
+
+template <class P>
+__global__ void __launch_bounds__(MSM_THREADS, 2)
+msm_accumulate_g2l_kernel(const Affine<Fp2<P>>* __restrict__ bases, const uint32_t* __restrict__ sorted_keys,
+                          const uint32_t* __restrict__ sorted_vals, const uint32_t* __restrict__ total_ptr,
+                          const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ counts,
+                          XYZZ<Fp2<P>>* __restrict__ buckets, XYZZ<Fp2<P>>* __restrict__ head,
+                          uint32_t* __restrict__ head_key, XYZZ<Fp2<P>>* __restrict__ tail,
+                          uint32_t* __restrict__ tail_key, uint32_t seg_log) {
+  using FL = Fp2L<P>;
+  using Fq = Fp<P>;
+  const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t seg = gid >> 1, par = gid & 1u;       // blockDim is even: par == lane parity
+  const uint32_t total = *total_ptr;
+  const uint64_t start64 = (uint64_t)seg << seg_log;
+  if (start64 >= total) return;                        // both lanes of a pair leave together
+  const uint32_t start = (uint32_t)start64;
+  const uint32_t seg_len = 1u << seg_log;
+  const uint32_t end = (start + seg_len < total) ? start + seg_len : total;
+  uint32_t cur_key = sorted_keys[start];
+  uint32_t run_start = start;
+  bool first_run = true;
+  XYZZ<FL> acc = XYZZ<FL>::inf();
+  auto flush = [&](uint32_t key, uint32_t run_end) {
+    const uint32_t o = offsets[key], cnt = counts[key];
+    const bool complete = (run_start == o) && (run_end == o + cnt);
+    if (complete) {
+      g2l_store<P>(&buckets[key], acc, par);
+    } else if (first_run) {
+      g2l_store<P>(&head[seg], acc, par);
+      if (par == 0) head_key[seg] = key;
+    } else {
+      g2l_store<P>(&tail[seg], acc, par);
+      if (par == 0) tail_key[seg] = key;
+    }
+  };
+  // register prefetch of this lane's halves of the next base: x.c[par] and y.c[par], 3 (BLS) / 2 (BN) x 16 B each
+  constexpr int Q = sizeof(Fq) / 16;
+  uint4 nx[2 * Q];
+  uint32_t v_next = sorted_vals[start];
+  {
+    const Fq* b = reinterpret_cast<const Fq*>(bases + (v_next & 0x7FFFFFFFu));
+    const uint4* sx = reinterpret_cast<const uint4*>(b + par);
+    const uint4* sy = reinterpret_cast<const uint4*>(b + 2 + par);
+#pragma unroll
+    for (int k = 0; k < Q; k++) {
+      nx[k] = sx[k];
+      nx[Q + k] = sy[k];
+    }
+  }
+  for (uint32_t e = start; e < end; e++) {
+    const uint32_t key = sorted_keys[e];
+    const uint32_t v = v_next;
+    Affine<FL> p;
+    {
+      uint32_t* dx = p.x.c.l;
+      uint32_t* dy = p.y.c.l;
+#pragma unroll
+      for (int k = 0; k < Q; k++) {
+        dx[4 * k + 0] = nx[k].x;
+        dx[4 * k + 1] = nx[k].y;
+        dx[4 * k + 2] = nx[k].z;
+        dx[4 * k + 3] = nx[k].w;
+        dy[4 * k + 0] = nx[Q + k].x;
+        dy[4 * k + 1] = nx[Q + k].y;
+        dy[4 * k + 2] = nx[Q + k].z;
+        dy[4 * k + 3] = nx[Q + k].w;
+      }
+    }
+    {
+      const uint32_t en = (e + 1 < end) ? e + 1 : e;
+      v_next = sorted_vals[en];
+      const Fq* b = reinterpret_cast<const Fq*>(bases + (v_next & 0x7FFFFFFFu));
+      const uint4* sx = reinterpret_cast<const uint4*>(b + par);
+      const uint4* sy = reinterpret_cast<const uint4*>(b + 2 + par);
+#pragma unroll
+      for (int k = 0; k < Q; k++) {
+        nx[k] = sx[k];
+        nx[Q + k] = sy[k];
+      }
+    }
+    if (key != cur_key) {
+      flush(cur_key, e);
+      cur_key = key;
+      run_start = e;
+      first_run = false;
+      acc = XYZZ<FL>::inf();
+    }
+    if (v >> 31) p.y = FL::neg(p.y);
+    xyzz_madd(acc, p);
+  }
+  flush(cur_key, end);
 }
 
 // buckets whose entries straddle segment boundaries: add their partial runs.  Buckets spread over more than
@@ -647,9 +783,25 @@ static void msm_accumulate_phase(ark355_ctx* ctx, const MsmSort& s, MsmBuckets& 
                s.offsets.as<uint32_t>(), s.counts.as<uint32_t>(), b.buckets.as<XYZZ<F>>(), b.head.as<XYZZ<F>>(),
                b.head_key.as<uint32_t>(), b.tail.as<XYZZ<F>>(), b.tail_key.as<uint32_t>(), p.seg_log);
   };
-  if constexpr (sizeof(F) > 64) {
-    if (g2_inline) launch(std::false_type{});
-    else launch(std::true_type{});
+  if constexpr (is_fp2<F>::value) {
+    // G2: lane-split kernel (two lanes per segment).  ARK355_G2_WHOLE=1 selects the whole-element kernel
+    // (inlined or, with ARK355_G2_INLINE=0, out-of-line) for A/B comparison.
+    static const int g2_whole = [] {
+      const char* e = getenv("ARK355_G2_WHOLE");
+      return e && e[0] == '1';
+    }();
+    if (!g2_whole) {
+      using P = typename F::Base::Params;
+      const uint32_t grid_l = (2 * segs + MSM_THREADS - 1) / MSM_THREADS;
+      ARK_LAUNCH((msm_accumulate_g2l_kernel<P>), dim3(grid_l), dim3(MSM_THREADS), 0, stream, d_bases,
+                 s.sorted_keys.as<uint32_t>(), s.sorted_vals.as<uint32_t>(), s.total.as<uint32_t>(),
+                 s.offsets.as<uint32_t>(), s.counts.as<uint32_t>(), b.buckets.as<XYZZ<F>>(), b.head.as<XYZZ<F>>(),
+                 b.head_key.as<uint32_t>(), b.tail.as<XYZZ<F>>(), b.tail_key.as<uint32_t>(), p.seg_log);
+    } else if (g2_inline) {
+      launch(std::false_type{});
+    } else {
+      launch(std::true_type{});
+    }
   } else {
     launch(std::false_type{});
   }
