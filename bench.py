@@ -31,14 +31,14 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=12)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--log-n", type=int, default=20, help="log2 of the constraint count (default: BASELINE configs[1])")
     ap.add_argument("--curve", default="bls12_381", choices=["bls12_381", "bn254"])
     ap.add_argument("--tight", action="store_true", help="domain-tight variant n = 2^k - 100 (N = 2^k)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true", help="skip the closed-form proof check")
-    ap.add_argument("--inflight", type=int, default=2,
+    ap.add_argument("--inflight", type=int, default=3,
                     help="proofs in flight per GPU (independent contexts sharing the resident key; 1 = strictly serial)")
     return ap.parse_args()
 

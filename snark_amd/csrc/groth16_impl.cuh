@@ -10,9 +10,9 @@
 //     a_ext   = [ a_query,    O, alpha_1, delta_1, O       ]
 //     b1_ext  = [ b_g1_query, O, beta_1,  O,       delta_1 ]
 //     b2_ext  = [ b_g2_query, O, beta_2,  O,       delta_2 ]
-//     l_ext   = [ l_query, delta_1 ]                                   (scalars zx[ell .. m+1))
-// one gets  A = MSM(a_ext, zx), B1 = MSM(b1_ext, zx), B2 = MSM(b2_ext, zx) (ONE digit/sort pass shared
-// by the three), L' = MSM(l_ext, zx[ell..m+1)) = l_acc - r s delta_1, H = MSM(h_query, h[0..N-1)), and
+//     l_ext   = [ O x ell,    l_query, delta_1, O, O, O ]              (aligned with zx as well)
+// one gets  A = MSM(a_ext, zx), B1 = MSM(b1_ext, zx), B2 = MSM(b2_ext, zx), L' = MSM(l_ext, zx) = l_acc - r s delta_1
+// (ONE digit/sort pass shared by the four), H = MSM(h_query, h[0..N-1)), and
 //     C = s*A + r*B1 + L' + H.
 // The only remaining sequential work is s*A and r*B1 (two 255-bit double-and-add chains) and three affine
 // normalisations: O(1) work, independent of the circuit size.  A single GPU lane needs ~25 ms for it
@@ -20,6 +20,7 @@
 // library's own host-compiled field code finishes the proof; ARK355_DEVICE_FINALIZE=1 keeps it on the device
 // (groth16_finalize_kernel) and must give the same bytes.
 #pragma once
+#include <future>
 #include "common.h"
 #include "msm_impl.cuh"
 #include "witness_impl.cuh"
@@ -34,8 +35,7 @@ struct PkDev {
   // MSM term-range sharding across GPUs: this handle holds terms [lo, lo+cnt) of each
   // (extended) query vector; shard_count == 1 is the whole key
   uint32_t shard_index = 0, shard_count = 1;
-  uint64_t z_lo = 0, z_cnt = 0;     // of the m+4 extended a/b terms
-  uint64_t l_lo = 0, l_cnt = 0;     // of the w+1 extended l terms
+  uint64_t z_lo = 0, z_cnt = 0;     // of the m+4 extended a/b/l terms
   uint64_t h_lo = 0, h_cnt = 0;     // of the N-1 h terms
 };
 
@@ -46,9 +46,9 @@ static inline void shard_range(uint64_t total, uint32_t idx, uint32_t cnt, uint6
 }
 
 struct ProverScratch {
-  // one sort per distinct scalar vector (zx, zx[ell..], h) and one bucket set per MSM: the five MSMs of a proof
-  // are in flight together on separate streams (sized for 288 GB of HBM, not for reuse)
-  MsmSort sortZ, sortL, sortH;
+  // one sort per distinct scalar vector (zx for A/B1/B2/L', h for H) and one bucket set per MSM: the five MSMs of
+  // a proof are in flight together on separate streams (sized for 288 GB of HBM, not for reuse)
+  MsmSort sortZ, sortH;
   MsmBuckets bkA, bkB1, bkB2, bkL, bkH;
   hipStream_t sW = nullptr, sS = nullptr, sA = nullptr, sR = nullptr;
   ~ProverScratch() {
@@ -119,12 +119,16 @@ static void finalize_host(const XYZZ<typename Curve::Fq> g1[4], const XYZZ<typen
   using Fq = typename Curve::Fq;
   using Fq2 = typename Curve::Fq2;
   using Fr = typename Curve::Fr;
-  XYZZ<Fq> c = xyzz_add(xyzz_mul_scalar(g1[0], s_canon.l, Fr::N), xyzz_mul_scalar(g1[1], r_canon.l, Fr::N));
+  // four independent pieces on four host threads: s*A, r*B1, affine(A), affine(B2); then C
+  auto f_sa = std::async(std::launch::async, [&] { return xyzz_mul_scalar(g1[0], s_canon.l, Fr::N); });
+  auto f_rb = std::async(std::launch::async, [&] { return xyzz_mul_scalar(g1[1], r_canon.l, Fr::N); });
+  auto f_pb = std::async(std::launch::async, [&] { return xyzz_to_affine(g2); });
+  Affine<Fq> pa = xyzz_to_affine(g1[0]);
+  XYZZ<Fq> c = xyzz_add(f_sa.get(), f_rb.get());
   c = xyzz_add(c, g1[2]);
   c = xyzz_add(c, g1[3]);
-  Affine<Fq> pa = xyzz_to_affine(g1[0]);
-  Affine<Fq2> pb = xyzz_to_affine(g2);
   Affine<Fq> pc = xyzz_to_affine(c);
+  Affine<Fq2> pb = f_pb.get();
   memset(out, 0, sizeof(*out));
   memcpy(out->a, &pa, sizeof(pa));
   memcpy(out->b, &pb, sizeof(pb));
@@ -190,7 +194,6 @@ static PkDev* pk_upload(const ark355_pk_desc* d, hipStream_t stream, uint32_t sh
     pk->shard_count = shard_count;
     const uint64_t hn = pk->N ? pk->N - 1 : 0;
     shard_range(m + 4, shard_index, shard_count, &pk->z_lo, &pk->z_cnt);
-    shard_range(pk->w + 1, shard_index, shard_count, &pk->l_lo, &pk->l_cnt);
     shard_range(hn, shard_index, shard_count, &pk->h_lo, &pk->h_cnt);
     ext(d->a_query, G1, d->alpha_g1, d->delta_g1, nullptr);
     precomp_build<Fq, Fr>(pk->a_ext, (uint8_t*)stage.p + pk->z_lo * G1, pk->z_cnt, stream);
@@ -201,10 +204,13 @@ static PkDev* pk_upload(const ark355_pk_desc* d, hipStream_t stream, uint32_t sh
     stage.ensure((pk->h_cnt ? pk->h_cnt : 1) * G1);
     if (pk->h_cnt) ARK_CHECK_HIP(hipMemcpy(stage.p, d->h_query + pk->h_lo * G1, pk->h_cnt * G1, hipMemcpyHostToDevice));
     precomp_build<Fq, Fr>(pk->h_query, stage.p, pk->h_cnt, stream);
-    stage.ensure((pk->w + 1) * G1);
-    if (pk->w) ARK_CHECK_HIP(hipMemcpy(stage.p, d->l_query, pk->w * G1, hipMemcpyHostToDevice));
-    ARK_CHECK_HIP(hipMemcpy((uint8_t*)stage.p + pk->w * G1, d->delta_g1, G1, hipMemcpyHostToDevice));
-    precomp_build<Fq, Fr>(pk->l_ext, (uint8_t*)stage.p + pk->l_lo * G1, pk->l_cnt, stream);
+    // l_ext aligned with zx: ell leading infinities (instance variables carry no l term), l_query, delta_1 at
+    // the -rs slot, three trailing infinities
+    stage.ensure((m + 4) * G1);
+    ARK_CHECK_HIP(hipMemset(stage.p, 0, (m + 4) * G1));
+    if (pk->w) ARK_CHECK_HIP(hipMemcpy((uint8_t*)stage.p + pk->ell * G1, d->l_query, pk->w * G1, hipMemcpyHostToDevice));
+    ARK_CHECK_HIP(hipMemcpy((uint8_t*)stage.p + m * G1, d->delta_g1, G1, hipMemcpyHostToDevice));
+    precomp_build<Fq, Fr>(pk->l_ext, (uint8_t*)stage.p + pk->z_lo * G1, pk->z_cnt, stream);
   } catch (...) {
     delete pk;
     throw;
@@ -218,8 +224,8 @@ static PkDev* pk_upload(const ark355_pk_desc* d, hipStream_t stream, uint32_t sh
 // latency-bound and is tucked underneath them):
 //   sM (ctx stream)  H2D of z and the tail scalars                                  -> evZ
 //   sW               witness map: SpMV, 7 NTTs, pointwise                            -> evH
-//   sS               digits/scan/scatter of zx, zx[ell..], then (after evH) of h     -> evSort[0..2]
-//   sA               bucket accumulation: A, B1, B2 (share sort 0), L', H            -> evAcc[0..4]
+//   sS               digits/scan/scatter of zx, then (after evH) of h               -> evSort[0], evSort[2]
+//   sA               bucket accumulation: A, B1, B2, L' (share sort 0), H            -> evAcc[0..4]
 //   sR               merge + bucket reduction + combine per MSM as evAcc[i] fires; D2H of the five XYZZ results
 template <class Curve>
 static void prove_run(ark355_ctx* ctx, ProverScratch& sc, const PkDev& pk, const R1csDev& r1, const void* z_src,
@@ -284,8 +290,7 @@ static void prove_run(ark355_ctx* ctx, ProverScratch& sc, const PkDev& pk, const
     ARK_CHECK_HIP(hipStreamWaitEvent(sS, ev[E_Z], 0));
     msm_sort<Fr>(ctx, sc.sortZ, (const uint8_t*)sc.zx.p + pk.z_lo * sizeof(Fr), pk.z_cnt, 1, sS, &pk.a_ext);
     ARK_CHECK_HIP(hipEventRecord(ev[E_SORT0], sS));
-    msm_sort<Fr>(ctx, sc.sortL, (const uint8_t*)sc.zx.p + (ell + pk.l_lo) * sizeof(Fr), pk.l_cnt, 1, sS, &pk.l_ext);
-    ARK_CHECK_HIP(hipEventRecord(ev[E_SORT1], sS));
+    ARK_CHECK_HIP(hipEventRecord(ev[E_SORT1], sS));     // (L' shares the sort of zx)
     ARK_CHECK_HIP(hipStreamWaitEvent(sS, ev[E_H], 0));
     msm_sort<Fr>(ctx, sc.sortH, (const uint8_t*)d_h + pk.h_lo * sizeof(Fr), pk.h_cnt, 1, sS, &pk.h_query);
     ARK_CHECK_HIP(hipEventRecord(ev[E_SORT2], sS));
@@ -302,7 +307,7 @@ static void prove_run(ark355_ctx* ctx, ProverScratch& sc, const PkDev& pk, const
         {E_SORT0, &sc.sortZ, &sc.bkA, false, pk.a_ext.table.p, 0},
         {E_SORT0, &sc.sortZ, &sc.bkB1, false, pk.b1_ext.table.p, 1},
         {E_SORT0, &sc.sortZ, &sc.bkB2, true, pk.b2_ext.table.p, 0},
-        {E_SORT1, &sc.sortL, &sc.bkL, false, pk.l_ext.table.p, 2},
+        {E_SORT0, &sc.sortZ, &sc.bkL, false, pk.l_ext.table.p, 2},
         {E_SORT2, &sc.sortH, &sc.bkH, false, pk.h_query.table.p, 3},
     };
     uint64_t pts = 0;

@@ -36,7 +36,7 @@ constexpr uint32_t MSM_INVALID = 0xFFFFFFFFu;
 #ifndef ARK_MSM_SEG_LOG_LARGE
 #define ARK_MSM_SEG_LOG_LARGE 6
 #endif
-constexpr uint32_t MSM_RED_K = 16;        // buckets per reduce lane
+constexpr uint32_t MSM_RED_K = 4;         // buckets per reduce lane (latency-bound kernel: short chains, many lanes)
 constexpr uint32_t MSM_THREADS = 256;
 #ifndef ARK_G1_PREFETCH
 #define ARK_G1_PREFETCH 1   // measured neutral on MI355X (7.75 vs 7.79 ms for A+B1); kept for small-n latency

@@ -31,7 +31,7 @@ if "--json" in sys.argv:
         rec["kernels"].setdefault(k, {})[c] = {"dispatches": n, "sum_kib": v}
     acc = {c: [0, 0.0] for c in ("FETCH_SIZE", "WRITE_SIZE")}
     for (k, c), (n, v) in agg.items():
-        if "msm_accumulate_kernel" in k and c in acc:
+        if "msm_accumulate" in k and c in acc:
             acc[c][0] += n
             acc[c][1] += v
     rec["msm_accumulate_kernel"] = {
