@@ -178,6 +178,50 @@ struct Fp {
         "v_mad_u64_u32 %0, vcc, %4, %5, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc"
         : "+v"(acc), "+v"(top) : "v"(x0), "v"(y0), "v"(x1), "s"(y1_const) : "vcc");
   }
+#include "mont_asm_chunks.inc"
+  // pairs i = I0 .. I0+CNT-1 of column K: a[i]*b[K-i] + m[i]*p[K-i], at most 6 pairs per asm statement (hipcc pads
+  // every asm statement whose result feeds the next instruction with an s_nop: fewer statements, fewer bubbles)
+  template <int CNT, int I0, int K>
+  ARK_D static void col_pairs(uint64_t& acc, uint32_t& top, const Fp& a, const Fp& b, const uint32_t* m) {
+#define ARK_PAIR(j) a.l[I0 + j], b.l[K - I0 - j], m[I0 + j], P::mod(K - I0 - j)
+    if constexpr (CNT >= 6) {
+      macc_chunk6(acc, top, ARK_PAIR(0), ARK_PAIR(1), ARK_PAIR(2), ARK_PAIR(3), ARK_PAIR(4), ARK_PAIR(5));
+      col_pairs<CNT - 6, I0 + 6, K>(acc, top, a, b, m);
+    } else if constexpr (CNT == 5) {
+      macc_chunk5(acc, top, ARK_PAIR(0), ARK_PAIR(1), ARK_PAIR(2), ARK_PAIR(3), ARK_PAIR(4));
+    } else if constexpr (CNT == 4) {
+      macc_chunk4(acc, top, ARK_PAIR(0), ARK_PAIR(1), ARK_PAIR(2), ARK_PAIR(3));
+    } else if constexpr (CNT == 3) {
+      macc_chunk3(acc, top, ARK_PAIR(0), ARK_PAIR(1), ARK_PAIR(2));
+    } else if constexpr (CNT == 2) {
+      macc_chunk2(acc, top, ARK_PAIR(0), ARK_PAIR(1));
+    } else if constexpr (CNT == 1) {
+      macc_chunk1(acc, top, ARK_PAIR(0));
+    }
+#undef ARK_PAIR
+  }
+  template <int K>
+  ARK_D static void mul_col_lo(uint64_t& acc, uint32_t& top, const Fp& a, const Fp& b, uint32_t* m, Fp& r) {
+    if constexpr (K < N) {
+      col_pairs<K, 0, K>(acc, top, a, b, m);
+      macc_vv(acc, top, a.l[K], b.l[0]);
+      m[K] = (uint32_t)acc * P::INV;
+      macc_vs(acc, top, m[K], P::mod(0));
+      acc = (acc >> 32) | ((uint64_t)top << 32);
+      top = 0;
+      mul_col_lo<K + 1>(acc, top, a, b, m, r);
+    }
+  }
+  template <int K>
+  ARK_D static void mul_col_hi(uint64_t& acc, uint32_t& top, const Fp& a, const Fp& b, const uint32_t* m, Fp& r) {
+    if constexpr (K < 2 * N - 1) {
+      col_pairs<2 * N - 1 - K, K - N + 1, K>(acc, top, a, b, m);
+      r.l[K - N] = (uint32_t)acc;
+      acc = (acc >> 32) | ((uint64_t)top << 32);
+      top = 0;
+      mul_col_hi<K + 1>(acc, top, a, b, m, r);
+    }
+  }
   // (A two-chain variant -- a*b and m*p products on separate accumulators with SGPR-pair carries -- was
   // measured on MI355X and is SLOWER: 46.0 vs 51.9 Gmul/s; the MAD chain is issue-bound, not latency-bound.)
   ARK_D static Fp mul(const Fp& a, const Fp& b) {
@@ -186,24 +230,8 @@ struct Fp {
     Fp r;
     uint64_t acc = 0;
     uint32_t top = 0;
-#pragma unroll
-    for (int k = 0; k < N; k++) {
-#pragma unroll
-      for (int i = 0; i < k; i++) macc_pair(acc, top, a.l[i], b.l[k - i], m[i], P::mod(k - i));
-      macc_vv(acc, top, a.l[k], b.l[0]);
-      m[k] = (uint32_t)acc * P::INV;
-      macc_vs(acc, top, m[k], P::mod(0));
-      acc = (acc >> 32) | ((uint64_t)top << 32);
-      top = 0;
-    }
-#pragma unroll
-    for (int k = N; k < 2 * N - 1; k++) {
-#pragma unroll
-      for (int i = k - N + 1; i < N; i++) macc_pair(acc, top, a.l[i], b.l[k - i], m[i], P::mod(k - i));
-      r.l[k - N] = (uint32_t)acc;
-      acc = (acc >> 32) | ((uint64_t)top << 32);
-      top = 0;
-    }
+    mul_col_lo<0>(acc, top, a, b, m, r);
+    mul_col_hi<N>(acc, top, a, b, m, r);
     r.l[N - 1] = (uint32_t)acc;
     return reduce_once(r, (uint32_t)(acc >> 32));
   }
@@ -214,34 +242,79 @@ struct Fp {
         "v_mad_u64_u32 %0, vcc, %4, %5, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc"
         : "+v"(acc), "+v"(top) : "v"(x0), "v"(y0), "v"(x1), "v"(y1) : "vcc");
   }
+  // dual-product pairs i = I0 .. I0+CNT-1 of column K (x1[i]*y1[K-i] + x2[i]*y2[K-i]) and the reduction products
+  // m[i]*p[K-i], chunked like col_pairs
+  template <int CNT, int I0, int K>
+  ARK_D static void col_dual(uint64_t& acc, uint32_t& top, const Fp& x1, const Fp& y1, const Fp& x2, const Fp& y2) {
+#define ARK_D4(j) x1.l[I0 + j], y1.l[K - I0 - j], x2.l[I0 + j], y2.l[K - I0 - j]
+    if constexpr (CNT >= 6) {
+      macc_dchunk6(acc, top, ARK_D4(0), ARK_D4(1), ARK_D4(2), ARK_D4(3), ARK_D4(4), ARK_D4(5));
+      col_dual<CNT - 6, I0 + 6, K>(acc, top, x1, y1, x2, y2);
+    } else if constexpr (CNT == 5) {
+      macc_dchunk5(acc, top, ARK_D4(0), ARK_D4(1), ARK_D4(2), ARK_D4(3), ARK_D4(4));
+    } else if constexpr (CNT == 4) {
+      macc_dchunk4(acc, top, ARK_D4(0), ARK_D4(1), ARK_D4(2), ARK_D4(3));
+    } else if constexpr (CNT == 3) {
+      macc_dchunk3(acc, top, ARK_D4(0), ARK_D4(1), ARK_D4(2));
+    } else if constexpr (CNT == 2) {
+      macc_dchunk2(acc, top, ARK_D4(0), ARK_D4(1));
+    } else if constexpr (CNT == 1) {
+      macc_dchunk1(acc, top, ARK_D4(0));
+    }
+#undef ARK_D4
+  }
+  template <int CNT, int I0, int K>
+  ARK_D static void col_red(uint64_t& acc, uint32_t& top, const uint32_t* m) {
+#define ARK_S2(j) m[I0 + j], P::mod(K - I0 - j)
+    if constexpr (CNT >= 6) {
+      macc_schunk6(acc, top, ARK_S2(0), ARK_S2(1), ARK_S2(2), ARK_S2(3), ARK_S2(4), ARK_S2(5));
+      col_red<CNT - 6, I0 + 6, K>(acc, top, m);
+    } else if constexpr (CNT == 5) {
+      macc_schunk5(acc, top, ARK_S2(0), ARK_S2(1), ARK_S2(2), ARK_S2(3), ARK_S2(4));
+    } else if constexpr (CNT == 4) {
+      macc_schunk4(acc, top, ARK_S2(0), ARK_S2(1), ARK_S2(2), ARK_S2(3));
+    } else if constexpr (CNT == 3) {
+      macc_schunk3(acc, top, ARK_S2(0), ARK_S2(1), ARK_S2(2));
+    } else if constexpr (CNT == 2) {
+      macc_schunk2(acc, top, ARK_S2(0), ARK_S2(1));
+    } else if constexpr (CNT == 1) {
+      macc_schunk1(acc, top, ARK_S2(0));
+    }
+#undef ARK_S2
+  }
+  template <int K>
+  ARK_D static void m2_col_lo(uint64_t& acc, uint32_t& top, const Fp& x1, const Fp& y1, const Fp& x2, const Fp& y2,
+                              uint32_t* m) {
+    if constexpr (K < N) {
+      col_dual<K + 1, 0, K>(acc, top, x1, y1, x2, y2);
+      col_red<K, 0, K>(acc, top, m);
+      m[K] = (uint32_t)acc * P::INV;
+      macc_vs(acc, top, m[K], P::mod(0));
+      acc = (acc >> 32) | ((uint64_t)top << 32);
+      top = 0;
+      m2_col_lo<K + 1>(acc, top, x1, y1, x2, y2, m);
+    }
+  }
+  template <int K>
+  ARK_D static void m2_col_hi(uint64_t& acc, uint32_t& top, const Fp& x1, const Fp& y1, const Fp& x2, const Fp& y2,
+                              const uint32_t* m, Fp& r) {
+    if constexpr (K < 2 * N - 1) {
+      col_dual<2 * N - 1 - K, K - N + 1, K>(acc, top, x1, y1, x2, y2);
+      col_red<2 * N - 1 - K, K - N + 1, K>(acc, top, m);
+      r.l[K - N] = (uint32_t)acc;
+      acc = (acc >> 32) | ((uint64_t)top << 32);
+      top = 0;
+      m2_col_hi<K + 1>(acc, top, x1, y1, x2, y2, m, r);
+    }
+  }
   ARK_D static Fp mul2sum(const Fp& x1, const Fp& y1, const Fp& x2, const Fp& y2) {
     static_assert(P::BITS <= 32 * N - 2, "needs two spare top bits");
     uint32_t m[N];
     Fp r;
     uint64_t acc = 0;
     uint32_t top = 0;
-#pragma unroll
-    for (int k = 0; k < N; k++) {
-#pragma unroll
-      for (int i = 0; i <= k; i++) macc_pair_vv(acc, top, x1.l[i], y1.l[k - i], x2.l[i], y2.l[k - i]);
-#pragma unroll
-      for (int i = 0; i < k; i++) macc_vs(acc, top, m[i], P::mod(k - i));
-      m[k] = (uint32_t)acc * P::INV;
-      macc_vs(acc, top, m[k], P::mod(0));
-      acc = (acc >> 32) | ((uint64_t)top << 32);
-      top = 0;
-    }
-#pragma unroll
-    for (int k = N; k < 2 * N - 1; k++) {
-#pragma unroll
-      for (int i = k - N + 1; i < N; i++) {
-        macc_pair_vv(acc, top, x1.l[i], y1.l[k - i], x2.l[i], y2.l[k - i]);
-        macc_vs(acc, top, m[i], P::mod(k - i));
-      }
-      r.l[k - N] = (uint32_t)acc;
-      acc = (acc >> 32) | ((uint64_t)top << 32);
-      top = 0;
-    }
+    m2_col_lo<0>(acc, top, x1, y1, x2, y2, m);
+    m2_col_hi<N>(acc, top, x1, y1, x2, y2, m, r);
     r.l[N - 1] = (uint32_t)acc;
     return reduce_once(r, (uint32_t)(acc >> 32));
   }

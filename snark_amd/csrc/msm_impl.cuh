@@ -340,6 +340,12 @@ ARK_D void g2l_store(XYZZ<Fp2<P>>* dst, const XYZZ<Fp2L<P>>& v, uint32_t par) {
   d[6 + par] = v.zzz.c;
 }
 
+#ifndef ARK_G2L_PREFETCH
+#define ARK_G2L_PREFETCH 0
+#endif
+// Two waves per SIMD need <= 256 registers per lane.  With the register prefetch of the next base the kernel
+// lands on 251-256, and that build ran at 11.2 ms on some MI355X boxes but 17-24 ms on others (same binary);
+// without it there is head-room below the cliff.
 template <class P>
 __global__ void __launch_bounds__(MSM_THREADS, 2)
 msm_accumulate_g2l_kernel(const Affine<Fp2<P>>* __restrict__ bases, const uint32_t* __restrict__ sorted_keys,
@@ -375,12 +381,13 @@ msm_accumulate_g2l_kernel(const Affine<Fp2<P>>* __restrict__ bases, const uint32
       if (par == 0) tail_key[seg] = key;
     }
   };
-  // register prefetch of this lane's halves of the next base: x.c[par] and y.c[par], 3 (BLS) / 2 (BN) x 16 B each
+  // this lane's halves of a base: x.c[par] and y.c[par], 3 (BLS) / 2 (BN) x 16 B each; optionally prefetched one
+  // iteration ahead into registers
   constexpr int Q = sizeof(Fq) / 16;
+  constexpr bool PF = ARK_G2L_PREFETCH != 0;
   uint4 nx[2 * Q];
-  uint32_t v_next = sorted_vals[start];
-  {
-    const Fq* b = reinterpret_cast<const Fq*>(bases + (v_next & 0x7FFFFFFFu));
+  auto fetch = [&](uint32_t v) {
+    const Fq* b = reinterpret_cast<const Fq*>(bases + (v & 0x7FFFFFFFu));
     const uint4* sx = reinterpret_cast<const uint4*>(b + par);
     const uint4* sy = reinterpret_cast<const uint4*>(b + 2 + par);
 #pragma unroll
@@ -388,10 +395,16 @@ msm_accumulate_g2l_kernel(const Affine<Fp2<P>>* __restrict__ bases, const uint32
       nx[k] = sx[k];
       nx[Q + k] = sy[k];
     }
-  }
+  };
+  uint32_t v_next = sorted_vals[start];
+  if constexpr (PF) fetch(v_next);
   for (uint32_t e = start; e < end; e++) {
     const uint32_t key = sorted_keys[e];
-    const uint32_t v = v_next;
+    uint32_t v = v_next;
+    if constexpr (!PF) {
+      v = sorted_vals[e];
+      fetch(v);
+    }
     Affine<FL> p;
     {
       uint32_t* dx = p.x.c.l;
@@ -408,17 +421,10 @@ msm_accumulate_g2l_kernel(const Affine<Fp2<P>>* __restrict__ bases, const uint32
         dy[4 * k + 3] = nx[Q + k].w;
       }
     }
-    {
+    if constexpr (PF) {
       const uint32_t en = (e + 1 < end) ? e + 1 : e;
       v_next = sorted_vals[en];
-      const Fq* b = reinterpret_cast<const Fq*>(bases + (v_next & 0x7FFFFFFFu));
-      const uint4* sx = reinterpret_cast<const uint4*>(b + par);
-      const uint4* sy = reinterpret_cast<const uint4*>(b + 2 + par);
-#pragma unroll
-      for (int k = 0; k < Q; k++) {
-        nx[k] = sx[k];
-        nx[Q + k] = sy[k];
-      }
+      fetch(v_next);
     }
     if (key != cur_key) {
       flush(cur_key, e);
