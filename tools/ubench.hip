@@ -23,7 +23,7 @@ __global__ void __launch_bounds__(256) k_ops(uint32_t* out, uint32_t a0, uint32_
       if (OP == 4) acc[i] = __umul24((uint32_t)acc[i], b) + 1;       // v_mul_u32_u24 / mad
       if (OP == 5) f[i] = __builtin_fma(f[i], 1.0000001, 0.5);                       // v_fma_f64
       if (OP == 6) acc[i] = (uint32_t)acc[i] + b;                                    // v_add_u32
-      if (OP == 7) acc[i] = __umulhi((uint32_t)acc[i] & 0xFFFFFF, b & 0xFFFFFF) + 1;     // v_mul_hi_u32_u24
+      if (OP == 7) acc[i] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)acc[i], 0xB1, 0xF, 0xF, false) + b;   // v_mov_b32_dpp quad_perm
     }
   }
   uint64_t s = 0; double fs = 0;
@@ -83,6 +83,24 @@ static int check_mul(const char* name) {
   return hb != 0;
 }
 
+template <class P>
+__global__ void __launch_bounds__(256, 2) k_madd_g2l(XYZZ<Fp2<P>>* out, const Affine<Fp2<P>>* in, int iters) {
+  using FL = Fp2L<P>;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int seg = t >> 1, par = t & 1;
+  XYZZ<FL> acc = XYZZ<FL>::inf();
+  for (int it = 0; it < iters; it++) {
+    const Fp<P>* b = reinterpret_cast<const Fp<P>*>(in + ((seg * 7 + it * 13) & 511));
+    Affine<FL> p;
+    p.x.c = b[par];
+    p.y.c = b[2 + par];
+    xyzz_madd(acc, p);
+  }
+  Fp<P>* d = reinterpret_cast<Fp<P>*>(out + seg);
+  d[par] = acc.x.c; d[2 + par] = acc.y.c; d[4 + par] = acc.zz.c; d[6 + par] = acc.zzz.c;
+}
+template <class P> static void l_madd_g2l(void* c);
+
 static float time_it(void (*launch)(void*), void* ctx, int reps) {
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   launch(ctx); hipDeviceSynchronize();
@@ -98,6 +116,8 @@ template <int OP> static void l_ops(void* c) { Ctx* x = (Ctx*)c; hipLaunchKernel
 template <class F, bool NI> static void l_fmul(void* c) { Ctx* x = (Ctx*)c; hipLaunchKernelGGL((k_fmul<F, NI>), dim3(x->blocks), dim3(256), 0, 0, (F*)x->out, (const F*)x->in, x->iters); }
 template <class F, bool NI> static void l_madd(void* c) { Ctx* x = (Ctx*)c; hipLaunchKernelGGL((k_madd<F, NI>), dim3(x->blocks), dim3(256), 0, 0, (XYZZ<F>*)x->out, (const Affine<F>*)x->in, x->iters); }
 
+template <class P> static void l_madd_g2l(void* c) { Ctx* x = (Ctx*)c; hipLaunchKernelGGL((k_madd_g2l<P>), dim3(x->blocks), dim3(256), 0, 0, (XYZZ<Fp2<P>>*)x->out, (const Affine<Fp2<P>>*)x->in, x->iters); }
+
 int main() {
   hipDeviceProp_t prop; CHECK(hipGetDeviceProperties(&prop, 0));
   printf("device: %s  CUs=%d  clock=%d MHz  LDS/block=%zu  regs/block=%d\n", prop.name, prop.multiProcessorCount, prop.clockRate / 1000, prop.sharedMemPerBlock, prop.regsPerBlock);
@@ -109,7 +129,7 @@ int main() {
   { uint32_t* h = (uint32_t*)calloc(1024 * 512 / 4, 4); for (int i = 0; i < 1024 * 128; i++) h[i] = (i * 2654435761u) >> 4; 
     // clear top limbs to stay below the modulus for every layout used
     CHECK(hipMemcpy(c.in, h, 1024 * 512, hipMemcpyHostToDevice)); free(h); }
-  const char* names[] = {"v_mad_u64_u32", "v_mul_lo_u32", "v_mul_hi_u32", "add_u64", "v_mul_u32_u24", "v_fma_f64", "v_add_u32", "v_mul_hi_u32_u24"};
+  const char* names[] = {"v_mad_u64_u32", "v_mul_lo_u32", "v_mul_hi_u32", "add_u64", "v_mul_u32_u24", "v_fma_f64", "v_add_u32", "v_mov_dpp+add"};
   void (*ls[])(void*) = {l_ops<0>, l_ops<1>, l_ops<2>, l_ops<3>, l_ops<4>, l_ops<5>, l_ops<6>, l_ops<7>};
   for (int op = 0; op < 8; op++) {
     float ms = time_it(ls[op], &c, 5);
@@ -130,7 +150,8 @@ int main() {
   struct { const char* n; void (*l)(void*); } md[] = {
     {"G1 BLS madd inline", l_madd<BlsFq, false>}, {"G1 BLS madd noinline", l_madd<BlsFq, true>},
     {"G2 BLS madd inline", l_madd<BlsFq2, false>}, {"G2 BLS madd noinline", l_madd<BlsFq2, true>},
-    {"G1 BN madd inline", l_madd<BnFq, false>}, {"G2 BN madd noinline", l_madd<BnFq2, true>}};
+    {"G1 BN madd inline", l_madd<BnFq, false>}, {"G2 BN madd noinline", l_madd<BnFq2, true>},
+    {"G2 BLS madd lane-split (x2 lanes)", l_madd_g2l<BlsFqParams>}, {"G2 BN madd lane-split (x2 lanes)", l_madd_g2l<BnFqParams>}};
   for (auto& f : md) {
     float ms = time_it(f.l, &c, 3);
     double ops = (double)c.blocks * 256 * c.iters;
