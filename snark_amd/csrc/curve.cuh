@@ -110,10 +110,17 @@ ARK_HD void xyzz_madd_t(XYZZ<F>& acc, const Affine<F>& p) {
   F Q = fmul<NI>(acc.x, PP);
   acc.zz = fmul<NI>(acc.zz, PP);
   acc.zzz = fmul<NI>(acc.zzz, PPP);
-  F T = fmul<NI>(acc.y, PPP);
-  F X3 = F::sub(F::sub(fsqr<NI>(R), PPP), F::mul2(Q));
-  acc.x = X3;
-  acc.y = F::sub(fmul<NI>(R, F::sub(Q, X3)), T);
+  if constexpr (!NI && F::FUSED_MUL_SUB) {
+    // Y3 = R (Q - X3) - Y1 PPP as one multi-product Montgomery pass (one reduction instead of two)
+    F X3 = F::sub(F::sub(fsqr<NI>(R), PPP), F::mul2(Q));
+    acc.x = X3;
+    acc.y = F::mul_sub(R, F::sub(Q, X3), acc.y, PPP);
+  } else {
+    F T = fmul<NI>(acc.y, PPP);
+    F X3 = F::sub(F::sub(fsqr<NI>(R), PPP), F::mul2(Q));
+    acc.x = X3;
+    acc.y = F::sub(fmul<NI>(R, F::sub(Q, X3)), T);
+  }
 }
 
 // a + b (add-2008-s); handles every special case.

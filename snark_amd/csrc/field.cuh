@@ -318,12 +318,61 @@ struct Fp {
     r.l[N - 1] = (uint32_t)acc;
     return reduce_once(r, (uint32_t)(acc >> 32));
   }
+  // (x1*y1 + x2*y2 + x3*y3 + x4*y4) * R^-1 mod p, one reduction for four products (the fused
+  // Y3 = R*(Q - X3) - Y1*PPP of the lane-split G2 mixed addition).  (4 p^2 + m p)/R < p (1 + 4p/R) < 2p needs
+  // 4p < R, i.e. two spare top bits.
+  template <int K>
+  ARK_D static void m4_col_lo(uint64_t& acc, uint32_t& top, const Fp& x1, const Fp& y1, const Fp& x2, const Fp& y2,
+                              const Fp& x3, const Fp& y3, const Fp& x4, const Fp& y4, uint32_t* m) {
+    if constexpr (K < N) {
+      col_dual<K + 1, 0, K>(acc, top, x1, y1, x2, y2);
+      col_dual<K + 1, 0, K>(acc, top, x3, y3, x4, y4);
+      col_red<K, 0, K>(acc, top, m);
+      m[K] = (uint32_t)acc * P::INV;
+      macc_vs(acc, top, m[K], P::mod(0));
+      acc = (acc >> 32) | ((uint64_t)top << 32);
+      top = 0;
+      m4_col_lo<K + 1>(acc, top, x1, y1, x2, y2, x3, y3, x4, y4, m);
+    }
+  }
+  template <int K>
+  ARK_D static void m4_col_hi(uint64_t& acc, uint32_t& top, const Fp& x1, const Fp& y1, const Fp& x2, const Fp& y2,
+                              const Fp& x3, const Fp& y3, const Fp& x4, const Fp& y4, const uint32_t* m, Fp& r) {
+    if constexpr (K < 2 * N - 1) {
+      col_dual<2 * N - 1 - K, K - N + 1, K>(acc, top, x1, y1, x2, y2);
+      col_dual<2 * N - 1 - K, K - N + 1, K>(acc, top, x3, y3, x4, y4);
+      col_red<2 * N - 1 - K, K - N + 1, K>(acc, top, m);
+      r.l[K - N] = (uint32_t)acc;
+      acc = (acc >> 32) | ((uint64_t)top << 32);
+      top = 0;
+      m4_col_hi<K + 1>(acc, top, x1, y1, x2, y2, x3, y3, x4, y4, m, r);
+    }
+  }
+  ARK_D static Fp mul4sum(const Fp& x1, const Fp& y1, const Fp& x2, const Fp& y2, const Fp& x3, const Fp& y3,
+                          const Fp& x4, const Fp& y4) {
+    static_assert(P::BITS <= 32 * N - 2, "needs two spare top bits");
+    uint32_t m[N];
+    Fp r;
+    uint64_t acc = 0;
+    uint32_t top = 0;
+    m4_col_lo<0>(acc, top, x1, y1, x2, y2, x3, y3, x4, y4, m);
+    m4_col_hi<N>(acc, top, x1, y1, x2, y2, x3, y3, x4, y4, m, r);
+    r.l[N - 1] = (uint32_t)acc;
+    return reduce_once(r, (uint32_t)(acc >> 32));
+  }
 #else
   ARK_HD static Fp mul(const Fp& a, const Fp& b) { return mul_c(a, b); }
   ARK_HD static Fp mul2sum(const Fp& x1, const Fp& y1, const Fp& x2, const Fp& y2) {
     return add(mul_c(x1, y1), mul_c(x2, y2));
   }
+  ARK_HD static Fp mul4sum(const Fp& x1, const Fp& y1, const Fp& x2, const Fp& y2, const Fp& x3, const Fp& y3,
+                           const Fp& x4, const Fp& y4) {
+    return add(add(mul_c(x1, y1), mul_c(x2, y2)), add(mul_c(x3, y3), mul_c(x4, y4)));
+  }
 #endif
+  // a*b - c*d with ONE Montgomery reduction (the Y3 of the mixed addition)
+  static constexpr bool FUSED_MUL_SUB = true;
+  ARK_HD static Fp mul_sub(const Fp& a, const Fp& b, const Fp& c, const Fp& d) { return mul2sum(a, b, neg(c), d); }
 
   ARK_HD static Fp sqr(const Fp& a) { return mul(a, a); }
 
@@ -392,6 +441,8 @@ struct Fp2 {
     Base m = Base::mul(a.c0, a.c1);
     return Fp2{t, Base::add(m, m)};
   }
+  static constexpr bool FUSED_MUL_SUB = false;
+  ARK_HD static Fp2 mul_sub(const Fp2& a, const Fp2& b, const Fp2& c, const Fp2& d) { return sub(mul(a, b), mul(c, d)); }
   ARK_HD_NOINLINE static Fp2 mul_ni(const Fp2& a, const Fp2& b) {
     Base v0 = Base::mul_ni(a.c0, b.c0);
     Base v1 = Base::mul_ni(a.c1, b.c1);
@@ -465,7 +516,39 @@ struct Fp2L {
     }
     return Fp2L{Base::mul2sum(x1, b.c, x2, pb)};
   }
-  ARK_D static Fp2L sqr(const Fp2L& a) { return mul(a, a); }
+  // (a0 + a1 u)^2 = (a0 + a1)(a0 - a1) + 2 a0 a1 u: ONE single-product Montgomery pass per lane
+  //   even lane: (a0 + a1) * (a0 - a1)        odd lane: (a0 + a0) * a1
+  ARK_D static Fp2L sqr(const Fp2L& a) {
+    const Base pa = xchg(a.c);
+    const bool odd = parity() != 0;
+    Base t;
+#pragma unroll
+    for (int i = 0; i < N; i++) t.l[i] = odd ? pa.l[i] : a.c.l[i];
+    const Base u = Base::add(pa, t);                 // even: a1 + a0      odd: a0 + a0
+    const Base d = Base::sub(a.c, pa);               // even: a0 - a1      (odd: unused)
+    Base v;
+#pragma unroll
+    for (int i = 0; i < N; i++) v.l[i] = odd ? a.c.l[i] : d.l[i];
+    return Fp2L{Base::mul(u, v)};
+  }
+  // a*b - c*d: four products, one reduction per lane
+  static constexpr bool FUSED_MUL_SUB = true;
+  ARK_D static Fp2L mul_sub(const Fp2L& a, const Fp2L& b, const Fp2L& c, const Fp2L& d) {
+    const bool odd = parity() != 0;
+    const Base pa = xchg(a.c), pb = xchg(b.c), pc = xchg(c.c), pd = xchg(d.c);
+    const Base npa = Base::neg(pa), nc = Base::neg(c.c);
+    Base x1, x2, x3, x4;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+      x1.l[i] = odd ? pa.l[i] : a.c.l[i];            // even: a0*b0 - a1*b1        odd: a0*b1 + a1*b0
+      x2.l[i] = odd ? a.c.l[i] : npa.l[i];
+      x4.l[i] = odd ? nc.l[i] : pc.l[i];             // even: -c0*d0 + c1*d1       odd: -c0*d1 - c1*d0
+    }
+    const Base npc = Base::neg(pc);
+#pragma unroll
+    for (int i = 0; i < N; i++) x3.l[i] = odd ? npc.l[i] : nc.l[i];
+    return Fp2L{Base::mul4sum(x1, b.c, x2, pb, x3, d.c, x4, pd)};
+  }
   ARK_D static Fp2L mul_ni(const Fp2L& a, const Fp2L& b) { return mul(a, b); }
   ARK_D static Fp2L sqr_ni(const Fp2L& a) { return mul(a, a); }
 };

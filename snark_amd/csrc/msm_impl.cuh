@@ -27,6 +27,11 @@
 namespace ark355 {
 
 constexpr uint32_t MSM_INVALID = 0xFFFFFFFFu;
+#ifdef ARK_DEBUG_SMALL_TABLE
+#define ARK_TBL_MASK 0x3FFu   // experiment only: every gather hits the same 1024 rows (results are wrong)
+#else
+#define ARK_TBL_MASK 0x7FFFFFFFu
+#endif
 // entries per accumulate lane = 2^seg_log, chosen per MSM (MsmPlan::seg_log): 32 keeps small MSMs wide enough to
 // fill the chip, 64 halves the partial runs (merge work, tail latency) of the 2^24-entry MSMs of a 2^20 proof
 // (measured on MI355X: 53.7 / 52.6 / 52.3 ms per proof for 32 / 64 / 128)
@@ -276,7 +281,7 @@ msm_accumulate_kernel(const Affine<F>* __restrict__ bases, const uint32_t* __res
   uint4 nx[Q];
   uint32_t v_next = sorted_vals[start];
   if constexpr (PREFETCH) {
-    const uint4* src = reinterpret_cast<const uint4*>(bases + (v_next & 0x7FFFFFFFu));
+    const uint4* src = reinterpret_cast<const uint4*>(bases + (v_next & ARK_TBL_MASK));
 #pragma unroll
     for (int k = 0; k < Q; k++) nx[k] = src[k];
   }
@@ -295,12 +300,12 @@ msm_accumulate_kernel(const Affine<F>* __restrict__ bases, const uint32_t* __res
       }
       const uint32_t en = (e + 1 < end) ? e + 1 : e;     // clamp: the last iteration re-reads its own entry
       v_next = sorted_vals[en];
-      const uint4* src = reinterpret_cast<const uint4*>(bases + (v_next & 0x7FFFFFFFu));
+      const uint4* src = reinterpret_cast<const uint4*>(bases + (v_next & ARK_TBL_MASK));
 #pragma unroll
       for (int k = 0; k < Q; k++) nx[k] = src[k];
     } else {
       v = sorted_vals[e];
-      p = bases[v & 0x7FFFFFFFu];
+      p = bases[v & ARK_TBL_MASK];
     }
     if (key != cur_key) {
       msm_flush_run<F>(cur_key, acc, first_run, run_start, e, seg, offsets, counts, buckets, head, head_key, tail,
@@ -387,7 +392,7 @@ msm_accumulate_g2l_kernel(const Affine<Fp2<P>>* __restrict__ bases, const uint32
   constexpr bool PF = ARK_G2L_PREFETCH != 0;
   uint4 nx[2 * Q];
   auto fetch = [&](uint32_t v) {
-    const Fq* b = reinterpret_cast<const Fq*>(bases + (v & 0x7FFFFFFFu));
+    const Fq* b = reinterpret_cast<const Fq*>(bases + (v & ARK_TBL_MASK));
     const uint4* sx = reinterpret_cast<const uint4*>(b + par);
     const uint4* sy = reinterpret_cast<const uint4*>(b + 2 + par);
 #pragma unroll
