@@ -53,15 +53,41 @@ struct Fp {
   ARK_HD bool operator!=(const Fp& o) const { return !(*this == o); }
 
   // r = a - p if a >= p else a   (a < 2p)
+  // Carry chains.  hipcc (clang) lowers __builtin_addc/__builtin_subc to v_add_co/v_addc_co/v_subb_co chains -- one
+  // VALU instruction per limb; the portable 64-bit formulation compiles to ~6 instructions per limb on gfx950
+  // (v_lshl_add_u64 + sign-extension moves; round-1 ISA listing: 13% of the bucket kernel).  g++ (the emulator
+  // build of the test tier) takes the portable path; both produce identical values.
+#if defined(__clang__)
+  ARK_HD static uint32_t adc(uint32_t a, uint32_t b, uint32_t& carry) {
+    unsigned c;
+    uint32_t r = __builtin_addc(a, b, carry, &c);
+    carry = c;
+    return r;
+  }
+  ARK_HD static uint32_t sbb(uint32_t a, uint32_t b, uint32_t& borrow) {
+    unsigned c;
+    uint32_t r = __builtin_subc(a, b, borrow, &c);
+    borrow = c;
+    return r;
+  }
+#else
+  ARK_HD static uint32_t adc(uint32_t a, uint32_t b, uint32_t& carry) {
+    uint64_t t = (uint64_t)a + b + carry;
+    carry = (uint32_t)(t >> 32);
+    return (uint32_t)t;
+  }
+  ARK_HD static uint32_t sbb(uint32_t a, uint32_t b, uint32_t& borrow) {
+    uint64_t t = (uint64_t)a - b - borrow;
+    borrow = (uint32_t)(t >> 32) & 1u;
+    return (uint32_t)t;
+  }
+#endif
+
   ARK_HD static Fp reduce_once(const Fp& a, uint32_t top) {
     Fp d;
-    uint64_t br = 0;
+    uint32_t br = 0;
 #pragma unroll
-    for (int i = 0; i < N; i++) {
-      uint64_t t = (uint64_t)a.l[i] - P::mod(i) - br;
-      d.l[i] = (uint32_t)t;
-      br = (t >> 32) & 1;
-    }
+    for (int i = 0; i < N; i++) d.l[i] = sbb(a.l[i], P::mod(i), br);
     // a >= p  <=>  no final borrow, or the (N+1)-th limb `top` absorbs it
     bool ge = (top != 0) || (br == 0);
     Fp r;
@@ -72,47 +98,31 @@ struct Fp {
 
   ARK_HD static Fp add(const Fp& a, const Fp& b) {
     Fp s;
-    uint64_t c = 0;
+    uint32_t c = 0;
 #pragma unroll
-    for (int i = 0; i < N; i++) {
-      c += (uint64_t)a.l[i] + b.l[i];
-      s.l[i] = (uint32_t)c;
-      c >>= 32;
-    }
-    return reduce_once(s, (uint32_t)c);
+    for (int i = 0; i < N; i++) s.l[i] = adc(a.l[i], b.l[i], c);
+    return reduce_once(s, c);
   }
 
   ARK_HD static Fp sub(const Fp& a, const Fp& b) {
     Fp d;
-    uint64_t br = 0;
+    uint32_t br = 0;
 #pragma unroll
-    for (int i = 0; i < N; i++) {
-      uint64_t t = (uint64_t)a.l[i] - b.l[i] - br;
-      d.l[i] = (uint32_t)t;
-      br = (t >> 32) & 1;
-    }
-    uint32_t mask = (uint32_t)0 - (uint32_t)br;
-    uint64_t c = 0;
+    for (int i = 0; i < N; i++) d.l[i] = sbb(a.l[i], b.l[i], br);
+    uint32_t mask = (uint32_t)0 - br;
+    uint32_t c = 0;
     Fp r;
 #pragma unroll
-    for (int i = 0; i < N; i++) {
-      c += (uint64_t)d.l[i] + (P::mod(i) & mask);
-      r.l[i] = (uint32_t)c;
-      c >>= 32;
-    }
+    for (int i = 0; i < N; i++) r.l[i] = adc(d.l[i], P::mod(i) & mask, c);
     return r;
   }
 
   ARK_HD static Fp neg(const Fp& a) {
     if (a.is_zero()) return a;
     Fp r;
-    uint64_t br = 0;
+    uint32_t br = 0;
 #pragma unroll
-    for (int i = 0; i < N; i++) {
-      uint64_t t = (uint64_t)P::mod(i) - a.l[i] - br;
-      r.l[i] = (uint32_t)t;
-      br = (t >> 32) & 1;
-    }
+    for (int i = 0; i < N; i++) r.l[i] = sbb(P::mod(i), a.l[i], br);
     return r;
   }
 
@@ -181,44 +191,45 @@ struct Fp {
 #include "mont_asm_chunks.inc"
   // pairs i = I0 .. I0+CNT-1 of column K: a[i]*b[K-i] + m[i]*p[K-i], at most 6 pairs per asm statement (hipcc pads
   // every asm statement whose result feeds the next instruction with an s_nop: fewer statements, fewer bubbles)
-  template <int CNT, int I0, int K>
+  template <int CNT, int I0, int K, bool FIRST = false>
   ARK_D static void col_pairs(uint64_t& acc, uint32_t& top, const Fp& a, const Fp& b, const uint32_t* m) {
 #define ARK_PAIR(j) a.l[I0 + j], b.l[K - I0 - j], m[I0 + j], P::mod(K - I0 - j)
+#define ARK_CH(n, ...) do { if constexpr (FIRST) macc_chunk##n##_f(acc, top, __VA_ARGS__); else macc_chunk##n(acc, top, __VA_ARGS__); } while (0)
     if constexpr (CNT >= 6) {
-      macc_chunk6(acc, top, ARK_PAIR(0), ARK_PAIR(1), ARK_PAIR(2), ARK_PAIR(3), ARK_PAIR(4), ARK_PAIR(5));
-      col_pairs<CNT - 6, I0 + 6, K>(acc, top, a, b, m);
+      ARK_CH(6, ARK_PAIR(0), ARK_PAIR(1), ARK_PAIR(2), ARK_PAIR(3), ARK_PAIR(4), ARK_PAIR(5));
+      col_pairs<CNT - 6, I0 + 6, K, false>(acc, top, a, b, m);
     } else if constexpr (CNT == 5) {
-      macc_chunk5(acc, top, ARK_PAIR(0), ARK_PAIR(1), ARK_PAIR(2), ARK_PAIR(3), ARK_PAIR(4));
+      ARK_CH(5, ARK_PAIR(0), ARK_PAIR(1), ARK_PAIR(2), ARK_PAIR(3), ARK_PAIR(4));
     } else if constexpr (CNT == 4) {
-      macc_chunk4(acc, top, ARK_PAIR(0), ARK_PAIR(1), ARK_PAIR(2), ARK_PAIR(3));
+      ARK_CH(4, ARK_PAIR(0), ARK_PAIR(1), ARK_PAIR(2), ARK_PAIR(3));
     } else if constexpr (CNT == 3) {
-      macc_chunk3(acc, top, ARK_PAIR(0), ARK_PAIR(1), ARK_PAIR(2));
+      ARK_CH(3, ARK_PAIR(0), ARK_PAIR(1), ARK_PAIR(2));
     } else if constexpr (CNT == 2) {
-      macc_chunk2(acc, top, ARK_PAIR(0), ARK_PAIR(1));
+      ARK_CH(2, ARK_PAIR(0), ARK_PAIR(1));
     } else if constexpr (CNT == 1) {
-      macc_chunk1(acc, top, ARK_PAIR(0));
+      ARK_CH(1, ARK_PAIR(0));
     }
+#undef ARK_CH
 #undef ARK_PAIR
   }
   template <int K>
   ARK_D static void mul_col_lo(uint64_t& acc, uint32_t& top, const Fp& a, const Fp& b, uint32_t* m, Fp& r) {
     if constexpr (K < N) {
-      col_pairs<K, 0, K>(acc, top, a, b, m);
+      if constexpr (K == 0) top = 0;
+      col_pairs<K, 0, K, true>(acc, top, a, b, m);            // starts the column: writes `top`
       macc_vv(acc, top, a.l[K], b.l[0]);
       m[K] = (uint32_t)acc * P::INV;
       macc_vs(acc, top, m[K], P::mod(0));
       acc = (acc >> 32) | ((uint64_t)top << 32);
-      top = 0;
       mul_col_lo<K + 1>(acc, top, a, b, m, r);
     }
   }
   template <int K>
   ARK_D static void mul_col_hi(uint64_t& acc, uint32_t& top, const Fp& a, const Fp& b, const uint32_t* m, Fp& r) {
     if constexpr (K < 2 * N - 1) {
-      col_pairs<2 * N - 1 - K, K - N + 1, K>(acc, top, a, b, m);
+      col_pairs<2 * N - 1 - K, K - N + 1, K, true>(acc, top, a, b, m);
       r.l[K - N] = (uint32_t)acc;
       acc = (acc >> 32) | ((uint64_t)top << 32);
-      top = 0;
       mul_col_hi<K + 1>(acc, top, a, b, m, r);
     }
   }
@@ -244,54 +255,57 @@ struct Fp {
   }
   // dual-product pairs i = I0 .. I0+CNT-1 of column K (x1[i]*y1[K-i] + x2[i]*y2[K-i]) and the reduction products
   // m[i]*p[K-i], chunked like col_pairs
-  template <int CNT, int I0, int K>
+  template <int CNT, int I0, int K, bool FIRST = false>
   ARK_D static void col_dual(uint64_t& acc, uint32_t& top, const Fp& x1, const Fp& y1, const Fp& x2, const Fp& y2) {
 #define ARK_D4(j) x1.l[I0 + j], y1.l[K - I0 - j], x2.l[I0 + j], y2.l[K - I0 - j]
+#define ARK_CH(n, ...) do { if constexpr (FIRST) macc_dchunk##n##_f(acc, top, __VA_ARGS__); else macc_dchunk##n(acc, top, __VA_ARGS__); } while (0)
     if constexpr (CNT >= 6) {
-      macc_dchunk6(acc, top, ARK_D4(0), ARK_D4(1), ARK_D4(2), ARK_D4(3), ARK_D4(4), ARK_D4(5));
-      col_dual<CNT - 6, I0 + 6, K>(acc, top, x1, y1, x2, y2);
+      ARK_CH(6, ARK_D4(0), ARK_D4(1), ARK_D4(2), ARK_D4(3), ARK_D4(4), ARK_D4(5));
+      col_dual<CNT - 6, I0 + 6, K, false>(acc, top, x1, y1, x2, y2);
     } else if constexpr (CNT == 5) {
-      macc_dchunk5(acc, top, ARK_D4(0), ARK_D4(1), ARK_D4(2), ARK_D4(3), ARK_D4(4));
+      ARK_CH(5, ARK_D4(0), ARK_D4(1), ARK_D4(2), ARK_D4(3), ARK_D4(4));
     } else if constexpr (CNT == 4) {
-      macc_dchunk4(acc, top, ARK_D4(0), ARK_D4(1), ARK_D4(2), ARK_D4(3));
+      ARK_CH(4, ARK_D4(0), ARK_D4(1), ARK_D4(2), ARK_D4(3));
     } else if constexpr (CNT == 3) {
-      macc_dchunk3(acc, top, ARK_D4(0), ARK_D4(1), ARK_D4(2));
+      ARK_CH(3, ARK_D4(0), ARK_D4(1), ARK_D4(2));
     } else if constexpr (CNT == 2) {
-      macc_dchunk2(acc, top, ARK_D4(0), ARK_D4(1));
+      ARK_CH(2, ARK_D4(0), ARK_D4(1));
     } else if constexpr (CNT == 1) {
-      macc_dchunk1(acc, top, ARK_D4(0));
+      ARK_CH(1, ARK_D4(0));
     }
+#undef ARK_CH
 #undef ARK_D4
   }
-  template <int CNT, int I0, int K>
+  template <int CNT, int I0, int K, bool FIRST = false>
   ARK_D static void col_red(uint64_t& acc, uint32_t& top, const uint32_t* m) {
 #define ARK_S2(j) m[I0 + j], P::mod(K - I0 - j)
+#define ARK_CH(n, ...) do { if constexpr (FIRST) macc_schunk##n##_f(acc, top, __VA_ARGS__); else macc_schunk##n(acc, top, __VA_ARGS__); } while (0)
     if constexpr (CNT >= 6) {
-      macc_schunk6(acc, top, ARK_S2(0), ARK_S2(1), ARK_S2(2), ARK_S2(3), ARK_S2(4), ARK_S2(5));
-      col_red<CNT - 6, I0 + 6, K>(acc, top, m);
+      ARK_CH(6, ARK_S2(0), ARK_S2(1), ARK_S2(2), ARK_S2(3), ARK_S2(4), ARK_S2(5));
+      col_red<CNT - 6, I0 + 6, K, false>(acc, top, m);
     } else if constexpr (CNT == 5) {
-      macc_schunk5(acc, top, ARK_S2(0), ARK_S2(1), ARK_S2(2), ARK_S2(3), ARK_S2(4));
+      ARK_CH(5, ARK_S2(0), ARK_S2(1), ARK_S2(2), ARK_S2(3), ARK_S2(4));
     } else if constexpr (CNT == 4) {
-      macc_schunk4(acc, top, ARK_S2(0), ARK_S2(1), ARK_S2(2), ARK_S2(3));
+      ARK_CH(4, ARK_S2(0), ARK_S2(1), ARK_S2(2), ARK_S2(3));
     } else if constexpr (CNT == 3) {
-      macc_schunk3(acc, top, ARK_S2(0), ARK_S2(1), ARK_S2(2));
+      ARK_CH(3, ARK_S2(0), ARK_S2(1), ARK_S2(2));
     } else if constexpr (CNT == 2) {
-      macc_schunk2(acc, top, ARK_S2(0), ARK_S2(1));
+      ARK_CH(2, ARK_S2(0), ARK_S2(1));
     } else if constexpr (CNT == 1) {
-      macc_schunk1(acc, top, ARK_S2(0));
+      ARK_CH(1, ARK_S2(0));
     }
+#undef ARK_CH
 #undef ARK_S2
   }
   template <int K>
   ARK_D static void m2_col_lo(uint64_t& acc, uint32_t& top, const Fp& x1, const Fp& y1, const Fp& x2, const Fp& y2,
                               uint32_t* m) {
     if constexpr (K < N) {
-      col_dual<K + 1, 0, K>(acc, top, x1, y1, x2, y2);
+      col_dual<K + 1, 0, K, true>(acc, top, x1, y1, x2, y2);
       col_red<K, 0, K>(acc, top, m);
       m[K] = (uint32_t)acc * P::INV;
       macc_vs(acc, top, m[K], P::mod(0));
       acc = (acc >> 32) | ((uint64_t)top << 32);
-      top = 0;
       m2_col_lo<K + 1>(acc, top, x1, y1, x2, y2, m);
     }
   }
@@ -299,11 +313,10 @@ struct Fp {
   ARK_D static void m2_col_hi(uint64_t& acc, uint32_t& top, const Fp& x1, const Fp& y1, const Fp& x2, const Fp& y2,
                               const uint32_t* m, Fp& r) {
     if constexpr (K < 2 * N - 1) {
-      col_dual<2 * N - 1 - K, K - N + 1, K>(acc, top, x1, y1, x2, y2);
+      col_dual<2 * N - 1 - K, K - N + 1, K, true>(acc, top, x1, y1, x2, y2);
       col_red<2 * N - 1 - K, K - N + 1, K>(acc, top, m);
       r.l[K - N] = (uint32_t)acc;
       acc = (acc >> 32) | ((uint64_t)top << 32);
-      top = 0;
       m2_col_hi<K + 1>(acc, top, x1, y1, x2, y2, m, r);
     }
   }
@@ -325,13 +338,12 @@ struct Fp {
   ARK_D static void m4_col_lo(uint64_t& acc, uint32_t& top, const Fp& x1, const Fp& y1, const Fp& x2, const Fp& y2,
                               const Fp& x3, const Fp& y3, const Fp& x4, const Fp& y4, uint32_t* m) {
     if constexpr (K < N) {
-      col_dual<K + 1, 0, K>(acc, top, x1, y1, x2, y2);
+      col_dual<K + 1, 0, K, true>(acc, top, x1, y1, x2, y2);
       col_dual<K + 1, 0, K>(acc, top, x3, y3, x4, y4);
       col_red<K, 0, K>(acc, top, m);
       m[K] = (uint32_t)acc * P::INV;
       macc_vs(acc, top, m[K], P::mod(0));
       acc = (acc >> 32) | ((uint64_t)top << 32);
-      top = 0;
       m4_col_lo<K + 1>(acc, top, x1, y1, x2, y2, x3, y3, x4, y4, m);
     }
   }
@@ -339,12 +351,11 @@ struct Fp {
   ARK_D static void m4_col_hi(uint64_t& acc, uint32_t& top, const Fp& x1, const Fp& y1, const Fp& x2, const Fp& y2,
                               const Fp& x3, const Fp& y3, const Fp& x4, const Fp& y4, const uint32_t* m, Fp& r) {
     if constexpr (K < 2 * N - 1) {
-      col_dual<2 * N - 1 - K, K - N + 1, K>(acc, top, x1, y1, x2, y2);
+      col_dual<2 * N - 1 - K, K - N + 1, K, true>(acc, top, x1, y1, x2, y2);
       col_dual<2 * N - 1 - K, K - N + 1, K>(acc, top, x3, y3, x4, y4);
       col_red<2 * N - 1 - K, K - N + 1, K>(acc, top, m);
       r.l[K - N] = (uint32_t)acc;
       acc = (acc >> 32) | ((uint64_t)top << 32);
-      top = 0;
       m4_col_hi<K + 1>(acc, top, x1, y1, x2, y2, x3, y3, x4, y4, m, r);
     }
   }
@@ -532,7 +543,10 @@ struct Fp2L {
     return Fp2L{Base::mul(u, v)};
   }
   // a*b - c*d: four products, one reduction per lane
-  static constexpr bool FUSED_MUL_SUB = true;
+#ifndef ARK_G2L_FUSE_Y3
+#define ARK_G2L_FUSE_Y3 1
+#endif
+  static constexpr bool FUSED_MUL_SUB = ARK_G2L_FUSE_Y3 != 0;
   ARK_D static Fp2L mul_sub(const Fp2L& a, const Fp2L& b, const Fp2L& c, const Fp2L& d) {
     const bool odd = parity() != 0;
     const Base pa = xchg(a.c), pb = xchg(b.c), pc = xchg(c.c), pd = xchg(d.c);
