@@ -301,21 +301,26 @@ static void prove_run(ark355_ctx* ctx, ProverScratch& sc, const PkDev& pk, const
       const MsmSort* sort;
       MsmBuckets* bk;
       bool g2;
-      const void* table;
+      const PrecompTable* tab;
       int res;
     } jobs[5] = {
-        {E_SORT0, &sc.sortZ, &sc.bkA, false, pk.a_ext.table.p, 0},
-        {E_SORT0, &sc.sortZ, &sc.bkB1, false, pk.b1_ext.table.p, 1},
-        {E_SORT0, &sc.sortZ, &sc.bkB2, true, pk.b2_ext.table.p, 0},
-        {E_SORT0, &sc.sortZ, &sc.bkL, false, pk.l_ext.table.p, 2},
-        {E_SORT2, &sc.sortH, &sc.bkH, false, pk.h_query.table.p, 3},
+        {E_SORT0, &sc.sortZ, &sc.bkA, false, &pk.a_ext, 0},
+        {E_SORT0, &sc.sortZ, &sc.bkB1, false, &pk.b1_ext, 1},
+        {E_SORT0, &sc.sortZ, &sc.bkB2, true, &pk.b2_ext, 0},
+        {E_SORT0, &sc.sortZ, &sc.bkL, false, &pk.l_ext, 2},
+        {E_SORT2, &sc.sortH, &sc.bkH, false, &pk.h_query, 3},
     };
     uint64_t pts = 0;
     for (int j = 0; j < 5; j++) {
       const Job& jb = jobs[j];
       ARK_CHECK_HIP(hipStreamWaitEvent(sA, ev[jb.sort_ev], 0));
-      if (jb.g2) msm_accumulate_phase<Fq2>(ctx, *jb.sort, *jb.bk, (const Affine<Fq2>*)jb.table, sA, acc0[j], acc1[j]);
-      else msm_accumulate_phase<Fq>(ctx, *jb.sort, *jb.bk, (const Affine<Fq>*)jb.table, sA, acc0[j], acc1[j]);
+      if (jb.g2) {
+        msm_accumulate_phase<Fq2>(ctx, *jb.sort, *jb.bk, jb.tab->table.template as<Affine<Fq2>>(), sA, acc0[j], acc1[j],
+                                  jb.tab->limb28);
+      } else {
+        msm_accumulate_phase<Fq>(ctx, *jb.sort, *jb.bk, jb.tab->table.template as<Affine<Fq>>(), sA, acc0[j], acc1[j],
+                                 jb.tab->limb28);
+      }
       ARK_CHECK_HIP(hipEventRecord(ev[E_ACC_DONE0 + j], sA));
       ARK_CHECK_HIP(hipStreamWaitEvent(sR, ev[E_ACC_DONE0 + j], 0));
       if (jb.g2) msm_reduce_phase<Fq2>(ctx, *jb.sort, *jb.bk, g2res, 0, sR);

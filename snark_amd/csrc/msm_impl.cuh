@@ -253,6 +253,10 @@ ARK_D void msm_flush_run(uint32_t key, const XYZZ<F>& acc, bool first_run, uint3
   }
 }
 
+}  // namespace ark355
+#include "msm28_impl.cuh"
+namespace ark355 {
+
 template <class F, bool NI>
 __global__ void __launch_bounds__(MSM_THREADS)
 msm_accumulate_kernel(const Affine<F>* __restrict__ bases, const uint32_t* __restrict__ sorted_keys,
@@ -678,9 +682,22 @@ batch_to_affine_kernel(const XYZZ<F>* __restrict__ in, Affine<F>* __restrict__ o
 // Window tables of a base vector: T[w*n + i] = 2^(c*w) * P_i, affine, for the plan the MSM of this length uses.
 struct PrecompTable {
   MsmPlan plan;
-  DevBuf table;
+  DevBuf table;          // windows * n rows: Affine<F>, or Affine28 rows when limb28 is set
   uint64_t n = 0;
+  bool limb28 = false;   // G1 tables are stored in the radix-2^28 form of field28.cuh (msm28_impl.cuh)
 };
+
+#ifndef ARK_LIMB28_DEFAULT
+#define ARK_LIMB28_DEFAULT 1
+#endif
+// ARK355_LIMB28=0|1: keep G1 window tables in the 32-bit form (A/B switch for the 28-bit accumulation kernel)
+static inline bool msm_use_limb28() {
+  static const int v = [] {
+    const char* e = getenv("ARK355_LIMB28");
+    return e ? (e[0] == '1') : ARK_LIMB28_DEFAULT;
+  }();
+  return v != 0;
+}
 
 template <class F, class Fr>
 static void precomp_build(PrecompTable& t, const void* d_bases, uint64_t n, hipStream_t stream) {
@@ -704,6 +721,20 @@ static void precomp_build(PrecompTable& t, const void* d_bases, uint64_t n, hipS
     ARK_CHECK_LAUNCH();
   }
   ARK_CHECK_HIP(hipStreamSynchronize(stream));     // tmp is freed on return
+  if constexpr (!is_fp2<F>::value) {
+    if (msm_use_limb28()) {
+      // re-encode the finished table for the 28-bit accumulation kernel; the 32-bit rows are dropped
+      using P = typename F::Params;
+      const uint64_t rows = (uint64_t)p.windows * n;
+      DevBuf t28(rows * sizeof(Affine28<P>));
+      ARK_LAUNCH((table_to28_kernel<P>), dim3((uint32_t)((rows + 255) / 256)), dim3(256), 0, stream,
+                 (const Affine<F>*)T, t28.as<Affine28<P>>(), rows);
+      ARK_CHECK_LAUNCH();
+      ARK_CHECK_HIP(hipStreamSynchronize(stream));
+      t.table = std::move(t28);
+      t.limb28 = true;
+    }
+  }
 }
 
 // ---- host driver ---------------------------------------------------------------------------------------------
@@ -766,7 +797,8 @@ struct MsmBuckets {
 // Phase 1 of the bucket method over an existing sort: bucket accumulation (the chip-filling kernel).
 template <class F>
 static void msm_accumulate_phase(ark355_ctx* ctx, const MsmSort& s, MsmBuckets& b, const Affine<F>* d_bases,
-                                 hipStream_t stream, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr) {
+                                 hipStream_t stream, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr,
+                                 bool bases28 = false) {
   const MsmPlan& p = s.plan;
   if (p.n == 0) return;
   const uint32_t segs = s.max_segments;
@@ -813,6 +845,13 @@ static void msm_accumulate_phase(ark355_ctx* ctx, const MsmSort& s, MsmBuckets& 
     } else {
       launch(std::true_type{});
     }
+  } else if (bases28) {
+    using P = typename F::Params;
+    ARK_LAUNCH((msm_accumulate28_kernel<P>), dim3(grid_s), dim3(MSM_THREADS), 0, stream,
+               reinterpret_cast<const Affine28<P>*>(d_bases), s.sorted_keys.as<uint32_t>(),
+               s.sorted_vals.as<uint32_t>(), s.total.as<uint32_t>(), s.offsets.as<uint32_t>(),
+               s.counts.as<uint32_t>(), b.buckets.as<XYZZ<F>>(), b.head.as<XYZZ<F>>(), b.head_key.as<uint32_t>(),
+               b.tail.as<XYZZ<F>>(), b.tail_key.as<uint32_t>(), p.seg_log);
   } else {
     launch(std::false_type{});
   }
@@ -864,8 +903,9 @@ static void msm_reduce_phase(ark355_ctx* ctx, const MsmSort& s, MsmBuckets& b, X
 // Both phases on one stream.
 template <class F>
 static void msm_buckets(ark355_ctx* ctx, const MsmSort& s, MsmBuckets& b, const Affine<F>* d_bases, XYZZ<F>* d_out,
-                        int accumulate, hipStream_t stream, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr) {
-  msm_accumulate_phase<F>(ctx, s, b, d_bases, stream, ev0, ev1);
+                        int accumulate, hipStream_t stream, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr,
+                        bool bases28 = false) {
+  msm_accumulate_phase<F>(ctx, s, b, d_bases, stream, ev0, ev1, bases28);
   msm_reduce_phase<F>(ctx, s, b, d_out, accumulate, stream);
 }
 

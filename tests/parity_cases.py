@@ -61,6 +61,44 @@ def msm_case(lib, ctx, C, group, n, seed=3, edge=True):
     assert fromraw(C, out) == G_.msm(pts, ks), (C.name, group, n)
 
 
+def resident_msm_edge_case(lib, ctx, C, group, n, to_dev, seed=11):
+    """Resident bases (ark355_bases_load: per-window tables; G1 tables live in the radix-2^28 form) + msm_dev with
+    the exceptional cases of the mixed addition INSIDE buckets: P + P, P + (-P), bases at infinity, runs of equal
+    points, zero / one / r-1 scalars.  `to_dev(bytes) -> (ptr, keepalive)` places the scalars where the library
+    expects device memory."""
+    rnd = random.Random(seed * 7919 + n + group)
+    G_ = g1(C) if group == 1 else g2(C)
+    raw = Z.g1_raw if group == 1 else Z.g2_raw
+    fromraw = Z.g1_from_raw if group == 1 else Z.g2_from_raw
+    sz = lib.sizes(C.curve_id)
+    psz = sz["g1"] if group == 1 else sz["g2"]
+    ks = [rnd.randrange(C.r) for _ in range(n)]
+    pts = G_.fixed_base_muls(G_.gen, [rnd.randrange(C.r) for _ in range(n)])
+    assert n >= 24
+    ks[0], ks[1], ks[2] = 0, 1, C.r - 1
+    pts[3] = None                                       # base at infinity
+    pts[4], ks[4] = pts[5], ks[5]                       # P + P in every window
+    pts[6], ks[6] = G_.neg(pts[7]), ks[7]               # P + (-P) in every window
+    for j in range(8, 13):                              # five copies: double, then keep adding the same point
+        pts[j], ks[j] = pts[13], ks[13]
+    pts[14], ks[14] = pts[15], (C.r - ks[15]) % C.r     # k P + (-k) P: negated digits meet the same table rows
+    for j in range(16, 20):                             # small scalars: everything lands in window 0
+        ks[j] = j - 15
+    pts[17] = pts[16]                                   # 1*P + 2*P: different buckets, same point
+    pts[19], ks[19] = pts[18], ks[18]                   # and a doubling inside the sparse window
+    h = lib.bases_load(ctx, C.curve_id, group, b"".join(raw(C, p) for p in pts), n)
+    try:
+        ptr, keep = to_dev(b"".join(Z.fr_canon(C, k) for k in ks))
+        out = lib.msm_dev(ctx, h, ptr, n, 0, psz)
+        assert fromraw(C, out) == G_.msm(pts, ks), (C.name, group, n)
+        # a prefix whose sum is exactly the point at infinity: P5 k + P5 k ... cancel? use the (6,7) pair alone
+        ptr2, keep2 = to_dev(b"".join(Z.fr_canon(C, k) for k in [0] * 6 + ks[6:8]))
+        out2 = lib.msm_dev(ctx, h, ptr2, 8, 0, psz)
+        assert fromraw(C, out2) is None
+    finally:
+        lib.dll.ark355_bases_free(h)
+
+
 def msm_known_dlog_case(lib, ctx, C, group, n, seed=4, skew=None):
     """Any size: bases s_i*G made on the device (ark355_fixed_base_mul), so MSM == (sum k_i s_i) * G."""
     rnd = random.Random(seed + n)

@@ -29,6 +29,16 @@ def test_msm_vs_naive(emul_lib, emul_ctx, C, group, n):
     pc.msm_case(emul_lib, emul_ctx, C, group, n)
 
 
+@pytest.mark.parametrize("C,group", [(BLS12_381, 1), (BN254, 1), (BLS12_381, 2)], ids=lambda v: getattr(v, "name", str(v)))
+def test_resident_tables_exceptional_additions(emul_lib, emul_ctx, C, group):
+    import numpy as np
+
+    def to_dev(b):      # emulator: "device" pointers are host pointers
+        a = np.frombuffer(b, dtype=np.uint8).copy()
+        return a.ctypes.data, a
+    pc.resident_msm_edge_case(emul_lib, emul_ctx, C, group, 24, to_dev)
+
+
 @pytest.mark.parametrize("skew", ["equal", "boolean"])
 def test_msm_skewed_scalars(emul_lib, emul_ctx, skew):
     # all-equal scalars: every term of a window lands in ONE bucket (long straddling runs);

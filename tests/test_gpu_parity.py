@@ -49,6 +49,20 @@ def test_msm_vs_naive(gpu_lib, gpu_ctx, C, group, n):
     pc.msm_case(gpu_lib, gpu_ctx, C, group, n)
 
 
+@pytest.mark.parametrize("C", CURVES, ids=lambda c: c.name)
+@pytest.mark.parametrize("group,n", [(1, 24), (1, 700), (2, 24), (2, 130)])
+def test_resident_tables_exceptional_additions(gpu_lib, gpu_ctx, C, group, n):
+    """bases_load + msm_dev: the radix-2^28 (G1) / lane-split (G2) bucket kernels over window tables, with
+    P + P, P + (-P), infinity and repeated points inside buckets."""
+    import numpy as np
+    import torch
+
+    def to_dev(b):
+        t = torch.from_numpy(np.frombuffer(b, dtype=np.uint8).copy()).cuda()
+        return t.data_ptr(), t
+    pc.resident_msm_edge_case(gpu_lib, gpu_ctx, C, group, n, to_dev)
+
+
 @pytest.mark.parametrize("C,group,n,skew", [
     (BLS12_381, 1, 1 << 14, None), (BLS12_381, 1, 1 << 14, "equal"), (BLS12_381, 1, 1 << 14, "boolean"),
     (BLS12_381, 2, 1 << 12, None), (BN254, 1, 1 << 14, None), (BN254, 2, 1 << 12, "boolean"),

@@ -3,6 +3,7 @@
 #include <stdio.h>
 #include <stdint.h>
 #include "../snark_amd/csrc/curve.cuh"
+#include "../snark_amd/csrc/field28.cuh"
 using namespace ark355;
 
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
@@ -36,6 +37,14 @@ __global__ void __launch_bounds__(256) k_fmul(F* out, const F* in, int iters) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   F a = in[t & 1023], b = in[(t + 1) & 1023];
   for (int it = 0; it < iters; it++) { a = fmul<NI>(a, b); b = F::add(b, a); }
+  out[t] = a;
+}
+
+template <class F>
+__global__ void __launch_bounds__(256) k_fmul28(F* out, const F* in, int iters) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  F a = in[t & 1023], b = in[(t + 1) & 1023];
+  for (int it = 0; it < iters; it++) { a = F::mul(a, b); b = F::norm(F::add(b, a)); }
   out[t] = a;
 }
 
@@ -114,6 +123,7 @@ static float time_it(void (*launch)(void*), void* ctx, int reps) {
 struct Ctx { void* out; void* in; int iters; int blocks; };
 template <int OP> static void l_ops(void* c) { Ctx* x = (Ctx*)c; hipLaunchKernelGGL(k_ops<OP>, dim3(x->blocks), dim3(256), 0, 0, (uint32_t*)x->out, 12345u, 6789u, x->iters); }
 template <class F, bool NI> static void l_fmul(void* c) { Ctx* x = (Ctx*)c; hipLaunchKernelGGL((k_fmul<F, NI>), dim3(x->blocks), dim3(256), 0, 0, (F*)x->out, (const F*)x->in, x->iters); }
+template <class F> static void l_fmul28(void* c) { Ctx* x = (Ctx*)c; hipLaunchKernelGGL((k_fmul28<F>), dim3(x->blocks), dim3(256), 0, 0, (F*)x->out, (const F*)x->in, x->iters); }
 template <class F, bool NI> static void l_madd(void* c) { Ctx* x = (Ctx*)c; hipLaunchKernelGGL((k_madd<F, NI>), dim3(x->blocks), dim3(256), 0, 0, (XYZZ<F>*)x->out, (const Affine<F>*)x->in, x->iters); }
 
 template <class P> static void l_madd_g2l(void* c) { Ctx* x = (Ctx*)c; hipLaunchKernelGGL((k_madd_g2l<P>), dim3(x->blocks), dim3(256), 0, 0, (XYZZ<Fp2<P>>*)x->out, (const Affine<Fp2<P>>*)x->in, x->iters); }
@@ -140,6 +150,7 @@ int main() {
   struct { const char* n; void (*l)(void*); double muls; } fm[] = {
     {"BlsFq mul inline", l_fmul<BlsFq, false>, 1}, {"BlsFq mul noinline", l_fmul<BlsFq, true>, 1},
     {"BlsFr mul inline", l_fmul<BlsFr, false>, 1}, {"BnFq mul inline", l_fmul<BnFq, false>, 1},
+    {"BlsFq 28-bit limbs", l_fmul28<BlsFq28>, 1}, {"BnFq 28-bit limbs", l_fmul28<BnFq28>, 1},
     {"BlsFq2 mul inline", l_fmul<BlsFq2, false>, 1}, {"BlsFq2 mul noinline", l_fmul<BlsFq2, true>, 1}};
   for (auto& f : fm) {
     float ms = time_it(f.l, &c, 3);
