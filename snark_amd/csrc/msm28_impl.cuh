@@ -55,22 +55,19 @@ ARK_HD_NOINLINE int madd28_classify(Fp28<P> pd, Fp28<P> r) {
   if (!Fp28<P>::is_zero_mod_p(pd)) return 0;
   return Fp28<P>::is_zero_mod_p(r) ? 1 : 2;
 }
-// 2 * (px, py) through the canonical 32-bit formulas
+// One coordinate (0: x, 1: y, 2: zz, 3: zzz) of 2 * (px, py), through the canonical 32-bit formulas.  Cold path;
+// called once per coordinate so that arguments and result travel in registers: a by-value / sret Acc28 made hipcc
+// keep the hot loop's accumulator in scratch memory (round-1 ISA listing: ~90 scratch accesses per mixed addition).
 template <class P>
-ARK_HD_NOINLINE Acc28<P> dbl28_affine_ni(Fp28<P> px, Fp28<P> py) {
+ARK_HD_NOINLINE Fp28<P> dbl28_coord_ni(Fp28<P> px, Fp28<P> py, int which) {
   using F = Fp28<P>;
   const Affine<Fp<P>> a{F::to_fp(px), F::to_fp(py)};
   const XYZZ<Fp<P>> d = xyzz_dbl_affine_t<true>(a);
-  return Acc28<P>{F::from_fp(d.x), F::from_fp(d.y), F::from_fp(d.zz), F::from_fp(d.zzz)};
+  return F::from_fp(which == 0 ? d.x : which == 1 ? d.y : which == 2 ? d.zz : d.zzz);
 }
 template <class P>
 ARK_HD_NOINLINE Fp28<P> one28_ni() {
   return Fp28<P>::from_fp(Fp<P>::one());
-}
-template <class P>
-ARK_HD_NOINLINE XYZZ<Fp<P>> acc28_to_xyzz_ni(Acc28<P> a) {
-  using F = Fp28<P>;
-  return XYZZ<Fp<P>>{F::to_fp(a.x), F::to_fp(a.y), F::to_fp(a.zz), F::to_fp(a.zzz)};
 }
 
 // acc += (px, +-py).  Value/limb classes (field28.cuh): table coordinates are canonical; acc.x is normalised and
@@ -107,7 +104,11 @@ ARK_D void madd28(Acc28<P>& acc, bool& empty, const Fp28<P>& px, const Fp28<P>& 
   if (Pd.multiple_hint() < 10u) {
     const int cls = madd28_classify<P>(Pd, R);
     if (cls == 1) {
-      acc = dbl28_affine_ni<P>(px, F::norm(pys));
+      const F yn = F::norm(pys);
+      acc.x = dbl28_coord_ni<P>(px, yn, 0);
+      acc.y = dbl28_coord_ni<P>(px, yn, 1);
+      acc.zz = dbl28_coord_ni<P>(px, yn, 2);
+      acc.zzz = dbl28_coord_ni<P>(px, yn, 3);
       if (acc.zz.limbs_all_zero()) empty = true;       // 2P = infinity (no such point on these curves)
       return;
     }
@@ -158,7 +159,13 @@ msm_accumulate28_kernel(const Affine28<P>* __restrict__ bases, const uint32_t* _
   acc.zz = F::zero();
   acc.zzz = F::zero();
   auto flush = [&](uint32_t key, uint32_t run_end) {
-    const XYZZ<Fq> out = empty ? XYZZ<Fq>::inf() : acc28_to_xyzz_ni<P>(acc);
+    XYZZ<Fq> out = XYZZ<Fq>::inf();
+    if (!empty) {
+      out.x = F::to_fp(acc.x);
+      out.y = F::to_fp(acc.y);
+      out.zz = F::to_fp(acc.zz);
+      out.zzz = F::to_fp(acc.zzz);
+    }
     msm_flush_run<Fq>(key, out, first_run, run_start, run_end, seg, offsets, counts, buckets, head, head_key, tail,
                       tail_key);
   };
@@ -208,6 +215,260 @@ msm_accumulate28_kernel(const Affine28<P>* __restrict__ bases, const uint32_t* _
     for (int k = 0; k < F::N; k++) any |= px.l[k] | py.l[k];
     if (any == 0) continue;                              // base at infinity
     madd28<P>(acc, empty, px, py, (v >> 31) != 0);
+  }
+  flush(cur_key, end);
+}
+
+
+// ================================================================================================================
+// G2: lane-split accumulation on 28-bit limbs.  Two lanes per segment (even: c0 components, odd: c1 components of
+// every Fq2 value, as in msm_accumulate_g2l_kernel); a table row is two Affine28 halves, {x.c0, y.c0} then
+// {x.c1, y.c1}, so that each lane gathers one aligned half.
+// OPT-IN (ARK355_G2_LIMB28=1): measured on MI355X it only ties with the 32-bit lane-split kernel (9.12 vs 9.11 ms
+// per 2^20-term MSM).  The multiply-add is the scarce instruction (5.5 cycles per wave) and the fused dual-product
+// pass needs 588 of them on 14 limbs against 444 on 12, which eats what the missing carry instructions save; the
+// G1 kernel, whose single-product passes go from 300 mad + 300 addc to 392 mad, gains 14%.
+// ================================================================================================================
+#ifndef ARK_G2L28_FUSE_Y3
+#define ARK_G2L28_FUSE_Y3 1
+#endif
+template <class P>
+struct Affine28G2 {
+  Affine28<P> half[2];
+};
+
+template <class P>
+__global__ void __launch_bounds__(256)
+table_to28_g2_kernel(const Affine<Fp2<P>>* __restrict__ src, Affine28G2<P>* __restrict__ dst, uint64_t rows) {
+  using F = Fp28<P>;
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows) return;
+  const Affine<Fp2<P>> a = src[i];
+  Affine28G2<P> o;
+#pragma unroll
+  for (int h = 0; h < 2; h++) {
+#pragma unroll
+    for (int k = 0; k < Affine28<P>::WORDS; k++) o.half[h].w[k] = 0;
+  }
+  if (!a.is_inf()) {
+    const F x0 = F::from_fp(a.x.c0), x1 = F::from_fp(a.x.c1), y0 = F::from_fp(a.y.c0), y1 = F::from_fp(a.y.c1);
+#pragma unroll
+    for (int k = 0; k < F::N; k++) {
+      o.half[0].w[k] = x0.l[k];
+      o.half[0].w[F::N + k] = y0.l[k];
+      o.half[1].w[k] = x1.l[k];
+      o.half[1].w[F::N + k] = y1.l[k];
+    }
+  }
+  dst[i] = o;
+}
+
+// Fq2 arithmetic of a lane pair on Fp28 components.  KA / BETA describe the PARTNER component of the first
+// operand (value < (KA-1) p, limbs <= BETA (2^28 - 1)): it is negated lazily on the even lane.
+template <class P>
+struct Pair28 {
+  using F = Fp28<P>;
+  static constexpr int N = F::N;
+  ARK_D static bool odd() { return (threadIdx.x & 1u) != 0; }
+  ARK_D static F xchg(const F& v) {
+    F r;
+#pragma unroll
+    for (int i = 0; i < N; i++) r.l[i] = ark_pair_xchg(v.l[i]);
+    return r;
+  }
+  ARK_D static bool both(bool b) { return b && (ark_pair_xchg(b ? 1u : 0u) != 0); }
+  ARK_D static F sel(bool c, const F& a, const F& b) {
+    F r;
+#pragma unroll
+    for (int i = 0; i < N; i++) r.l[i] = c ? a.l[i] : b.l[i];
+    return r;
+  }
+  //   even: a0 b0 + (-a1) b1          odd: a0 b1 + a1 b0
+  template <uint32_t KA, uint32_t BETA>
+  ARK_D static F mul(const F& a, const F& b) {
+    const F pa = xchg(a), pb = xchg(b);
+    const F npa = F::template neg<KA, BETA>(pa);
+    const bool o = odd();
+    return F::mul2sum(sel(o, pa, a), b, sel(o, a, npa), pb);
+  }
+  //   even: (a0 + a1)(a0 - a1)        odd: (2 a0) a1            (a normalised, components < (KA-1) p)
+  template <uint32_t KA>
+  ARK_D static F sqr(const F& a) {
+    const F pa = xchg(a);
+    const bool o = odd();
+    const F u = F::add(pa, sel(o, pa, a));
+    const F d = F::template sub<KA, 1>(a, pa);
+    return F::mul(u, sel(o, a, d));
+  }
+  // a b + c d, four products and one reduction per lane
+  template <uint32_t KA, uint32_t BA, uint32_t KC, uint32_t BC>
+  ARK_D static F mul2(const F& a, const F& b, const F& c, const F& d) {
+    const F pa = xchg(a), pb = xchg(b), pc = xchg(c), pd = xchg(d);
+    const F npa = F::template neg<KA, BA>(pa), npc = F::template neg<KC, BC>(pc);
+    const bool o = odd();
+    return F::mul4sum(sel(o, pa, a), b, sel(o, a, npa), pb, sel(o, pc, c), d, sel(o, c, npc), pd);
+  }
+};
+
+// One coordinate of 2 * (x, y) for the pair's point through the canonical Fq2 formulas (both lanes compute it, each
+// keeps its half); per coordinate for the same reason as dbl28_coord_ni.
+template <class P>
+ARK_HD_NOINLINE Fp28<P> dbl28_g2_coord_ni(Fp28<P> x_own, Fp28<P> x_other, Fp28<P> y_own, Fp28<P> y_other,
+                                          bool is_odd, int which) {
+  using F = Fp28<P>;
+  const Fp<P> xo = F::to_fp(x_own), xp = F::to_fp(x_other), yo = F::to_fp(y_own), yp = F::to_fp(y_other);
+  Affine<Fp2<P>> a;
+  a.x.c0 = is_odd ? xp : xo;
+  a.x.c1 = is_odd ? xo : xp;
+  a.y.c0 = is_odd ? yp : yo;
+  a.y.c1 = is_odd ? yo : yp;
+  const XYZZ<Fp2<P>> d = xyzz_dbl_affine_t<true>(a);
+  const Fp2<P> c = which == 0 ? d.x : which == 1 ? d.y : which == 2 ? d.zz : d.zzz;
+  return F::from_fp(is_odd ? c.c1 : c.c0);
+}
+
+// acc += (px, +-py) over Fq2, one component per lane.  Same formula and value classes as madd28; Pd, R and
+// T = Q - X3 are normalised before they enter a multi-product pass, which keeps every column below
+// 14 (2^56 + 2^57 + 2^57 + 2^58) + 14 2^56 < 2^63 (the emulator build traps on any column overflow).
+template <class P>
+ARK_D void madd28_g2(Acc28<P>& acc, bool& empty, const Fp28<P>& px, const Fp28<P>& py, bool negate) {
+  using F = Fp28<P>;
+  using L = Pair28<P>;
+  const F pys = L::sel(negate, F::template neg<2, 1>(py), py);
+  if (empty) {
+    const F one = L::odd() ? F::zero() : one28_ni<P>();
+    acc.x = px;
+    acc.y = F::norm(pys);
+    acc.zz = one;
+    acc.zzz = one;
+    empty = false;
+    return;
+  }
+  const F U2 = L::template mul<2, 1>(px, acc.zz);
+  const F S2 = L::template mul<3, 3>(pys, acc.zzz);          // pys limbs <= 2^29 - 1
+  const F Pd = F::norm(F::template sub<8, 1>(U2, acc.x));
+  const F R = F::norm(F::template sub<3, 1>(S2, acc.y));
+  if (L::both(Pd.multiple_hint() < 10u)) {
+    if (L::both(F::is_zero_mod_p(Pd))) {
+      if (L::both(F::is_zero_mod_p(R))) {
+        const F yn = F::norm(pys);
+        const F pxo = L::xchg(px), yno = L::xchg(yn);
+        acc.x = dbl28_g2_coord_ni<P>(px, pxo, yn, yno, L::odd(), 0);
+        acc.y = dbl28_g2_coord_ni<P>(px, pxo, yn, yno, L::odd(), 1);
+        acc.zz = dbl28_g2_coord_ni<P>(px, pxo, yn, yno, L::odd(), 2);
+        acc.zzz = dbl28_g2_coord_ni<P>(px, pxo, yn, yno, L::odd(), 3);
+        if (L::both(acc.zz.limbs_all_zero())) empty = true;
+      } else {
+        empty = true;
+      }
+      return;
+    }
+  }
+  const F PP = L::template sqr<11>(Pd);
+  const F PPP = L::template mul<11, 1>(Pd, PP);
+  const F Q = L::template mul<8, 1>(acc.x, PP);
+  acc.zz = L::template mul<3, 1>(acc.zz, PP);
+  acc.zzz = L::template mul<3, 1>(acc.zzz, PPP);
+  const F W = F::add(PPP, F::add(Q, Q));
+  const F X3 = F::norm(F::add(L::template sqr<6>(R), F::template neg<5, 4>(W)));
+  const F T = F::norm(F::template sub<8, 1>(Q, X3));
+  const F NY = F::template neg<3, 1>(acc.y);
+#if ARK_G2L28_FUSE_Y3
+  acc.y = L::template mul2<6, 1, 4, 3>(R, T, NY, PPP);
+#else
+  // two dual-product passes and a lazy sum: 196 more multiply-adds than the fused four-product pass (A/B knob;
+  // it does not change the register spills of this kernel)
+  const F Y3a = L::template mul<6, 1>(R, T);
+  const F Y3b = L::template mul<4, 3>(NY, PPP);
+  acc.y = F::norm(F::add(Y3a, Y3b));
+#endif
+  acc.x = X3;
+}
+
+template <class P>
+__global__ void __launch_bounds__(MSM_THREADS, 2)
+msm_accumulate_g2l28_kernel(const Affine28G2<P>* __restrict__ bases, const uint32_t* __restrict__ sorted_keys,
+                            const uint32_t* __restrict__ sorted_vals, const uint32_t* __restrict__ total_ptr,
+                            const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ counts,
+                            XYZZ<Fp2<P>>* __restrict__ buckets, XYZZ<Fp2<P>>* __restrict__ head,
+                            uint32_t* __restrict__ head_key, XYZZ<Fp2<P>>* __restrict__ tail,
+                            uint32_t* __restrict__ tail_key, uint32_t seg_log) {
+  using F = Fp28<P>;
+  using Fq = Fp<P>;
+  using L = Pair28<P>;
+  constexpr int Q = Affine28<P>::Q;
+  const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t seg = gid >> 1, par = gid & 1u;       // blockDim is even: par == lane parity
+  const uint32_t total = *total_ptr;
+  const uint64_t start64 = (uint64_t)seg << seg_log;
+  if (start64 >= total) return;                        // both lanes of a pair leave together
+  const uint32_t start = (uint32_t)start64;
+  const uint32_t seg_len = 1u << seg_log;
+  const uint32_t end = (start + seg_len < total) ? start + seg_len : total;
+  uint32_t cur_key = sorted_keys[start];
+  uint32_t run_start = start;
+  bool first_run = true;
+  bool empty = true;
+  Acc28<P> acc;
+  acc.x = F::zero();
+  acc.y = F::zero();
+  acc.zz = F::zero();
+  acc.zzz = F::zero();
+  auto flush = [&](uint32_t key, uint32_t run_end) {
+    // this lane's halves of the four Fq2 coordinates, canonical 32-bit form
+    XYZZ<Fq> mine = XYZZ<Fq>::inf();
+    if (!empty) {
+      mine.x = F::to_fp(acc.x);
+      mine.y = F::to_fp(acc.y);
+      mine.zz = F::to_fp(acc.zz);
+      mine.zzz = F::to_fp(acc.zzz);
+    }
+    const uint32_t o = offsets[key], cnt = counts[key];
+    const bool complete = (run_start == o) && (run_end == o + cnt);
+    XYZZ<Fp2<P>>* dst = complete ? &buckets[key] : (first_run ? &head[seg] : &tail[seg]);
+    Fq* d = reinterpret_cast<Fq*>(dst);
+    d[0 + par] = mine.x;
+    d[2 + par] = mine.y;
+    d[4 + par] = mine.zz;
+    d[6 + par] = mine.zzz;
+    if (!complete && par == 0) {
+      if (first_run) head_key[seg] = key;
+      else tail_key[seg] = key;
+    }
+  };
+  for (uint32_t e = start; e < end; e++) {
+    const uint32_t key = sorted_keys[e];
+    const uint32_t v = sorted_vals[e];
+    F px, py;
+    {
+      const uint4* src = reinterpret_cast<const uint4*>(&bases[v & ARK_TBL_MASK].half[par]);
+      uint32_t d[4 * Q];
+#pragma unroll
+      for (int k = 0; k < Q; k++) {
+        const uint4 t = src[k];
+        d[4 * k + 0] = t.x;
+        d[4 * k + 1] = t.y;
+        d[4 * k + 2] = t.z;
+        d[4 * k + 3] = t.w;
+      }
+#pragma unroll
+      for (int k = 0; k < F::N; k++) {
+        px.l[k] = d[k];
+        py.l[k] = d[F::N + k];
+      }
+    }
+    if (key != cur_key) {
+      flush(cur_key, e);
+      cur_key = key;
+      run_start = e;
+      first_run = false;
+      empty = true;
+    }
+    uint32_t any = 0;
+#pragma unroll
+    for (int k = 0; k < F::N; k++) any |= px.l[k] | py.l[k];
+    if ((any | ark_pair_xchg(any)) == 0) continue;       // base at infinity (pair-wide)
+    madd28_g2<P>(acc, empty, px, py, (v >> 31) != 0);
   }
   flush(cur_key, end);
 }

@@ -684,19 +684,17 @@ struct PrecompTable {
   MsmPlan plan;
   DevBuf table;          // windows * n rows: Affine<F>, or Affine28 rows when limb28 is set
   uint64_t n = 0;
-  bool limb28 = false;   // G1 tables are stored in the radix-2^28 form of field28.cuh (msm28_impl.cuh)
+  bool limb28 = false;   // rows are stored in the radix-2^28 form of field28.cuh (msm28_impl.cuh)
 };
 
 #ifndef ARK_LIMB28_DEFAULT
 #define ARK_LIMB28_DEFAULT 1
 #endif
-// ARK355_LIMB28=0|1: keep G1 window tables in the 32-bit form (A/B switch for the 28-bit accumulation kernel)
-static inline bool msm_use_limb28() {
-  static const int v = [] {
-    const char* e = getenv("ARK355_LIMB28");
-    return e ? (e[0] == '1') : ARK_LIMB28_DEFAULT;
-  }();
-  return v != 0;
+// ARK355_LIMB28=0|1 (default 1): G1 window tables and bucket accumulation in the radix-2^28 form (msm28_impl.cuh).
+// ARK355_G2_LIMB28=0|1 (default 0): the same for G2 (lane-split); it only ties with the 32-bit lane-split kernel.
+static inline bool msm_use_limb28(bool g2) {       // read when a table is built (not cached: tests flip it)
+  const char* e = getenv(g2 ? "ARK355_G2_LIMB28" : "ARK355_LIMB28");
+  return e ? (e[0] == '1') : (g2 ? false : ARK_LIMB28_DEFAULT != 0);
 }
 
 template <class F, class Fr>
@@ -721,19 +719,26 @@ static void precomp_build(PrecompTable& t, const void* d_bases, uint64_t n, hipS
     ARK_CHECK_LAUNCH();
   }
   ARK_CHECK_HIP(hipStreamSynchronize(stream));     // tmp is freed on return
-  if constexpr (!is_fp2<F>::value) {
-    if (msm_use_limb28()) {
-      // re-encode the finished table for the 28-bit accumulation kernel; the 32-bit rows are dropped
+  if (msm_use_limb28(is_fp2<F>::value)) {
+    // re-encode the finished table for the 28-bit accumulation kernels; the 32-bit rows are dropped
+    const uint64_t rows = (uint64_t)p.windows * n;
+    const dim3 grid28((uint32_t)((rows + 255) / 256));
+    DevBuf t28;
+    if constexpr (is_fp2<F>::value) {
+      using P = typename F::Base::Params;
+      t28.alloc(rows * sizeof(Affine28G2<P>));
+      ARK_LAUNCH((table_to28_g2_kernel<P>), grid28, dim3(256), 0, stream, (const Affine<F>*)T,
+                 t28.as<Affine28G2<P>>(), rows);
+    } else {
       using P = typename F::Params;
-      const uint64_t rows = (uint64_t)p.windows * n;
-      DevBuf t28(rows * sizeof(Affine28<P>));
-      ARK_LAUNCH((table_to28_kernel<P>), dim3((uint32_t)((rows + 255) / 256)), dim3(256), 0, stream,
-                 (const Affine<F>*)T, t28.as<Affine28<P>>(), rows);
-      ARK_CHECK_LAUNCH();
-      ARK_CHECK_HIP(hipStreamSynchronize(stream));
-      t.table = std::move(t28);
-      t.limb28 = true;
+      t28.alloc(rows * sizeof(Affine28<P>));
+      ARK_LAUNCH((table_to28_kernel<P>), grid28, dim3(256), 0, stream, (const Affine<F>*)T,
+                 t28.as<Affine28<P>>(), rows);
     }
+    ARK_CHECK_LAUNCH();
+    ARK_CHECK_HIP(hipStreamSynchronize(stream));
+    t.table = std::move(t28);
+    t.limb28 = true;
   }
 }
 
@@ -833,7 +838,15 @@ static void msm_accumulate_phase(ark355_ctx* ctx, const MsmSort& s, MsmBuckets& 
       const char* e = getenv("ARK355_G2_WHOLE");
       return e && e[0] == '1';
     }();
-    if (!g2_whole) {
+    if (bases28) {
+      using P = typename F::Base::Params;
+      const uint32_t grid_l = (2 * segs + MSM_THREADS - 1) / MSM_THREADS;
+      ARK_LAUNCH((msm_accumulate_g2l28_kernel<P>), dim3(grid_l), dim3(MSM_THREADS), 0, stream,
+                 reinterpret_cast<const Affine28G2<P>*>(d_bases), s.sorted_keys.as<uint32_t>(),
+                 s.sorted_vals.as<uint32_t>(), s.total.as<uint32_t>(), s.offsets.as<uint32_t>(),
+                 s.counts.as<uint32_t>(), b.buckets.as<XYZZ<F>>(), b.head.as<XYZZ<F>>(), b.head_key.as<uint32_t>(),
+                 b.tail.as<XYZZ<F>>(), b.tail_key.as<uint32_t>(), p.seg_log);
+    } else if (!g2_whole) {
       using P = typename F::Base::Params;
       const uint32_t grid_l = (2 * segs + MSM_THREADS - 1) / MSM_THREADS;
       ARK_LAUNCH((msm_accumulate_g2l_kernel<P>), dim3(grid_l), dim3(MSM_THREADS), 0, stream, d_bases,

@@ -39,6 +39,21 @@ def test_resident_tables_exceptional_additions(emul_lib, emul_ctx, C, group):
     pc.resident_msm_edge_case(emul_lib, emul_ctx, C, group, 24, to_dev)
 
 
+@pytest.mark.parametrize("env", [{"ARK355_G2_LIMB28": "1"}, {"ARK355_LIMB28": "0"}], ids=["g2-28bit", "g1-32bit"])
+def test_resident_tables_alternate_limb_forms(emul_lib, emul_ctx, monkeypatch, env):
+    """The opt-in 28-bit lane-split G2 kernel and the 32-bit G1 kernel over window tables (the A/B switches)."""
+    import numpy as np
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+
+    def to_dev(b):
+        a = np.frombuffer(b, dtype=np.uint8).copy()
+        return a.ctypes.data, a
+    group = 2 if "ARK355_G2_LIMB28" in env else 1
+    pc.resident_msm_edge_case(emul_lib, emul_ctx, BLS12_381, group, 24, to_dev)
+    pc.resident_msm_edge_case(emul_lib, emul_ctx, BN254, group, 24, to_dev)
+
+
 @pytest.mark.parametrize("skew", ["equal", "boolean"])
 def test_msm_skewed_scalars(emul_lib, emul_ctx, skew):
     # all-equal scalars: every term of a window lands in ONE bucket (long straddling runs);

@@ -63,6 +63,22 @@ def test_resident_tables_exceptional_additions(gpu_lib, gpu_ctx, C, group, n):
     pc.resident_msm_edge_case(gpu_lib, gpu_ctx, C, group, n, to_dev)
 
 
+@pytest.mark.parametrize("env", [{"ARK355_G2_LIMB28": "1"}, {"ARK355_LIMB28": "0"}], ids=["g2-28bit", "g1-32bit"])
+def test_resident_tables_alternate_limb_forms(gpu_lib, gpu_ctx, monkeypatch, env):
+    """The opt-in 28-bit lane-split G2 kernel and the 32-bit G1 kernel over window tables (the A/B switches)."""
+    import numpy as np
+    import torch
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+
+    def to_dev(b):
+        t = torch.from_numpy(np.frombuffer(b, dtype=np.uint8).copy()).cuda()
+        return t.data_ptr(), t
+    group = 2 if "ARK355_G2_LIMB28" in env else 1
+    for C in CURVES:
+        pc.resident_msm_edge_case(gpu_lib, gpu_ctx, C, group, 200, to_dev)
+
+
 @pytest.mark.parametrize("C,group,n,skew", [
     (BLS12_381, 1, 1 << 14, None), (BLS12_381, 1, 1 << 14, "equal"), (BLS12_381, 1, 1 << 14, "boolean"),
     (BLS12_381, 2, 1 << 12, None), (BN254, 1, 1 << 14, None), (BN254, 2, 1 << 12, "boolean"),
