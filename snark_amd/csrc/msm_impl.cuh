@@ -187,31 +187,80 @@ msm_digits_kernel(const Fr* __restrict__ scalars, uint32_t n, int mont, uint32_t
 }
 
 // ---- exclusive scan of `m` u32 counters by one workgroup ---------------------------------------------
-static __global__ void __launch_bounds__(1024)
+// Tiles of 1024 x SCAN_EPT counters: coalesced 16-byte loads, a shuffle scan per wave, the 16 wave totals through
+// LDS, a running carry across tiles.  (The first version gave every thread one contiguous chunk: uncoalesced, and
+// 0.17 ms for the 2^17..2^18-entry tables of the two-level sort.)
+constexpr uint32_t SCAN_THREADS = 1024;
+constexpr uint32_t SCAN_EPT = 16;
+static __global__ void __launch_bounds__(SCAN_THREADS)
 scan_exclusive_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, uint32_t m,
                       uint32_t* __restrict__ total) {
-  __shared__ uint32_t part[1024];
-  const uint32_t tid = threadIdx.x, nth = blockDim.x;
-  const uint32_t chunk = (m + nth - 1) / nth;
-  const uint32_t lo = tid * chunk;
-  const uint32_t hi = (lo + chunk < m) ? lo + chunk : m;
-  uint32_t s = 0;
-  for (uint32_t i = lo; i < hi; i++) s += in[i];
-  part[tid] = s;
+  __shared__ uint32_t wave_tot[SCAN_THREADS / 64];
+  __shared__ uint32_t carry_s;
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  if (tid == 0) carry_s = 0;
   __syncthreads();
-  for (uint32_t d = 1; d < nth; d <<= 1) {
-    uint32_t v = (tid >= d) ? part[tid - d] : 0;
+  constexpr uint32_t TILE = SCAN_THREADS * SCAN_EPT;
+  for (uint64_t base = 0; base < m; base += TILE) {
+    // thread t owns SCAN_EPT consecutive counters: four aligned 16-byte pieces
+    uint32_t v[SCAN_EPT];
+    const uint64_t first = base + (uint64_t)tid * SCAN_EPT;
+#pragma unroll
+    for (uint32_t q = 0; q < SCAN_EPT / 4; q++) {
+      const uint64_t i = first + 4 * q;
+      if (i + 3 < m) {
+        const uint4 t = *reinterpret_cast<const uint4*>(in + i);
+        v[4 * q + 0] = t.x;
+        v[4 * q + 1] = t.y;
+        v[4 * q + 2] = t.z;
+        v[4 * q + 3] = t.w;
+      } else {
+#pragma unroll
+        for (uint32_t k = 0; k < 4; k++) v[4 * q + k] = (i + k < m) ? in[i + k] : 0u;
+      }
+    }
+    uint32_t s = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < SCAN_EPT; k++) s += v[k];
+    // inclusive scan of s across the wave
+    uint32_t inc = s;
+#pragma unroll
+    for (uint32_t d = 1; d < 64; d <<= 1) {
+      const uint32_t o = __shfl_up(inc, d, 64);
+      if (lane >= d) inc += o;
+    }
+    if (lane == 63) wave_tot[wave] = inc;
     __syncthreads();
-    part[tid] += v;
+    uint32_t wbase = 0, tile_total = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < SCAN_THREADS / 64; w++) {
+      const uint32_t t = wave_tot[w];
+      if (w < wave) wbase += t;
+      tile_total += t;
+    }
+    uint32_t run = carry_s + wbase + (inc - s);
+#pragma unroll
+    for (uint32_t q = 0; q < SCAN_EPT / 4; q++) {
+      const uint64_t i = first + 4 * q;
+      uint32_t o[4];
+#pragma unroll
+      for (uint32_t k = 0; k < 4; k++) {
+        o[k] = run;
+        run += v[4 * q + k];
+      }
+      if (i + 3 < m) {
+        *reinterpret_cast<uint4*>(out + i) = make_uint4(o[0], o[1], o[2], o[3]);
+      } else {
+#pragma unroll
+        for (uint32_t k = 0; k < 4; k++)
+          if (i + k < m) out[i + k] = o[k];
+      }
+    }
+    __syncthreads();                     // everyone has read carry_s and wave_tot
+    if (tid == 0) carry_s += tile_total;
     __syncthreads();
   }
-  uint32_t run = part[tid] - s;
-  for (uint32_t i = lo; i < hi; i++) {
-    const uint32_t v = in[i];
-    out[i] = run;
-    run += v;
-  }
-  if (tid == nth - 1 && total) *total = part[tid];
+  if (tid == 0 && total) *total = carry_s;
 }
 
 // ---- K3: scatter (counting sort) ----------------------------------------------------------------------
@@ -246,6 +295,7 @@ constexpr uint32_t SORT_LO_BITS = 8;
 constexpr uint32_t SORT_LO = 1u << SORT_LO_BITS;
 constexpr uint32_t SORT_MAX_BINS = 4096;       // LDS counters of level 1
 constexpr uint32_t SORT_SPT = 4;               // scalars per thread in level 1
+constexpr uint32_t SORT_HI_THREADS = 1024;     // level-1 workgroup: 4096 scalars, [bin][workgroup] table stays small
 constexpr uint32_t SORT_EPT = 16;              // entries per thread in level 2
 constexpr uint32_t SORT_TILE = MSM_THREADS * SORT_EPT;
 
@@ -284,15 +334,15 @@ ARK_D void msm_for_each_digit(Fr k, int mont, uint32_t i, uint32_t n, uint32_t c
 }
 
 template <class Fr>
-__global__ void __launch_bounds__(MSM_THREADS)
+__global__ void __launch_bounds__(SORT_HI_THREADS)
 sort_hi_hist_kernel(const Fr* __restrict__ scalars, uint32_t n, int mont, uint32_t c, uint32_t windows, int precomp,
                     uint32_t table_stride, uint32_t bins, uint32_t* __restrict__ hist /* [bin][gridDim.x] */) {
   __shared__ uint32_t lds[SORT_MAX_BINS];
   for (uint32_t b = threadIdx.x; b < bins; b += blockDim.x) lds[b] = 0;
   __syncthreads();
-  const uint32_t base = blockIdx.x * (MSM_THREADS * SORT_SPT);
+  const uint32_t base = blockIdx.x * (SORT_HI_THREADS * SORT_SPT);
   for (uint32_t j = 0; j < SORT_SPT; j++) {
-    const uint32_t i = base + j * MSM_THREADS + threadIdx.x;
+    const uint32_t i = base + j * SORT_HI_THREADS + threadIdx.x;
     if (i < n) {
       msm_for_each_digit<Fr>(scalars[i], mont, i, n, c, windows, precomp, table_stride,
                              [&](uint32_t, uint32_t key, uint32_t) { atomicAdd(&lds[key >> SORT_LO_BITS], 1u); });
@@ -303,7 +353,7 @@ sort_hi_hist_kernel(const Fr* __restrict__ scalars, uint32_t n, int mont, uint32
 }
 
 template <class Fr>
-__global__ void __launch_bounds__(MSM_THREADS)
+__global__ void __launch_bounds__(SORT_HI_THREADS)
 sort_hi_scatter_kernel(const Fr* __restrict__ scalars, uint32_t n, int mont, uint32_t c, uint32_t windows,
                        int precomp, uint32_t table_stride, uint32_t bins,
                        const uint32_t* __restrict__ hist_scanned /* [bin][gridDim.x], exclusive */,
@@ -311,9 +361,9 @@ sort_hi_scatter_kernel(const Fr* __restrict__ scalars, uint32_t n, int mont, uin
   __shared__ uint32_t lds[SORT_MAX_BINS];
   for (uint32_t b = threadIdx.x; b < bins; b += blockDim.x) lds[b] = hist_scanned[(size_t)b * gridDim.x + blockIdx.x];
   __syncthreads();
-  const uint32_t base = blockIdx.x * (MSM_THREADS * SORT_SPT);
+  const uint32_t base = blockIdx.x * (SORT_HI_THREADS * SORT_SPT);
   for (uint32_t j = 0; j < SORT_SPT; j++) {
-    const uint32_t i = base + j * MSM_THREADS + threadIdx.x;
+    const uint32_t i = base + j * SORT_HI_THREADS + threadIdx.x;
     if (i < n) {
       msm_for_each_digit<Fr>(scalars[i], mont, i, n, c, windows, precomp, table_stride,
                              [&](uint32_t, uint32_t key, uint32_t val) {
@@ -940,7 +990,7 @@ static void msm_sort(ark355_ctx* ctx, MsmSort& s, const void* d_scalars, uint64_
                mont, p.c, p.windows, p.precomp ? 1 : 0, stride, s.keys.as<uint32_t>(), s.vals.as<uint32_t>(),
                s.counts.as<uint32_t>());
     ARK_CHECK_LAUNCH();
-    ARK_LAUNCH(scan_exclusive_kernel, dim3(1), dim3(1024), 0, stream, s.counts.as<uint32_t>(),
+    ARK_LAUNCH(scan_exclusive_kernel, dim3(1), dim3(SCAN_THREADS), 0, stream, s.counts.as<uint32_t>(),
                s.offsets.as<uint32_t>(), p.total_buckets, s.total.as<uint32_t>());
     ARK_CHECK_LAUNCH();
     const uint32_t grid_e = (uint32_t)((entries + MSM_THREADS - 1) / MSM_THREADS);
@@ -951,19 +1001,19 @@ static void msm_sort(ark355_ctx* ctx, MsmSort& s, const void* d_scalars, uint64_
     return;
   }
   // level 1: group by bin (key >> 8) into keys/vals
-  const uint32_t per_wg = MSM_THREADS * SORT_SPT;
+  const uint32_t per_wg = SORT_HI_THREADS * SORT_SPT;
   const uint32_t grid1 = (uint32_t)((n + per_wg - 1) / per_wg);
   const size_t hist_elems = (size_t)bins * grid1;
   s.hist.ensure(hist_elems * 4);
   s.hist_scanned.ensure(hist_elems * 4);
-  ARK_LAUNCH((sort_hi_hist_kernel<Fr>), dim3(grid1), dim3(MSM_THREADS), 0, stream, (const Fr*)d_scalars, (uint32_t)n,
+  ARK_LAUNCH((sort_hi_hist_kernel<Fr>), dim3(grid1), dim3(SORT_HI_THREADS), 0, stream, (const Fr*)d_scalars, (uint32_t)n,
              mont, p.c, p.windows, p.precomp ? 1 : 0, stride, bins, s.hist.as<uint32_t>());
   ARK_CHECK_LAUNCH();
   ARK_REQUIRE(hist_elems < (1ull << 31), ARK355_EINVAL, "sort histogram too large");
-  ARK_LAUNCH(scan_exclusive_kernel, dim3(1), dim3(1024), 0, stream, s.hist.as<uint32_t>(),
+  ARK_LAUNCH(scan_exclusive_kernel, dim3(1), dim3(SCAN_THREADS), 0, stream, s.hist.as<uint32_t>(),
              s.hist_scanned.as<uint32_t>(), (uint32_t)hist_elems, s.total.as<uint32_t>());
   ARK_CHECK_LAUNCH();
-  ARK_LAUNCH((sort_hi_scatter_kernel<Fr>), dim3(grid1), dim3(MSM_THREADS), 0, stream, (const Fr*)d_scalars,
+  ARK_LAUNCH((sort_hi_scatter_kernel<Fr>), dim3(grid1), dim3(SORT_HI_THREADS), 0, stream, (const Fr*)d_scalars,
              (uint32_t)n, mont, p.c, p.windows, p.precomp ? 1 : 0, stride, bins, s.hist_scanned.as<uint32_t>(),
              s.keys.as<uint32_t>(), s.vals.as<uint32_t>());
   ARK_CHECK_LAUNCH();
@@ -973,7 +1023,7 @@ static void msm_sort(ark355_ctx* ctx, MsmSort& s, const void* d_scalars, uint64_
              s.vals.as<uint32_t>(), s.total.as<uint32_t>(), s.counts.as<uint32_t>(), s.offsets.as<uint32_t>(),
              s.cursor.as<uint32_t>(), s.sorted_keys.as<uint32_t>(), s.sorted_vals.as<uint32_t>());
   ARK_CHECK_LAUNCH();
-  ARK_LAUNCH(scan_exclusive_kernel, dim3(1), dim3(1024), 0, stream, s.counts.as<uint32_t>(),
+  ARK_LAUNCH(scan_exclusive_kernel, dim3(1), dim3(SCAN_THREADS), 0, stream, s.counts.as<uint32_t>(),
              s.offsets.as<uint32_t>(), p.total_buckets, s.total.as<uint32_t>());
   ARK_CHECK_LAUNCH();
   ARK_LAUNCH((sort_lo_kernel<true>), dim3(grid2), dim3(MSM_THREADS), 0, stream, s.keys.as<uint32_t>(),

@@ -36,6 +36,7 @@ struct dim3 {
 struct uint4 {
   unsigned x, y, z, w;
 };
+static inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) { return uint4{x, y, z, w}; }
 
 namespace emu {
 enum State { RUN = 0, WAVE_WAIT = 1, BLOCK_WAIT = 2, DONE = 3 };
