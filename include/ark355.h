@@ -106,6 +106,18 @@ int32_t ark355_prove(ark355_ctx* ctx, const ark355_pk* pk, const ark355_r1cs* r1
 int32_t ark355_prove_dev(ark355_ctx* ctx, const ark355_pk* pk, const ark355_r1cs* r1cs, const void* d_z,
                          uint64_t z_len, const uint8_t r[32], const uint8_t s[32], ark355_proof_raw* out);
 
+/* Many independent proofs of ONE circuit on one GPU (BASELINE.json configs[4]: 64 proofs at n = 2^18, eight per
+ * GPU).  Replaces a pool of OS threads that each call SNARK::prove (snark/src/lib.rs:50-54) -- the reference's
+ * ConstraintSystemRef is Rc<RefCell<..>> (constraint_system_ref.rs:33), so upstream parallelism is exactly "one
+ * thread per proof" (Threading).  z[i]: host assignment of proof i (z_len Fr each, Montgomery);
+ * r, s: count x 32 B canonical; out: count proofs.  Up to `inflight` (1..16) proofs are in flight on private
+ * streams and scratch owned by `ctx`; the key and CSR handles are shared, read-only.  While one proof is in a
+ * serial phase (digit sort, last bucket reduction, host finish) the others keep the CUs busy.  Returns the error
+ * of the first failing proof (out[] of the others is still written). */
+int32_t ark355_prove_batch(ark355_ctx* ctx, const ark355_pk* pk, const ark355_r1cs* r1cs, const uint8_t* const* z,
+                           uint64_t z_len, const uint8_t* r, const uint8_t* s, uint64_t count, uint32_t inflight,
+                           ark355_proof_raw* out);
+
 /* ---- one proof, MSM term ranges sharded over several GPUs (BASELINE.json configs[2]) ----------
  * Every rank loads shard `shard_index` of `shard_count` of the SAME key descriptor (terms
  * [T*i/G, T*(i+1)/G) of each query vector), computes the witness map redundantly, and returns the five

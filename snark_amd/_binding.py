@@ -39,7 +39,7 @@ SYMBOLS = [
     "ark355_msm_g1", "ark355_msm_g2", "ark355_bases_load", "ark355_bases_free", "ark355_msm_dev",
     "ark355_msm_dev_partial", "ark355_xyzz_sum", "ark355_fixed_base_mul", "ark355_get_timings",
     "ark355_get_kernel_stats", "ark355_pk_load_shard", "ark355_partial_size", "ark355_prove_shard",
-    "ark355_prove_combine",
+    "ark355_prove_combine", "ark355_prove_batch",
 ]
 
 
@@ -129,6 +129,7 @@ class Lib:
         d.ark355_partial_size.restype = u64
         d.ark355_prove_shard.argtypes = [vp, vp, vp, vp, u64, vp, vp, vp]
         d.ark355_prove_combine.argtypes = [vp, i32, vp, u64, vp, vp, P(ProofRaw)]
+        d.ark355_prove_batch.argtypes = [vp, vp, vp, vp, u64, vp, vp, u64, u32, vp]
         d.ark355_get_timings.argtypes = [vp, P(Timings)]
         d.ark355_get_kernel_stats.argtypes = [vp, P(C.c_float), P(u64), P(u64)]
         for name in SYMBOLS:
@@ -209,6 +210,18 @@ class Lib:
             rc = self.dll.ark355_prove(ctx, pk, r1cs, zb, z_len, rb, sb, C.byref(out))
         self.check(ctx, rc)
         return bytes(out.a)[:sizes["g1"]], bytes(out.b)[:sizes["g2"]], bytes(out.c)[:sizes["g1"]]
+
+    def prove_batch(self, ctx, pk, r1cs, zs, z_len, rs, ss, sizes, inflight=3):
+        """ark355_prove_batch: `zs` host assignments (bytes), `rs`/`ss` canonical 32-byte scalars, one per proof."""
+        count = len(zs)
+        out = (ProofRaw * max(1, count))()
+        bufs = [_buf(z) for z in zs]
+        ptrs = (C.c_void_p * max(1, count))(*[C.cast(b[0], C.c_void_p) for b in bufs])
+        rb, k1 = _buf(b"".join(rs) if count else None)
+        sb, k2 = _buf(b"".join(ss) if count else None)
+        rc = self.dll.ark355_prove_batch(ctx, pk, r1cs, ptrs, z_len, rb, sb, count, int(inflight), out)
+        self.check(ctx, rc)
+        return [(bytes(o.a)[:sizes["g1"]], bytes(o.b)[:sizes["g2"]], bytes(o.c)[:sizes["g1"]]) for o in out[:count]]
 
     def prove_shard(self, ctx, curve, pk_shard, r1cs, z, z_len, r: bytes, s: bytes):
         out = np.zeros(self.dll.ark355_partial_size(curve), dtype=np.uint8)

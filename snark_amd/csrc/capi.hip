@@ -1,7 +1,9 @@
 // extern "C" surface of libark355.so (include/ark355.h).  No C++ exception crosses this boundary:
 // every entry point catches and maps to an error code (the reference builds with panic='abort' for
 // exactly that reason, /root/reference/Cargo.toml:33,45).
+#include <atomic>
 #include <new>
+#include <thread>
 #include "api_impl.cuh"
 
 namespace ark355 {
@@ -25,6 +27,8 @@ namespace {
 struct CtxExtra {
   ProverScratch prover;
   GenericScratch generic;
+  std::vector<ark355_ctx*> lanes;     // child contexts of ark355_prove_batch (same device, private streams/scratch)
+  ~CtxExtra();
 };
 std::mutex g_extra_mu;
 std::map<ark355_ctx*, CtxExtra*> g_extra;
@@ -34,6 +38,10 @@ CtxExtra& extra(ark355_ctx* ctx) {
   auto it = g_extra.find(ctx);
   if (it == g_extra.end()) it = g_extra.emplace(ctx, new CtxExtra()).first;
   return *it->second;
+}
+
+CtxExtra::~CtxExtra() {
+  for (ark355_ctx* c : lanes) ark355_ctx_destroy(c);
 }
 
 template <class Fn>
@@ -105,14 +113,16 @@ void ark355_ctx_destroy(ark355_ctx* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
+  CtxExtra* ex = nullptr;
   {
     std::lock_guard<std::mutex> lk(g_extra_mu);
     auto it = g_extra.find(ctx);
     if (it != g_extra.end()) {
-      delete it->second;
+      ex = it->second;
       g_extra.erase(it);
     }
   }
+  delete ex;       // outside the lock: it destroys the batch worker contexts, which come back through here
   for (auto& kv : ctx->ntt_tables) delete kv.second;
   (void)hipStreamDestroy(ctx->stream);
   delete ctx;
@@ -189,6 +199,71 @@ int32_t ark355_prove(ark355_ctx* ctx, const ark355_pk* pk, const ark355_r1cs* r1
 int32_t ark355_prove_dev(ark355_ctx* ctx, const ark355_pk* pk, const ark355_r1cs* r1, const void* d_z, uint64_t z_len,
                          const uint8_t r[32], const uint8_t s[32], ark355_proof_raw* out) {
   return prove_common(ctx, pk, r1, d_z, z_len, true, r, s, out);
+}
+
+int32_t ark355_prove_batch(ark355_ctx* ctx, const ark355_pk* pk, const ark355_r1cs* r1, const uint8_t* const* z,
+                           uint64_t z_len, const uint8_t* r, const uint8_t* s, uint64_t count, uint32_t inflight,
+                           ark355_proof_raw* out) {
+  if (!ctx || !pk || !r1 || (count && (!z || !r || !s || !out))) return ARK355_EINVAL;
+  if (inflight < 1 || inflight > 16) return ARK355_EINVAL;
+  if (count == 0) return ARK355_OK;
+#if defined(ARK_EMUL)
+  inflight = 1;                        // the test-only emulator is single-threaded
+#endif
+  if (inflight > count) inflight = (uint32_t)count;
+  int32_t first_err = ARK355_OK;
+  std::string first_msg;
+  const int32_t rc = guarded(ctx, [&] {
+    CtxExtra& ex = extra(ctx);
+    while (ex.lanes.size() + 1 < inflight) {
+      ark355_ctx* c = nullptr;
+      const int32_t e = ark355_ctx_create(ctx->device, &c);
+      if (e != ARK355_OK) throw HipError{e, "ark355_prove_batch: cannot create a worker context"};
+      ex.lanes.push_back(c);
+    }
+    std::atomic<uint64_t> next{0};
+    std::mutex err_mu;
+    auto work = [&](ark355_ctx* lane) {
+      for (;;) {
+        const uint64_t i = next.fetch_add(1);
+        if (i >= count) return;
+        int32_t e;
+        if (lane == ctx) {
+          // the parent's mutex is already held by this call: run its share on the calling thread, unguarded path
+          e = ARK355_OK;
+          try {
+            if (!z[i]) throw HipError{ARK355_EINVAL, "null assignment pointer"};
+            if (z_len < r1->d->m) throw HipError{ARK355_E_ASSIGNMENT_MISSING, "assignment shorter than num_instance + num_witness"};
+            if (pk->d->shard_count != 1) throw HipError{ARK355_EINVAL, "this key handle is an MSM shard"};
+            (void)hipSetDevice(ctx->device);
+            CURVE_DISPATCH(pk->d->curve, A::prove(ctx, ex.prover, *pk->d, *r1->d, z[i], false, r + 32 * i, s + 32 * i, out + i));
+          } catch (const HipError& he) {
+            e = he.code;
+            ctx->last_error = he.what;
+          } catch (const std::exception& se) {
+            e = ARK355_EINVAL;
+            ctx->last_error = se.what();
+          }
+        } else {
+          e = z[i] ? prove_common(lane, pk, r1, z[i], z_len, false, r + 32 * i, s + 32 * i, out + i) : ARK355_EINVAL;
+        }
+        if (e != ARK355_OK) {
+          std::lock_guard<std::mutex> lk(err_mu);
+          if (first_err == ARK355_OK) {
+            first_err = e;
+            first_msg = "proof " + std::to_string(i) + ": " + lane->last_error;
+          }
+        }
+      }
+    };
+    std::vector<std::thread> th;
+    for (uint32_t k = 1; k < inflight; k++) th.emplace_back(work, ex.lanes[k - 1]);
+    work(ctx);
+    for (auto& t : th) t.join();
+  });
+  if (rc != ARK355_OK) return rc;
+  if (first_err != ARK355_OK) ctx->last_error = first_msg;
+  return first_err;
 }
 
 uint64_t ark355_partial_size(int32_t curve) {

@@ -472,6 +472,7 @@ struct Fp2 {
   }
 };
 
+#ifndef ARK_PLAIN_HOST
 // Lane-split Fq2: the two lanes of a pair (lane ^ 1) hold c0 and c1 of the SAME element.  Used by the G2 bucket
 // accumulation so that a G2 mixed addition needs G1-like registers per lane (the whole-element version sits at
 // 256 VGPR + 253 AGPR, one wave per SIMD).  Additions are component-wise; a multiplication exchanges the two
@@ -566,6 +567,8 @@ struct Fp2L {
   ARK_D static Fp2L mul_ni(const Fp2L& a, const Fp2L& b) { return mul(a, b); }
   ARK_D static Fp2L sqr_ni(const Fp2L& a) { return mul(a, a); }
 };
+
+#endif  // ARK_PLAIN_HOST
 
 using BlsFq = Fp<BlsFqParams>;
 using BlsFr = Fp<BlsFrParams>;

@@ -38,4 +38,5 @@ __device__ __forceinline__ uint32_t ark_pair_xchg(uint32_t v) {
 #define ARK_HD inline
 #define ARK_HD_NOINLINE __attribute__((noinline))
 #define ARK_D inline
+#define ARK_PLAIN_HOST 1      // no lanes here: lane-pair types (Fp2L) are not declared
 #endif

@@ -260,6 +260,23 @@ class Groth16:
             raise SynthesisError(str(e)) from e
         return Proof(a, b, c)
 
+    def prove_batch(self, pk: ProvingKey, r1cs: R1CS, zs, rng=None, rs=None, inflight: int = 3):
+        """Many proofs of one circuit (`ark355_prove_batch`): zs = one assignment per proof (Montgomery bytes or
+        lists of ints); randomisers are drawn from `rng` in the order r_0, s_0, r_1, s_1, ... unless `rs` gives the
+        (r, s) pairs.  Up to `inflight` proofs share the GPU at a time."""
+        cv = self.curve
+        if rs is None:
+            rs = [(rng() % cv.r, rng() % cv.r) for _ in zs]
+        zb = [z if isinstance(z, (bytes, bytearray, np.ndarray)) else b"".join(cv.fr_mont(v) for v in z) for z in zs]
+        z_len = min((len(z) // 32 for z in zb), default=0)
+        pkh, rh = self.load_pk(pk), self.load_r1cs(r1cs)
+        try:
+            out = self.lib.prove_batch(self.ctx, pkh, rh, zb, z_len, [cv.fr_canon(r) for r, _ in rs],
+                                       [cv.fr_canon(s) for _, s in rs], self.sizes, inflight=inflight)
+        except Ark355Error as e:
+            raise SynthesisError(str(e)) from e
+        return [Proof(a, b, c) for a, b, c in out]
+
     def is_satisfied(self, r1cs: R1CS, z) -> Optional[int]:
         """None if satisfied, else the first failing constraint index (constraint_system.rs:661-687)."""
         cv = self.curve

@@ -280,6 +280,45 @@ class Groth16 {
     return p;
   }
 
+  // Many proofs of one circuit (ark355_prove_batch): each circuit instance is synthesised on the calling thread (the
+  // constraint system is single-threaded by construction, constraint_system_ref.rs:33), then all assignments are
+  // proved with up to `inflight` proofs sharing the GPU.  Randomisers are drawn as r_0, s_0, r_1, s_1, ...
+  std::vector<Proof> prove_batch(ProvingKey& pk, const std::vector<Circuit*>& circuits, const Rng& rng,
+                                 uint32_t inflight = 3) const {
+    namespace g = ark_relations::gr1cs;
+    std::vector<std::vector<Fr>> zs;
+    std::vector<uint8_t> rc(32 * circuits.size(), 0), sc(32 * circuits.size(), 0);
+    for (size_t i = 0; i < circuits.size(); i++) {
+      CSRef cs = CSRef::new_ref();
+      cs.set_optimization_goal(g::OptimizationGoal::Constraints);
+      const bool resident = pk.resident && pk.resident->r1cs;
+      if (resident) cs.set_mode(g::SynthesisMode::prove(false, false));
+      circuits[i]->generate_constraints(cs);
+      cs.finalize();
+      if (!resident) load(pk, cs);
+      zs.push_back(cs.borrow().full_assignment());
+      rng().to_canonical_bytes(&rc[32 * i]);
+      rng().to_canonical_bytes(&sc[32 * i]);
+    }
+    std::vector<const uint8_t*> zp;
+    uint64_t z_len = zs.empty() ? 0 : zs[0].size();
+    for (const auto& z : zs) {
+      zp.push_back(reinterpret_cast<const uint8_t*>(z.data()));
+      if (z.size() < z_len) z_len = z.size();
+    }
+    std::vector<ark355_proof_raw> raw(circuits.size());
+    if (circuits.empty()) return {};
+    be_->check(ark355_prove_batch(be_->ctx(), pk.resident->pk, pk.resident->r1cs, zp.data(), z_len, rc.data(), sc.data(),
+                                  circuits.size(), inflight, raw.data()));
+    std::vector<Proof> out(circuits.size());
+    for (size_t i = 0; i < circuits.size(); i++) {
+      out[i].a.assign(raw[i].a, raw[i].a + G1);
+      out[i].b.assign(raw[i].b, raw[i].b + G2);
+      out[i].c.assign(raw[i].c, raw[i].c + G1);
+    }
+    return out;
+  }
+
   void load(ProvingKey& pk, const CSRef& cs) const {
     namespace g = ark_relations::gr1cs;
     auto res = std::make_shared<typename ProvingKey::Resident>();

@@ -175,3 +175,36 @@ def prove_case(lib, ctx, C, A, B, Cm, z, ell, td=None, rs=((0x1234567890abcdef, 
         lib.dll.ark355_pk_free(pkh)
         lib.dll.ark355_r1cs_free(r1)
     return pk
+
+
+def prove_batch_case(lib, ctx, C, count=5, n=9, inflight=3):
+    """ark355_prove_batch: `count` proofs of one circuit, different witnesses and randomisers, a few in flight;
+    every proof must equal the oracle's closed-form proof for the same (z, r, s)."""
+    sz = lib.sizes(C.curve_id)
+    td = G.Trapdoor(tau=0xabcdef0123, alpha=0x1111, beta=0x2222, gamma=0x3333, delta=0x4444)
+    insts = [S.mulchain_direct(C.r, n, seed=0x355 + k) for k in range(count)]
+    A, B, Cm, z0, ell = insts[0]
+    m = len(z0)
+    pko = G.setup(C, A, B, Cm, ell, m, td)
+    N = 1 << pko.domain_log
+    r1 = r1cs_load_from_rows(lib, ctx, C, A, B, Cm, ell, m - ell)
+    pk = pk_load_from_oracle(lib, ctx, C, pko, ell, m - ell, N)
+    try:
+        rs = [(0x1234 + 7 * k, 0x9999 + 13 * k) for k in range(count)]
+        zs = [z_bytes(C, inst[3]) for inst in insts]
+        out = lib.prove_batch(ctx, pk, r1, zs, m, [Z.fr_canon(C, r) for r, _ in rs],
+                              [Z.fr_canon(C, s) for _, s in rs], sz, inflight=inflight)
+        assert len(out) == count
+        for k in range(count):
+            got = G.Proof(Z.g1_from_raw(C, out[k][0]), Z.g2_from_raw(C, out[k][1]), Z.g1_from_raw(C, out[k][2]))
+            assert got == G.prove_closed_form(C, pko, insts[k][3], ell, rs[k][0], rs[k][1]), (C.name, k)
+        # error path: short assignments -> SynthesisError::AssignmentMissing for the batch
+        try:
+            lib.prove_batch(ctx, pk, r1, zs, m - 1, [Z.fr_canon(C, 1)] * count, [Z.fr_canon(C, 2)] * count, sz)
+            assert False, "short assignment must fail"
+        except Exception as e:
+            assert getattr(e, "code", None) == -16
+        assert lib.prove_batch(ctx, pk, r1, [], m, [], [], sz) == []
+    finally:
+        lib.dll.ark355_pk_free(pk)
+        lib.dll.ark355_r1cs_free(r1)

@@ -140,3 +140,8 @@ def test_host_mirror_setup_prove_over_emulator(emul_lib):
         assert g.is_satisfied(r1, zb) is not None
     finally:
         g.close()
+
+
+def test_prove_batch(emul_lib, emul_ctx):
+    """ark355_prove_batch over the emulator (runs its proofs one after another there)."""
+    pc.prove_batch_case(emul_lib, emul_ctx, BN254, count=3, n=6)

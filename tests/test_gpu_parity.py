@@ -161,3 +161,11 @@ def _host_mirror_case(curve_name, n, seed):
 @pytest.mark.parametrize("curve_name,n", [("bls12_381", 1 << 12), ("bn254", 1 << 12), ("bls12_381", (1 << 16) - 100)])
 def test_host_mirror_setup_prove_closed_form(gpu_lib, curve_name, n):
     _host_mirror_case(curve_name, n, seed=0x355)
+
+
+@pytest.mark.parametrize("C", CURVES, ids=lambda c: c.name)
+def test_prove_batch_in_flight(gpu_lib, gpu_ctx, C):
+    """ark355_prove_batch: 7 proofs, 3 in flight on private streams, each byte-checked against the closed form;
+    then a larger circuit with 4 in flight."""
+    pc.prove_batch_case(gpu_lib, gpu_ctx, C, count=7, n=40, inflight=3)
+    pc.prove_batch_case(gpu_lib, gpu_ctx, C, count=4, n=500, inflight=4)

@@ -44,6 +44,7 @@ def test_cpp_snark_trait_prove_matches_oracle(exe, curve_name, circuit, n):
     C = CURVES[curve_name]
     r = subprocess.run([exe, "--prove", curve_name, circuit, str(n)], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
+    assert "batch_ok 1" in r.stdout          # Groth16::prove_batch (ark355_prove_batch) agreed with single proofs
     got = _parse(r.stdout)
     if circuit == "dummy":
         A, B, Cm, z, ell = S.cs_to_instance(S.dummy_cs(C.r, n))
