@@ -26,6 +26,12 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+# Secondary, integer roofline of the bucket-accumulation kernels.  The scarce instruction is v_mad_u64_u32: the
+# whole chip issues 28.8 T of them per second (tools/ubench.hip, profiles/r01_ubench_*.txt: 46.8 per clock per CU).
+# Multiply-adds per mixed addition are read off the ISA of the shipped kernels (tools/isa_blocks.py, hot blocks):
+#   G1 on radix-2^28 limbs (msm_accumulate28_kernel), G2 lane-split on 32-bit limbs (two lanes per addition).
+MAD_PEAK_T = 28.8
+MADS_PER_ADD = {"bls12_381": {"g1": 3542, "g2": 2 * 3888}, "bn254": {"g1": 1720, "g2": 2 * 1728}}
 
 
 def parse_args():
@@ -142,6 +148,7 @@ def main():
                     if record is not None:
                         record[0] += ks["accumulate_ms"]
                         record[1] += ks["launches"]
+                        record[2] += ks["points"]
         ths = [threading.Thread(target=worker, args=(c,)) for c in ctxs]
         for t in ths:
             t.start()
@@ -150,7 +157,7 @@ def main():
         return results
 
     run(max(1, -(-args.warmup // len(ctxs))) if args.warmup else 0, None, per_worker=True)
-    rec = [0.0, 0]
+    rec = [0.0, 0, 0]
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -160,7 +167,7 @@ def main():
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
-    acc_ms_sum, acc_launches = rec
+    acc_ms_sum, acc_launches, acc_points = rec
     last = results[-1]
     tim = g.lib.timings(g.ctx)
     if world > 1:
@@ -191,6 +198,12 @@ def main():
         achieved = alg_bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
         prove_alg_bytes = (7 * 64 * N + alg_bytes_per_proof + 32 * m + 8 * int(sum(int(rp[-1]) for rp in r1.row_ptr))
                            + 3 * 32 * n)
+        # integer roofline: multiply-adds issued by the accumulation launches / their summed duration
+        windows = acc_points / max(1, args.steps) / float(g1_terms + g2_terms)       # table windows per term
+        mpa = MADS_PER_ADD[args.curve]
+        mads_per_proof = windows * (g1_terms * mpa["g1"] + g2_terms * mpa["g2"])
+        acc_ms_per_proof = acc_ms_sum / max(1, args.steps)
+        mad_rate_t = mads_per_proof / (acc_ms_per_proof * 1e-3) / 1e12 if acc_ms_per_proof > 0 else 0.0
         out = {
             "metric": "R1CS constraints/sec (Groth16 prove, BLS12-381)" if args.curve == "bls12_381"
                       else "R1CS constraints/sec (Groth16 prove, BN254)",
@@ -208,7 +221,13 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(n, args.curve),
                          "kernel": "msm_accumulate_kernel (bucket accumulation, 4 G1 + 1 G2 launches per proof)",
                          "alg_bytes_per_launch": alg_bytes_per_launch, "avg_launch_ms": avg_launch_ms,
-                         "note": "integer-ALU bound by construction (~10 Fq mul per 128 B term); see DESIGN.md"},
+                         "note": "integer-ALU bound by construction (~10 Fq mul per 128 B term); see DESIGN.md",
+                         "alu": {"unit": "T v_mad_u64_u32/s", "achieved": mad_rate_t, "peak": MAD_PEAK_T,
+                                 "frac": mad_rate_t / MAD_PEAK_T, "windows_per_term": windows,
+                                 "mads_per_add": mpa,
+                                 "note": "all 5 accumulation launches of a proof; with several proofs in flight the "
+                                         "launches share the chip, so the single-stream run (--inflight 1) is the "
+                                         "clean reading"}},
             "parity": parity,
             "phases_ms": tim,
             "prove_alg_bytes": prove_alg_bytes,

@@ -9,6 +9,7 @@ timeout 600 python bench.py --no-cpu-baseline --inflight 1 > gpurun_out/bench_in
 timeout 600 python bench.py --no-cpu-baseline --curve bn254 > gpurun_out/bench_bn254.log 2>&1
 timeout 600 python bench.py --no-cpu-baseline --tight > gpurun_out/bench_tight.log 2>&1
 timeout 600 python bench.py --no-cpu-baseline --log-n 18 > gpurun_out/bench_n18.log 2>&1
+timeout 300 tools/ubench.bin > gpurun_out/ubench.log 2>&1
 R=$PWD
 cd /tmp && export TMPDIR=/tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_stats -o r1 -- python $R/bench.py --no-cpu-baseline --inflight 1 --steps 5 --warmup 2 > $R/gpurun_out/rocprof_stats.log 2>&1

@@ -38,7 +38,7 @@ if "--json" in sys.argv:
         "launches": acc["FETCH_SIZE"][0],
         "fetch_bytes_per_launch": acc["FETCH_SIZE"][1] * 1024 / max(1, acc["FETCH_SIZE"][0]),
         "write_bytes_per_launch": acc["WRITE_SIZE"][1] * 1024 / max(1, acc["WRITE_SIZE"][0]),
-        "note": "FETCH_SIZE/WRITE_SIZE as counted (KiB->B); random 96/192-B gathers: no gfx950 doubling applied "
+        "note": "FETCH_SIZE/WRITE_SIZE as counted (KiB->B); random 128-B (G1, Affine28 rows) / 2x96-B (G2) gathers: no gfx950 doubling applied "
                 "(calibration in DESIGN.md section 3)",
     }
     json.dump(rec, open(out, "w"), indent=1)
