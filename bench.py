@@ -44,7 +44,7 @@ def parse_args():
     ap.add_argument("--tight", action="store_true", help="domain-tight variant n = 2^k - 100 (N = 2^k)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true", help="skip the closed-form proof check")
-    ap.add_argument("--inflight", type=int, default=3,
+    ap.add_argument("--inflight", type=int, default=4,
                     help="proofs in flight per GPU (independent contexts sharing the resident key; 1 = strictly serial)")
     return ap.parse_args()
 

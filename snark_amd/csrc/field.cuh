@@ -167,6 +167,55 @@ struct Fp {
     return reduce_once(r, t[N]);
   }
 
+#if !defined(__HIP_DEVICE_COMPILE__) && defined(__SIZEOF_INT128__)
+  // Host flavour: the same Montgomery product on 64-bit limbs (CIOS, 128-bit partial products); ~3x the speed of the
+  // 32-bit loop above on the EPYC host.  Used by the O(1) proof tail (two 255-bit scalar multiplications, three
+  // inversions) and by the host-side setup scalars; identical values (R = 2^(32N) = 2^(64 N/2)).
+  static Fp mul_h64(const Fp& a, const Fp& b) {
+    static_assert(N % 2 == 0, "even limb count");
+    constexpr int M = N / 2;
+    typedef unsigned __int128 u128;
+    uint64_t x[M], y[M], p[M], t[M + 2];
+    for (int i = 0; i < M; i++) {
+      x[i] = (uint64_t)a.l[2 * i] | ((uint64_t)a.l[2 * i + 1] << 32);
+      y[i] = (uint64_t)b.l[2 * i] | ((uint64_t)b.l[2 * i + 1] << 32);
+      p[i] = (uint64_t)P::mod(2 * i) | ((uint64_t)P::mod(2 * i + 1) << 32);
+    }
+    // -p^-1 mod 2^64 from the 32-bit constant by one Newton step: inv64 = inv32 * (2 + p0 * inv32)
+    const uint64_t inv32 = (uint64_t)P::INV;
+    const uint64_t inv64 = inv32 * (2 + p[0] * inv32);
+    for (int i = 0; i < M + 2; i++) t[i] = 0;
+    for (int i = 0; i < M; i++) {
+      u128 c = 0;
+      for (int j = 0; j < M; j++) {
+        c += (u128)x[j] * y[i] + t[j];
+        t[j] = (uint64_t)c;
+        c >>= 64;
+      }
+      c += t[M];
+      t[M] = (uint64_t)c;
+      t[M + 1] = (uint64_t)(c >> 64);
+      const uint64_t m = t[0] * inv64;
+      c = (u128)m * p[0] + t[0];
+      c >>= 64;
+      for (int j = 1; j < M; j++) {
+        c += (u128)m * p[j] + t[j];
+        t[j - 1] = (uint64_t)c;
+        c >>= 64;
+      }
+      c += t[M];
+      t[M - 1] = (uint64_t)c;
+      t[M] = t[M + 1] + (uint64_t)(c >> 64);
+    }
+    Fp r;
+    for (int i = 0; i < M; i++) {
+      r.l[2 * i] = (uint32_t)t[i];
+      r.l[2 * i + 1] = (uint32_t)(t[i] >> 32);
+    }
+    return reduce_once(r, (uint32_t)t[M]);
+  }
+#endif
+
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(ARK_NO_ASM_MUL)
   // gfx950 flavour: product scanning (FIPS) over a 96-bit column accumulator {top : acc}.  Every partial
   // product is ONE v_mad_u64_u32 (32x32 + 64 -> 64, carry-out in VCC) plus ONE v_addc_co_u32 that banks the
@@ -372,7 +421,13 @@ struct Fp {
     return reduce_once(r, (uint32_t)(acc >> 32));
   }
 #else
-  ARK_HD static Fp mul(const Fp& a, const Fp& b) { return mul_c(a, b); }
+  ARK_HD static Fp mul(const Fp& a, const Fp& b) {
+#if !defined(__HIP_DEVICE_COMPILE__) && defined(__SIZEOF_INT128__)
+    return mul_h64(a, b);
+#else
+    return mul_c(a, b);
+#endif
+  }
   ARK_HD static Fp mul2sum(const Fp& x1, const Fp& y1, const Fp& x2, const Fp& y2) {
     return add(mul_c(x1, y1), mul_c(x2, y2));
   }

@@ -238,8 +238,29 @@ static void prove_run(ark355_ctx* ctx, ProverScratch& sc, const PkDev& pk, const
   ARK_REQUIRE(pk.ell == r1.ell && pk.w == r1.w && pk.N == r1.N, ARK355_EINVAL,
               "proving key and R1CS dimensions differ");
   hipStream_t sM = ctx->stream;
-  for (hipStream_t* st : {&sc.sW, &sc.sS, &sc.sA, &sc.sR})
-    if (!*st) ARK_CHECK_HIP(hipStreamCreate(st));
+  // The short kernels that feed the accumulations (witness map, sorts) and the latency-bound reductions outrank the
+  // long accumulation launches: when workgroup slots free up, a waiting NTT pass or sort of ANOTHER proof in flight
+  // is dispatched before the next round of accumulation workgroups, which keeps an accumulation queued at all times.
+  // ARK355_STREAM_PRIO=0 turns it off (A/B).
+  static const bool prio = [] {
+    const char* e = getenv("ARK355_STREAM_PRIO");
+    return !(e && e[0] == '0');
+  }();
+  int prio_lo = 0, prio_hi = 0;
+#if !defined(ARK_EMUL)
+  if (prio) (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);     // hi is the numerically smaller value
+#endif
+  for (hipStream_t* st : {&sc.sW, &sc.sS, &sc.sR}) {
+    if (*st) continue;
+#if !defined(ARK_EMUL)
+    if (prio && prio_hi != prio_lo) {
+      ARK_CHECK_HIP(hipStreamCreateWithPriority(st, hipStreamDefault, prio_hi));
+      continue;
+    }
+#endif
+    ARK_CHECK_HIP(hipStreamCreate(st));
+  }
+  if (!sc.sA) ARK_CHECK_HIP(hipStreamCreate(&sc.sA));      // default = lowest of the two levels gfx950 exposes
   const char* serial = getenv("ARK355_SERIAL");
   const bool one_stream = serial && serial[0] == '1';
   hipStream_t sW = one_stream ? sM : sc.sW, sS = one_stream ? sM : sc.sS, sA = one_stream ? sM : sc.sA,
