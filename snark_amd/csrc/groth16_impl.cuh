@@ -20,6 +20,7 @@
 // library's own host-compiled field code finishes the proof; ARK355_DEVICE_FINALIZE=1 keeps it on the device
 // (groth16_finalize_kernel) and must give the same bytes.
 #pragma once
+#include <chrono>
 #include <future>
 #include "common.h"
 #include "msm_impl.cuh"
@@ -237,6 +238,15 @@ static void prove_run(ark355_ctx* ctx, ProverScratch& sc, const PkDev& pk, const
   ARK_REQUIRE(pk.curve == Curve::ID && r1.curve == Curve::ID, ARK355_EINVAL, "curve mismatch");
   ARK_REQUIRE(pk.ell == r1.ell && pk.w == r1.w && pk.N == r1.N, ARK355_EINVAL,
               "proving key and R1CS dimensions differ");
+  const auto t_enter = std::chrono::steady_clock::now();
+  auto since = [&](std::chrono::steady_clock::time_point t) {
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count();
+  };
+  static const bool trace_host = [] {
+    const char* e = getenv("ARK355_TRACE_HOST");
+    return e && e[0] == '1';
+  }();
+  double t_launched = 0, t_synced = 0, t_tail = 0;
   hipStream_t sM = ctx->stream;
   // The short kernels that feed the accumulations (witness map, sorts) and the latency-bound reductions outrank the
   // long accumulation launches: when workgroup slots free up, a waiting NTT pass or sort of ANOTHER proof in flight
@@ -373,8 +383,11 @@ static void prove_run(ark355_ctx* ctx, ProverScratch& sc, const PkDev& pk, const
       ARK_CHECK_HIP(hipMemcpyAsync(h1, g1res, sizeof(h1), hipMemcpyDeviceToHost, sR));
       ARK_CHECK_HIP(hipMemcpyAsync(&h2, g2res, sizeof(h2), hipMemcpyDeviceToHost, sR));
       ARK_CHECK_HIP(hipEventRecord(ev[E_END], sR));
+      t_launched = since(t_enter);
       ARK_CHECK_HIP(hipStreamSynchronize(sR));
+      t_synced = since(t_enter);
       finalize_host<Curve>(h1, h2, rc, scn, out);
+      t_tail = since(t_enter);
     }
     // every stream has drained into sR through the event chain; make the host view consistent
     ARK_CHECK_HIP(hipStreamSynchronize(sA));
@@ -386,6 +399,10 @@ static void prove_run(ark355_ctx* ctx, ProverScratch& sc, const PkDev& pk, const
       return ms;
     };
     // phases overlap across streams: the entries are elapsed times of the respective stream segments
+    if (trace_host)
+      fprintf(stderr, "[ark355] prove host wall: all work queued %.2f ms, GPU drained %.2f ms, host tail done %.2f ms, "
+                      "epilogue %.2f ms; GPU span %.2f ms\n",
+              t_launched, t_synced, t_tail, since(t_enter), el(ev[E_START], ev[E_END]));
     ctx->timings.total_ms = el(ev[E_START], ev[E_END]);
     ctx->timings.h2d_ms = el(ev[E_START], ev[E_Z]);
     ctx->timings.witness_map_ms = el(ev[E_Z], ev[E_H]);
