@@ -5,7 +5,8 @@
 // kernel's VALU instructions are carry bookkeeping (round-1 ISA listing).  With 28-bit limbs a column of a
 // 14-limb product-scanning pass (<= 14 a*b + 14 m*p products of < 2^60) fits a 64-bit accumulator with room to
 // spare: NO carry instruction at all, no per-product reduce_once, and additions/subtractions become limb-wise
-// (lazy) operations.  BLS12-381 Fq: 392 mad + 68 other VALU instead of 300 mad + 300 addc + ~50.
+// (lazy) operations.  (hipcc starts each column on a second accumulator and joins the two with one 64-bit add;
+// forcing a single dependent chain was measured: no difference.)  BLS12-381 Fq: 392 mad + 68 other VALU instead of 300 mad + 300 addc + ~50.
 //
 // Representation.  N = 14 (BLS12-381 Fq) / 10 (BN254 Fq) limbs, value = sum l[i] 2^(28 i), Montgomery radix
 // R' = 2^(28 N) (R' = R * 2^SHIFT with R = 2^(32 NB) of field.cuh).  Values are NOT kept canonical:
