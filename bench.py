@@ -29,9 +29,9 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 # Secondary, integer roofline of the bucket-accumulation kernels.  The scarce instruction is v_mad_u64_u32: the
 # whole chip issues 28.8 T of them per second (tools/ubench.hip, profiles/r01_ubench_*.txt: 46.8 per clock per CU).
 # Multiply-adds per mixed addition are read off the ISA of the shipped kernels (tools/isa_blocks.py, hot blocks):
-#   G1 on radix-2^28 limbs (msm_accumulate28_kernel), G2 lane-split on 32-bit limbs (two lanes per addition).
+#   G1 and lane-split G2 (two lanes per addition) on radix-2^28 limbs (msm_accumulate28_kernel, msm_accumulate_g2l28_kernel).
 MAD_PEAK_T = 28.8
-MADS_PER_ADD = {"bls12_381": {"g1": 3542, "g2": 2 * 3888}, "bn254": {"g1": 1720, "g2": 2 * 1728}}
+MADS_PER_ADD = {"bls12_381": {"g1": 3542, "g2": 2 * 5292}, "bn254": {"g1": 1720, "g2": 2 * 2610}}
 
 
 def parse_args():

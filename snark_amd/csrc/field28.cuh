@@ -88,6 +88,24 @@ struct Fp28 {
     return t.v[i];
   }
 
+  // Register image for values RETURNED by out-of-line (cold) functions of the bucket kernels: a vector type comes back
+  // in VGPRs, a struct of N limbs through a hidden pointer -- and `acc.x = cold_call()` then hands the address of the
+  // hot loop's accumulator to the callee, which keeps the whole accumulator in scratch memory.
+  typedef uint32_t Vec __attribute__((vector_size(64)));
+  static_assert(N <= 16, "Vec holds 16 limbs");
+  ARK_HD Vec to_vec() const {
+    Vec v = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < N; i++) v[i] = l[i];
+    return v;
+  }
+  ARK_HD static Fp28 from_vec(const Vec& v) {
+    Fp28 r;
+#pragma unroll
+    for (int i = 0; i < N; i++) r.l[i] = v[i];
+    return r;
+  }
+
   ARK_HD static Fp28 zero() {
     Fp28 r;
 #pragma unroll
@@ -307,6 +325,17 @@ struct Fp28 {
     return r;
   }
   ARK_HD_NOINLINE static bool is_zero_mod_p(Fp28 a) { return canon(a).limbs_all_zero(); }
+  // Inlined flavour for the bucket kernels: a CALL with the accumulator live across it forces those values into the
+  // few callee-saved VGPRs; they did not fit, and hipcc kept one accumulator coordinate in scratch for the whole loop.
+  ARK_HD static bool is_zero_mod_p_inl(const Fp28& a) {
+    Fp28 r = norm(a);
+    r = cond_sub<16>(r);
+    r = cond_sub<8>(r);
+    r = cond_sub<4>(r);
+    r = cond_sub<2>(r);
+    r = cond_sub<1>(r);
+    return r.limbs_all_zero();
+  }
 
   // x R mod p (32-bit Montgomery form, canonical)  ->  x R' mod p, normalised 28-bit limbs, canonical
   ARK_HD_NOINLINE static Fp28 from_fp(Base xin) {

@@ -59,15 +59,15 @@ ARK_HD_NOINLINE int madd28_classify(Fp28<P> pd, Fp28<P> r) {
 // called once per coordinate so that arguments and result travel in registers: a by-value / sret Acc28 made hipcc
 // keep the hot loop's accumulator in scratch memory (round-1 ISA listing: ~90 scratch accesses per mixed addition).
 template <class P>
-ARK_HD_NOINLINE Fp28<P> dbl28_coord_ni(Fp28<P> px, Fp28<P> py, int which) {
+ARK_HD_NOINLINE typename Fp28<P>::Vec dbl28_coord_ni(Fp28<P> px, Fp28<P> py, int which) {
   using F = Fp28<P>;
   const Affine<Fp<P>> a{F::to_fp(px), F::to_fp(py)};
   const XYZZ<Fp<P>> d = xyzz_dbl_affine_t<true>(a);
-  return F::from_fp(which == 0 ? d.x : which == 1 ? d.y : which == 2 ? d.zz : d.zzz);
+  return F::from_fp(which == 0 ? d.x : which == 1 ? d.y : which == 2 ? d.zz : d.zzz).to_vec();
 }
 template <class P>
-ARK_HD_NOINLINE Fp28<P> one28_ni() {
-  return Fp28<P>::from_fp(Fp<P>::one());
+ARK_HD_NOINLINE typename Fp28<P>::Vec one28_ni() {
+  return Fp28<P>::from_fp(Fp<P>::one()).to_vec();
 }
 
 // acc += (px, +-py).  Value/limb classes (field28.cuh): table coordinates are canonical; acc.x is normalised and
@@ -89,7 +89,7 @@ ARK_D void madd28(Acc28<P>& acc, bool& empty, const Fp28<P>& px, const Fp28<P>& 
     for (int i = 0; i < F::N; i++) pys.l[i] = negate ? n.l[i] : py.l[i];
   }
   if (empty) {
-    const F one = one28_ni<P>();
+    const F one = F::from_vec(one28_ni<P>());
     acc.x = px;
     acc.y = F::norm(pys);
     acc.zz = one;
@@ -105,10 +105,10 @@ ARK_D void madd28(Acc28<P>& acc, bool& empty, const Fp28<P>& px, const Fp28<P>& 
     const int cls = madd28_classify<P>(Pd, R);
     if (cls == 1) {
       const F yn = F::norm(pys);
-      acc.x = dbl28_coord_ni<P>(px, yn, 0);
-      acc.y = dbl28_coord_ni<P>(px, yn, 1);
-      acc.zz = dbl28_coord_ni<P>(px, yn, 2);
-      acc.zzz = dbl28_coord_ni<P>(px, yn, 3);
+      acc.x = F::from_vec(dbl28_coord_ni<P>(px, yn, 0));
+      acc.y = F::from_vec(dbl28_coord_ni<P>(px, yn, 1));
+      acc.zz = F::from_vec(dbl28_coord_ni<P>(px, yn, 2));
+      acc.zzz = F::from_vec(dbl28_coord_ni<P>(px, yn, 3));
       if (acc.zz.limbs_all_zero()) empty = true;       // 2P = infinity (no such point on these curves)
       return;
     }
@@ -158,7 +158,8 @@ msm_accumulate28_kernel(const Affine28<P>* __restrict__ bases, const uint32_t* _
   acc.y = F::zero();
   acc.zz = F::zero();
   acc.zzz = F::zero();
-  auto flush = [&](uint32_t key, uint32_t run_end) {
+  // always_inline: a closure that is inlined late keeps every captured variable (the accumulator!) in scratch memory
+  auto flush = [&](uint32_t key, uint32_t run_end) __attribute__((always_inline)) {
     XYZZ<Fq> out = XYZZ<Fq>::inf();
     if (!empty) {
       out.x = F::to_fp(acc.x);
@@ -224,11 +225,11 @@ msm_accumulate28_kernel(const Affine28<P>* __restrict__ bases, const uint32_t* _
 // G2: lane-split accumulation on 28-bit limbs.  Two lanes per segment (even: c0 components, odd: c1 components of
 // every Fq2 value, as in msm_accumulate_g2l_kernel); a table row is two Affine28 halves, {x.c0, y.c0} then
 // {x.c1, y.c1}, so that each lane gathers one aligned half.
-// OPT-IN (ARK355_G2_LIMB28=1): measured on MI355X it only ties with the 32-bit lane-split kernel (9.12 vs 9.11 ms
-// per 2^20-term MSM).  The multiply-add is the scarce instruction (5.5 cycles per wave) and the fused dual-product
-// pass needs 588 of them on 14 limbs against 444 on 12, which eats what the missing carry instructions save; the
-// G1 kernel, whose single-product passes go from 300 mad + 300 addc to 392 mad, gains 14%.
-// ================================================================================================================
+// Measured on MI355X: 9.2 ms per 2^20-term MSM against 10.8 ms for the 32-bit lane-split kernel (same box, both
+// interleaved with the witness map) -- once the accumulator really lived in registers.  The first version of this
+// kernel only tied: its flush picked the destination with a select among captured pointers, hipcc turned that into an
+// indexed load from the lambda's closure object, the closure could not be scalarised, and EVERY captured variable (the
+// accumulator included) stayed in scratch memory: 28 x 16-byte scratch accesses per mixed addition.
 #ifndef ARK_G2L28_FUSE_Y3
 #define ARK_G2L28_FUSE_Y3 1
 #endif
@@ -310,21 +311,30 @@ struct Pair28 {
   }
 };
 
-// One coordinate of 2 * (x, y) for the pair's point through the canonical Fq2 formulas (both lanes compute it, each
-// keeps its half); per coordinate for the same reason as dbl28_coord_ni.
+// One coordinate (0: x, 1: y, 2: zz, 3: zzz) of 2 * (x, y) for the pair's point (mdbl-2008-s-1), computed with the
+// same lane-split 28-bit arithmetic as the mixed addition.  Cold path (P == acc), called once per coordinate so that
+// arguments and result travel in registers.  Its register footprint matters: the kernel's VGPR budget is the maximum
+// over its callees, and a version that went through the canonical Fq2 formulas (256 VGPRs, 56 argument registers)
+// both capped the kernel at two waves per SIMD and made the allocator keep the hot loop's accumulator in scratch.
+//   U = 2y, V = U^2, W = U V, S = x V, M = 3 x^2, X3 = M^2 - 2S, Y3 = M (S - X3) - W y, ZZ = V, ZZZ = W
+// x canonical, y normalised and < 2p.
 template <class P>
-ARK_HD_NOINLINE Fp28<P> dbl28_g2_coord_ni(Fp28<P> x_own, Fp28<P> x_other, Fp28<P> y_own, Fp28<P> y_other,
-                                          bool is_odd, int which) {
+ARK_HD_NOINLINE typename Fp28<P>::Vec dbl28_g2_coord_ni(Fp28<P> x, Fp28<P> y, int which) {
   using F = Fp28<P>;
-  const Fp<P> xo = F::to_fp(x_own), xp = F::to_fp(x_other), yo = F::to_fp(y_own), yp = F::to_fp(y_other);
-  Affine<Fp2<P>> a;
-  a.x.c0 = is_odd ? xp : xo;
-  a.x.c1 = is_odd ? xo : xp;
-  a.y.c0 = is_odd ? yp : yo;
-  a.y.c1 = is_odd ? yo : yp;
-  const XYZZ<Fp2<P>> d = xyzz_dbl_affine_t<true>(a);
-  const Fp2<P> c = which == 0 ? d.x : which == 1 ? d.y : which == 2 ? d.zz : d.zzz;
-  return F::from_fp(is_odd ? c.c1 : c.c0);
+  using L = Pair28<P>;
+  const F U = F::norm(F::add(y, y));                                   // < 4p
+  const F V = L::template sqr<6>(U);
+  if (which == 2) return V.to_vec();
+  const F W = L::template mul<6, 1>(U, V);
+  if (which == 3) return W.to_vec();
+  const F S = L::template mul<2, 1>(x, V);
+  const F X2 = L::template sqr<3>(x);
+  const F M = F::norm(F::add(X2, F::add(X2, X2)));                     // < 3.6p
+  const F X3 = F::norm(F::add(L::template sqr<5>(M), F::template neg<4, 2>(F::add(S, S))));   // < 5.2p
+  if (which == 0) return X3.to_vec();
+  const F T = F::norm(F::template sub<8, 1>(S, X3));
+  const F NW = F::template neg<3, 1>(W);
+  return L::template mul2<5, 1, 4, 3>(M, T, NW, y).to_vec();
 }
 
 // acc += (px, +-py) over Fq2, one component per lane.  Same formula and value classes as madd28; Pd, R and
@@ -336,7 +346,7 @@ ARK_D void madd28_g2(Acc28<P>& acc, bool& empty, const Fp28<P>& px, const Fp28<P
   using L = Pair28<P>;
   const F pys = L::sel(negate, F::template neg<2, 1>(py), py);
   if (empty) {
-    const F one = L::odd() ? F::zero() : one28_ni<P>();
+    const F one = L::odd() ? F::zero() : F::from_vec(one28_ni<P>());
     acc.x = px;
     acc.y = F::norm(pys);
     acc.zz = one;
@@ -349,14 +359,13 @@ ARK_D void madd28_g2(Acc28<P>& acc, bool& empty, const Fp28<P>& px, const Fp28<P
   const F Pd = F::norm(F::template sub<8, 1>(U2, acc.x));
   const F R = F::norm(F::template sub<3, 1>(S2, acc.y));
   if (L::both(Pd.multiple_hint() < 10u)) {
-    if (L::both(F::is_zero_mod_p(Pd))) {
-      if (L::both(F::is_zero_mod_p(R))) {
+    if (L::both(F::is_zero_mod_p_inl(Pd))) {
+      if (L::both(F::is_zero_mod_p_inl(R))) {
         const F yn = F::norm(pys);
-        const F pxo = L::xchg(px), yno = L::xchg(yn);
-        acc.x = dbl28_g2_coord_ni<P>(px, pxo, yn, yno, L::odd(), 0);
-        acc.y = dbl28_g2_coord_ni<P>(px, pxo, yn, yno, L::odd(), 1);
-        acc.zz = dbl28_g2_coord_ni<P>(px, pxo, yn, yno, L::odd(), 2);
-        acc.zzz = dbl28_g2_coord_ni<P>(px, pxo, yn, yno, L::odd(), 3);
+        acc.x = F::from_vec(dbl28_g2_coord_ni<P>(px, yn, 0));
+        acc.y = F::from_vec(dbl28_g2_coord_ni<P>(px, yn, 1));
+        acc.zz = F::from_vec(dbl28_g2_coord_ni<P>(px, yn, 2));
+        acc.zzz = F::from_vec(dbl28_g2_coord_ni<P>(px, yn, 3));
         if (L::both(acc.zz.limbs_all_zero())) empty = true;
       } else {
         empty = true;
@@ -414,7 +423,8 @@ msm_accumulate_g2l28_kernel(const Affine28G2<P>* __restrict__ bases, const uint3
   acc.y = F::zero();
   acc.zz = F::zero();
   acc.zzz = F::zero();
-  auto flush = [&](uint32_t key, uint32_t run_end) {
+  // always_inline: a closure that is inlined late keeps every captured variable (the accumulator!) in scratch memory
+  auto flush = [&](uint32_t key, uint32_t run_end) __attribute__((always_inline)) {
     // this lane's halves of the four Fq2 coordinates, canonical 32-bit form
     XYZZ<Fq> mine = XYZZ<Fq>::inf();
     if (!empty) {
@@ -425,15 +435,24 @@ msm_accumulate_g2l28_kernel(const Affine28G2<P>* __restrict__ bases, const uint3
     }
     const uint32_t o = offsets[key], cnt = counts[key];
     const bool complete = (run_start == o) && (run_end == o + cnt);
-    XYZZ<Fp2<P>>* dst = complete ? &buckets[key] : (first_run ? &head[seg] : &tail[seg]);
-    Fq* d = reinterpret_cast<Fq*>(dst);
-    d[0 + par] = mine.x;
-    d[2 + par] = mine.y;
-    d[4 + par] = mine.zz;
-    d[6 + par] = mine.zzz;
-    if (!complete && par == 0) {
-      if (first_run) head_key[seg] = key;
-      else tail_key[seg] = key;
+    // three explicit branches, NOT a select among the captured pointers: hipcc turns such a select into an indexed
+    // load from the closure object, which then cannot be scalarised -- and every captured variable, the accumulator
+    // included, lives in scratch memory for the whole loop (28 x 16-byte scratch accesses per mixed addition)
+    auto store = [&](XYZZ<Fp2<P>>* dst) __attribute__((always_inline)) {
+      Fq* d = reinterpret_cast<Fq*>(dst);
+      d[0 + par] = mine.x;
+      d[2 + par] = mine.y;
+      d[4 + par] = mine.zz;
+      d[6 + par] = mine.zzz;
+    };
+    if (complete) {
+      store(&buckets[key]);
+    } else if (first_run) {
+      store(&head[seg]);
+      if (par == 0) head_key[seg] = key;
+    } else {
+      store(&tail[seg]);
+      if (par == 0) tail_key[seg] = key;
     }
   };
   for (uint32_t e = start; e < end; e++) {

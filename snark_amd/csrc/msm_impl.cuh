@@ -889,11 +889,11 @@ struct PrecompTable {
 #ifndef ARK_LIMB28_DEFAULT
 #define ARK_LIMB28_DEFAULT 1
 #endif
-// ARK355_LIMB28=0|1 (default 1): G1 window tables and bucket accumulation in the radix-2^28 form (msm28_impl.cuh).
-// ARK355_G2_LIMB28=0|1 (default 0): the same for G2 (lane-split); it only ties with the 32-bit lane-split kernel.
+// ARK355_LIMB28=0|1 / ARK355_G2_LIMB28=0|1 (both default 1): window tables and bucket accumulation of G1 / G2 in the
+// radix-2^28 form (msm28_impl.cuh); 0 keeps the 32-bit kernels (A/B switches, exercised by the tests).
 static inline bool msm_use_limb28(bool g2) {       // read when a table is built (not cached: tests flip it)
   const char* e = getenv(g2 ? "ARK355_G2_LIMB28" : "ARK355_LIMB28");
-  return e ? (e[0] == '1') : (g2 ? false : ARK_LIMB28_DEFAULT != 0);
+  return e ? (e[0] == '1') : (ARK_LIMB28_DEFAULT != 0);
 }
 
 template <class F, class Fr>

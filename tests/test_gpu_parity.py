@@ -63,9 +63,10 @@ def test_resident_tables_exceptional_additions(gpu_lib, gpu_ctx, C, group, n):
     pc.resident_msm_edge_case(gpu_lib, gpu_ctx, C, group, n, to_dev)
 
 
-@pytest.mark.parametrize("env", [{"ARK355_G2_LIMB28": "1"}, {"ARK355_LIMB28": "0"}], ids=["g2-28bit", "g1-32bit"])
+@pytest.mark.parametrize("env", [{"ARK355_G2_LIMB28": "0"}, {"ARK355_LIMB28": "0"}], ids=["g2-32bit", "g1-32bit"])
 def test_resident_tables_alternate_limb_forms(gpu_lib, gpu_ctx, monkeypatch, env):
-    """The opt-in 28-bit lane-split G2 kernel and the 32-bit G1 kernel over window tables (the A/B switches)."""
+    """The 32-bit lane-split G2 kernel and the 32-bit G1 kernel over window tables (the A/B switches; the defaults
+    are the radix-2^28 kernels)."""
     import numpy as np
     import torch
     for k, v in env.items():
