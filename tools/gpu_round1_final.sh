@@ -15,7 +15,10 @@ cd /tmp && export TMPDIR=/tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_stats -o r1 -- python $R/bench.py --no-cpu-baseline --inflight 1 --steps 5 --warmup 2 > $R/gpurun_out/rocprof_stats.log 2>&1
 timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/prof_fetch -o r1 -- python $R/bench.py --steps 1 --warmup 0 --inflight 1 --no-cpu-baseline --no-check > $R/gpurun_out/rocprof_fetch.log 2>&1
 timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/prof_write -o r1 -- python $R/bench.py --steps 1 --warmup 0 --inflight 1 --no-cpu-baseline --no-check > $R/gpurun_out/rocprof_write.log 2>&1
+ARK355_SERIAL=1 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/serial -o serial -- python $R/bench.py --no-cpu-baseline --inflight 1 --steps 5 --warmup 2 > $R/gpurun_out/serial_bench.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/trace -o t -- python $R/bench.py --no-cpu-baseline --steps 12 --warmup 4 > $R/gpurun_out/trace_bench.log 2>&1
 cd $R
+python tools/trace_analyze.py gpurun_out/trace/t_kernel_trace.csv 12 > gpurun_out/timeline_summary.txt 2>&1
 python tools/pmc_summary.py --json gpurun_out/pmc_latest.json --workload "bls12_381:n=1048576" > gpurun_out/pmc_summary.log 2>&1
 find gpurun_out -name "*kernel_trace.csv" -size +20M -delete
 find gpurun_out -name "*counter_collection.csv" -size +20M -delete
