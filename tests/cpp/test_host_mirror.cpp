@@ -7,6 +7,7 @@
 //        proof / vk bytes so that the pytest side can compare them with the oracle.
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <string>
 
 #include "../../snark_amd/host/snark.hpp"
@@ -80,6 +81,150 @@ struct MulChain : ConstraintSynthesizer<F> {
     cs.enforce_r1cs_constraint([&] { return L() + ws[n]; }, [&] { return L() + Variable::One(); }, [&] { return L() + x1; });
   }
 };
+
+// splitmix64 stream of SURVEY.md 8d (same generator as oracle/synthetic.py)
+struct SplitMix64 {
+  uint64_t s;
+  explicit SplitMix64(uint64_t seed) : s(seed) {}
+  uint64_t next() {
+    s += 0x9E3779B97F4A7C15ull;
+    uint64_t z = s;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+  }
+  // four little-endian u64 limbs -> integer mod r
+  template <class F>
+  F next_fr() {
+    uint64_t l[4];
+    for (int i = 0; i < 4; i++) l[i] = next();
+    const F t32 = F::from_u64(1ull << 32), t64 = t32 * t32;
+    F v = F::from_u64(l[3]);
+    for (int i = 2; i >= 0; i--) v = v * t64 + F::from_u64(l[i]);
+    return v;
+  }
+};
+
+// S3 "bench-LC" (shape of relations/examples/bench.rs:13,36-56 made satisfiable): LCs of 1..=10 terms
+// with random coefficients over the 10 most recent variables, c_i a fresh witness.  Same stream order as
+// oracle/synthetic.py:bench_lc_cs, so the two constraint systems are identical.
+template <class F>
+struct BenchLc : ConstraintSynthesizer<F> {
+  size_t n;
+  uint64_t seed;
+  BenchLc(size_t n_, uint64_t seed_ = 0x355) : n(n_), seed(seed_) {}
+  void generate_constraints(ConstraintSystemRef<F> cs) override {
+    using L = LinearCombination<F>;
+    SplitMix64 rng(seed);
+    std::vector<Variable> vars;
+    std::vector<F> vals;                      // value of vars[i]
+    for (int i = 0; i < 10; i++) {
+      F v = rng.next_fr<F>();
+      vars.push_back(cs.new_witness_variable([&] { return v; }));
+      vals.push_back(v);
+    }
+    vars.push_back(cs.new_input_variable([] { return F::from_u64(7); }));
+    vals.push_back(F::from_u64(7));
+    auto rand_lc = [&](std::vector<std::pair<F, Variable>>& terms) {
+      const size_t k = 1 + rng.next() % 10;
+      const size_t base = vars.size() - 10;
+      F acc = F::zero();
+      terms.clear();
+      for (size_t j = 0; j < k; j++) {
+        F c = rng.next_fr<F>();
+        const size_t idx = base + rng.next() % 10;
+        terms.push_back({c, vars[idx]});
+        acc = acc + c * vals[idx];
+      }
+      return acc;
+    };
+    std::vector<std::pair<F, Variable>> ta, tb;
+    for (size_t i = 0; i < n; i++) {
+      const F va = rand_lc(ta);
+      const F vb = rand_lc(tb);
+      const F cval = va * vb;
+      const Variable cvar = cs.new_witness_variable([&] { return cval; });
+      vars.push_back(cvar);
+      vals.push_back(cval);
+      auto mk = [](const std::vector<std::pair<F, Variable>>& t) {
+        L lc;
+        for (const auto& cv : t) lc = lc + cv;
+        return lc;
+      };
+      cs.enforce_r1cs_constraint([&] { return mk(ta); }, [&] { return mk(tb); }, [&] { return L() + cvar; });
+    }
+  }
+};
+
+// The reference's own synthesis benchmark circuit (relations/examples/bench.rs:16-83): unit coefficients, an extra
+// symbolic LC on every other constraint, three fresh witnesses per constraint.  Timing only (not satisfiable); the
+// pseudo-random choices come from splitmix64 instead of the reference's StdRng.
+template <class F>
+struct RefBenchCircuit : ConstraintSynthesizer<F> {
+  F a;
+  size_t n;
+  RefBenchCircuit(F a_, size_t n_) : a(a_), n(n_) {}
+  void generate_constraints(ConstraintSystemRef<F> cs) override {
+    using L = LinearCombination<F>;
+    std::vector<Variable> vars;
+    for (int i = 0; i < 3; i++) vars.push_back(cs.new_witness_variable([&] { return a; }));
+    vars.reserve(3 * n + 3);
+    SplitMix64 ra(0), rb(1), rc(2);
+    for (size_t i = 0; i < n; i++) {
+      const size_t cur = vars.size() < 10 ? vars.size() : 10, lower = vars.size() - cur;
+      const size_t ka = 1 + ra.next() % 10, kb = 1 + rb.next() % 10;
+      auto pick = [&](SplitMix64& r, size_t k) {
+        L lc;
+        for (size_t j = 0; j < k; j++) lc = lc + vars[lower + r.next() % cur];
+        return lc;
+      };
+      const Variable ci = vars[lower + rc.next() % cur];
+      if (i % 2 == 0) {
+        const Variable extra = cs.new_lc([&] { return pick(rc, ka); });
+        cs.enforce_r1cs_constraint([&] { return pick(ra, ka) + extra; }, [&] { return pick(rb, kb); },
+                                   [&] { return L() + ci; });
+      } else {
+        cs.enforce_r1cs_constraint([&] { return pick(ra, ka); }, [&] { return pick(rb, kb); }, [&] { return L() + ci; });
+      }
+      for (int j = 0; j < 3; j++) vars.push_back(cs.new_witness_variable([&] { return a; }));
+    }
+  }
+};
+
+static void test_bench_lc_is_satisfied() {
+  BenchLc<Fr> c(50);
+  auto cs = ConstraintSystemRef<Fr>::new_ref();
+  c.generate_constraints(cs);
+  CHECK(cs.num_constraints() == 50 && cs.num_instance_variables() == 2 && cs.num_witness_variables() == 60);
+  cs.finalize();
+  CHECK(cs.is_satisfied());
+}
+
+// host synthesis throughput: the reference's examples/bench.rs measurement -- generate_constraints
+// in Prove{construct_matrices: true} mode, then finalize -- plus to_matrices, on this machine's host
+template <class F>
+static int run_synth_bench(size_t n) {
+  RefBenchCircuit<F> circ(F::from_u64(0x1234567), n);
+  auto cs = ConstraintSystemRef<F>::new_ref();
+  cs.set_optimization_goal(OptimizationGoal::Constraints);
+  cs.set_mode(SynthesisMode::prove(true, false));
+  auto t0 = std::chrono::steady_clock::now();
+  circ.generate_constraints(cs);
+  auto t1 = std::chrono::steady_clock::now();
+  cs.finalize();
+  auto t2 = std::chrono::steady_clock::now();
+  auto m = cs.to_matrices().at("R1CS");
+  auto t3 = std::chrono::steady_clock::now();
+  size_t nnz = 0;
+  for (int k = 0; k < 3; k++)
+    for (const auto& row : m[k]) nnz += row.size();
+  auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+  printf("synth_constraints=%zu\nsynth_witnesses=%zu\nsynth_nnz=%zu\n", (size_t)cs.num_constraints(),
+         (size_t)cs.num_witness_variables(), nnz);
+  printf("synth_generate_ms=%.3f\nsynth_finalize_ms=%.3f\nsynth_to_matrices_ms=%.3f\n", ms(t0, t1), ms(t1, t2), ms(t2, t3));
+  printf("synth_constraints_per_s=%.0f\n", n / (ms(t0, t2) * 1e-3));
+  return 0;
+}
 
 static void test_circuit2_matrices() {
   // gr1cs/tests/mod.rs:136-147 against circuit2.rs:19-43
@@ -184,6 +329,7 @@ static int run_prove(const std::string& circuit, size_t n) {
   typename G::Rng rng = [&]() { return F::from_u64(seq[pos++]); };
   std::unique_ptr<ConstraintSynthesizer<F>> circ;
   if (circuit == "dummy") circ.reset(new DummyCircuit<F>(F::from_u64(3), F::from_u64(5), n, n));
+  else if (circuit == "benchlc") circ.reset(new BenchLc<F>(n));
   else circ.reset(new MulChain<F>(F::from_u64(0x355), F::from_u64(0x356), n));
   auto keys = groth.circuit_specific_setup(*circ, rng);
   auto proof = groth.prove(keys.first, *circ, rng);
@@ -229,7 +375,13 @@ int main(int argc, char** argv) {
       return 2;
     }
   }
+  if (argc >= 4 && std::string(argv[1]) == "--synth-bench") {
+    const size_t n = strtoull(argv[3], nullptr, 10);
+    if (std::string(argv[2]) == "bn254") return run_synth_bench<ark_snark::Field<ark355::BnFr>>(n);
+    return run_synth_bench<Fr>(n);
+  }
   test_circuit2_matrices();
+  test_bench_lc_is_satisfied();
   test_variable_ordering();
   test_dummy_circuit_synthesizes();
   test_modes_and_quirks();

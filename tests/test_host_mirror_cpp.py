@@ -31,13 +31,27 @@ def test_cpp_mirror_cpu_checks(exe):
     assert "all CPU checks passed" in out.stdout
 
 
+def test_cpp_host_synthesis_benchmark(exe):
+    """the reference's examples/bench.rs measurement on the C++ mirror (generate_constraints in
+    Prove{construct_matrices} mode + finalize).  Checks the shape of the synthesised system; the rate is reported,
+    not asserted."""
+    n = 1 << 13
+    out = subprocess.run([exe, "--synth-bench", "bls12_381", str(n)], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    kv = dict(line.split("=", 1) for line in out.stdout.strip().splitlines())
+    assert int(kv["synth_constraints"]) == n
+    assert int(kv["synth_witnesses"]) == 3 + 3 * n
+    assert 3 * n <= int(kv["synth_nnz"]) <= 31 * n
+    assert float(kv["synth_constraints_per_s"]) > 0
+
+
 def _parse(out):
     return {k: bytes.fromhex(v) for k, v in (line.split("=", 1) for line in out.strip().splitlines() if "=" in line)}
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("curve_name,circuit,n", [("bls12_381", "dummy", 64), ("bls12_381", "mulchain", 100),
-                                                  ("bn254", "mulchain", 37)])
+                                                  ("bn254", "mulchain", 37), ("bls12_381", "benchlc", 40)])
 def test_cpp_snark_trait_prove_matches_oracle(exe, curve_name, circuit, n):
     from oracle import groth16 as G, serialize as Z, synthetic as S
     from oracle.fields import CURVES
@@ -48,6 +62,8 @@ def test_cpp_snark_trait_prove_matches_oracle(exe, curve_name, circuit, n):
     got = _parse(r.stdout)
     if circuit == "dummy":
         A, B, Cm, z, ell = S.cs_to_instance(S.dummy_cs(C.r, n))
+    elif circuit == "benchlc":          # S3: random coefficients, repeated columns (same splitmix64 stream in C++)
+        A, B, Cm, z, ell = S.cs_to_instance(S.bench_lc_cs(C.r, n))
     else:
         A, B, Cm, z, ell = S.mulchain_direct(C.r, n, start=(0x355, 0x356))
     td = G.Trapdoor(tau=0x1234567, alpha=11, beta=22, gamma=33, delta=44)
