@@ -23,7 +23,8 @@
 namespace ark355 {
 
 #if defined(ARK_EMUL)
-// emulator builds check every 64-bit column accumulator against a 128-bit shadow (bounds analysis is enforced)
+// emulator builds check every 64-bit column accumulator against a 128-bit shadow and every lazy limb operation
+// against wrap-around: the bounds analysis written next to the formulas is enforced, not assumed
 #define ARK_F28_CHECK 1
 #endif
 
@@ -123,7 +124,12 @@ struct Fp28 {
   ARK_HD static Fp28 add(const Fp28& a, const Fp28& b) {
     Fp28 r;
 #pragma unroll
-    for (int i = 0; i < N; i++) r.l[i] = a.l[i] + b.l[i];
+    for (int i = 0; i < N; i++) {
+#if ARK_F28_CHECK
+      if ((uint64_t)a.l[i] + b.l[i] > 0xFFFFFFFFull) __builtin_trap();
+#endif
+      r.l[i] = a.l[i] + b.l[i];
+    }
     return r;
   }
   // a - b + K p   (b: limbs <= BETA (2^28 - 1), value < (K - 1) p)
@@ -131,7 +137,12 @@ struct Fp28 {
   ARK_HD static Fp28 sub(const Fp28& a, const Fp28& b) {
     Fp28 r;
 #pragma unroll
-    for (int i = 0; i < N; i++) r.l[i] = a.l[i] + (bias<K, BETA>(i) - b.l[i]);
+    for (int i = 0; i < N; i++) {
+#if ARK_F28_CHECK
+      if (bias<K, BETA>(i) < b.l[i] || (uint64_t)a.l[i] + bias<K, BETA>(i) - b.l[i] > 0xFFFFFFFFull) __builtin_trap();
+#endif
+      r.l[i] = a.l[i] + (bias<K, BETA>(i) - b.l[i]);
+    }
     return r;
   }
   // K p - b
@@ -139,7 +150,12 @@ struct Fp28 {
   ARK_HD static Fp28 neg(const Fp28& b) {
     Fp28 r;
 #pragma unroll
-    for (int i = 0; i < N; i++) r.l[i] = bias<K, BETA>(i) - b.l[i];
+    for (int i = 0; i < N; i++) {
+#if ARK_F28_CHECK
+      if (bias<K, BETA>(i) < b.l[i]) __builtin_trap();      // a limb would wrap: the bias class is too small
+#endif
+      r.l[i] = bias<K, BETA>(i) - b.l[i];
+    }
     return r;
   }
   // carry propagation: limbs < 2^28 except the top one (which keeps whatever is left)
