@@ -78,3 +78,18 @@ def test_cpp_snark_trait_prove_matches_oracle(exe, curve_name, circuit, n):
     assert [Z.g1_from_raw(C, got["vk_gamma_abc_g1"][i * s1:(i + 1) * s1]) for i in range(ell)] == pk.vk.gamma_abc_g1
     assert G.verify(C, pk.vk, z[1:ell], G.Proof(Z.g1_from_raw(C, got["proof_a"]), Z.g2_from_raw(C, got["proof_b"]),
                                                 Z.g1_from_raw(C, got["proof_c"])))
+
+
+def test_madd28_chains_match_32bit_formulas():
+    """tests/cpp/test_madd28_emul.cpp: ~48k G1 and 12k lane-pair G2 mixed additions per curve on radix-2^28 limbs, with
+    forced P + P / P + (-P) cases, against the canonical 32-bit formulas; the emulator build traps on any column
+    overflow or limb wrap-around on the way."""
+    src = os.path.join(CPP_DIR, "test_madd28_emul.cpp")
+    exe28 = os.path.join(CPP_DIR, "test_madd28_emul")
+    emul = os.path.join(ROOT, "tests", "emul")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-DARK_EMUL", "-w", "-I", emul,
+                           "-I", os.path.join(ROOT, "snark_amd", "csrc"), "-I", os.path.join(ROOT, "include"),
+                           src, os.path.join(emul, "hip_emul.cpp"), "-o", exe28, "-lpthread"])
+    out = subprocess.run([exe28], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "all chains agree" in out.stdout
