@@ -367,9 +367,10 @@ struct Fp28 {
     }
     return r;
   }
-  // inverse of from_fp for any lazy value < 32 p: canonical 32-bit Montgomery form
-  ARK_HD_NOINLINE static Base to_fp(Fp28 a) {
-    const Fp28 c = canon(a);
+  // canonical limbs (value < p) -> the 32-bit Montgomery form: repack, then divide by 2^SHIFT in ONE Montgomery-style
+  // step: t = -x p^-1 mod 2^SHIFT makes x + t p divisible by 2^SHIFT, and (x + t p) / 2^SHIFT < 2p.  (The first
+  // version halved SHIFT times: 8 / 24 carry chains per coordinate, most of the cost of a bucket flush on BN254.)
+  ARK_HD static Base repack_and_unshift(const Fp28& c) {
     Base x = Base::zero();
 #pragma unroll
     for (int i = 0; i < N; i++) {
@@ -378,18 +379,34 @@ struct Fp28 {
       if (q < NB) x.l[q] |= (uint32_t)v;
       if (q + 1 < NB) x.l[q + 1] |= (uint32_t)(v >> 32);
     }
-    // divide by 2^SHIFT mod p: halve SHIFT times ((x odd ? x + p : x) >> 1; x + p < 2^(32 NB) by the spare bit)
-    for (int s = 0; s < SHIFT; s++) {
-      const uint32_t odd = 0u - (x.l[0] & 1u);
-      uint32_t cy = 0;
-      Base t;
+    if constexpr (SHIFT > 0) {
+      const uint32_t t = (x.l[0] * P::INV) & ((1u << SHIFT) - 1u);
+      uint32_t w[NB + 1];
+      uint64_t cy = 0;
 #pragma unroll
-      for (int i = 0; i < NB; i++) t.l[i] = Base::adc(x.l[i], P::mod(i) & odd, cy);
+      for (int i = 0; i < NB; i++) {
+        cy += (uint64_t)t * P::mod(i) + x.l[i];
+        w[i] = (uint32_t)cy;
+        cy >>= 32;
+      }
+      w[NB] = (uint32_t)cy;
+      Base r;
 #pragma unroll
-      for (int i = 0; i < NB - 1; i++) x.l[i] = (t.l[i] >> 1) | (t.l[i + 1] << 31);
-      x.l[NB - 1] = (t.l[NB - 1] >> 1) | (cy << 31);
+      for (int i = 0; i < NB; i++) r.l[i] = (w[i] >> SHIFT) | (w[i + 1] << (32 - SHIFT));
+      return Base::reduce_once(r, 0u);
+    } else {
+      return x;
     }
-    return x;
+  }
+  // inverse of from_fp for any lazy value < 32 p
+  ARK_HD_NOINLINE static Base to_fp(Fp28 a) { return repack_and_unshift(canon(a)); }
+  // the same for values < 8 p (everything a bucket accumulator holds): three conditional subtractions instead of five
+  ARK_HD_NOINLINE static Base to_fp_lt8(Fp28 a) {
+    Fp28 r = norm(a);
+    r = cond_sub<4>(r);
+    r = cond_sub<2>(r);
+    r = cond_sub<1>(r);
+    return repack_and_unshift(r);
   }
 };
 

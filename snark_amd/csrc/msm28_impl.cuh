@@ -162,10 +162,10 @@ msm_accumulate28_kernel(const Affine28<P>* __restrict__ bases, const uint32_t* _
   auto flush = [&](uint32_t key, uint32_t run_end) __attribute__((always_inline)) {
     XYZZ<Fq> out = XYZZ<Fq>::inf();
     if (!empty) {
-      out.x = F::to_fp(acc.x);
-      out.y = F::to_fp(acc.y);
-      out.zz = F::to_fp(acc.zz);
-      out.zzz = F::to_fp(acc.zzz);
+      out.x = F::to_fp_lt8(acc.x);
+      out.y = F::to_fp_lt8(acc.y);
+      out.zz = F::to_fp_lt8(acc.zz);
+      out.zzz = F::to_fp_lt8(acc.zzz);
     }
     msm_flush_run<Fq>(key, out, first_run, run_start, run_end, seg, offsets, counts, buckets, head, head_key, tail,
                       tail_key);
@@ -432,10 +432,10 @@ msm_accumulate_g2l28_kernel(const Affine28G2<P>* __restrict__ bases, const uint3
     // this lane's halves of the four Fq2 coordinates, canonical 32-bit form
     XYZZ<Fq> mine = XYZZ<Fq>::inf();
     if (!empty) {
-      mine.x = F::to_fp(acc.x);
-      mine.y = F::to_fp(acc.y);
-      mine.zz = F::to_fp(acc.zz);
-      mine.zzz = F::to_fp(acc.zzz);
+      mine.x = F::to_fp_lt8(acc.x);
+      mine.y = F::to_fp_lt8(acc.y);
+      mine.zz = F::to_fp_lt8(acc.zz);
+      mine.zzz = F::to_fp_lt8(acc.zzz);
     }
     const uint32_t o = offsets[key], cnt = counts[key];
     const bool complete = (run_start == o) && (run_end == o + cnt);
