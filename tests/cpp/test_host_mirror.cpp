@@ -223,6 +223,18 @@ static int run_synth_bench(size_t n) {
          (size_t)cs.num_witness_variables(), nnz);
   printf("synth_generate_ms=%.3f\nsynth_finalize_ms=%.3f\nsynth_to_matrices_ms=%.3f\n", ms(t0, t1), ms(t1, t2), ms(t2, t3));
   printf("synth_constraints_per_s=%.0f\n", n / (ms(t0, t2) * 1e-3));
+  // witness-only re-synthesis (what every proof after the first does: SynthesisMode::Prove{false, false} records no
+  // constraint, constraint_system_ref.rs:241-243) + assembling z
+  RefBenchCircuit<F> circ2(F::from_u64(0x7654321), n);
+  auto cs2 = ConstraintSystemRef<F>::new_ref();
+  cs2.set_mode(SynthesisMode::prove(false, false));
+  auto t4 = std::chrono::steady_clock::now();
+  circ2.generate_constraints(cs2);
+  cs2.finalize();
+  std::vector<F> z = cs2.borrow().full_assignment();
+  auto t5 = std::chrono::steady_clock::now();
+  printf("witness_only_ms=%.3f\nwitness_only_constraints_per_s=%.0f\nwitness_only_z_len=%zu\n", ms(t4, t5),
+         n / (ms(t4, t5) * 1e-3), z.size());
   return 0;
 }
 
