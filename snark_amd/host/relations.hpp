@@ -316,10 +316,34 @@ class ConstraintSystem {
   }
   // :768-774 -> predicate/mod.rs:207-217.  BTreeMap<Label, Vec<Matrix<F>>> with the single label "R1CS".
   std::map<std::string, std::vector<Matrix<F>>> to_matrices() const {
-    std::vector<Matrix<F>> mats(3);
+    std::map<std::string, std::vector<Matrix<F>>> out;
+    std::vector<Matrix<F>>& mats = out[R1CS_PREDICATE_LABEL];
+    mats.resize(3);
+    for (int k = 0; k < 3; k++) mats[k].reserve(num_r1cs_constraints);
     for (size_t i = 0; i < num_r1cs_constraints; i++)
-      for (int k = 0; k < 3; k++) mats[k].push_back(make_row(get_lc(r1cs_args[k][i])));
-    return {{R1CS_PREDICATE_LABEL, mats}};
+      for (int k = 0; k < 3; k++) mats[k].push_back(make_row_of(r1cs_args[k][i]));
+    return out;
+  }
+  // make_row(get_lc(v)) without materialising the intermediate LinearCombination (same rows, same order)
+  std::vector<std::pair<F, size_t>> make_row_of(Variable v) const {
+    std::vector<std::pair<F, size_t>> row;
+    if (v.is_zero()) return row;
+    size_t lc_idx;
+    auto push = [&](const F& c, const Variable& var) {
+      if (c == F::zero() || var.is_zero()) return;
+      size_t idx;
+      if (!var.get_variable_index(num_instance_variables, &idx))
+        throw std::logic_error("make_row: un-inlined symbolic LC (the reference panics here, constraint_system.rs:800)");
+      row.emplace_back(c, idx);
+    };
+    if (v.get_lc_index(&lc_idx)) {
+      const auto& terms = lc_map.at(lc_idx);
+      row.reserve(terms.size());
+      for (const auto& cv : terms) push(cv.first, cv.second);
+    } else {
+      push(F::one(), v);
+    }
+    return row;
   }
 
   // assignment.rs:26-35

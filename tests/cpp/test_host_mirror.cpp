@@ -213,7 +213,8 @@ static int run_synth_bench(size_t n) {
   auto t1 = std::chrono::steady_clock::now();
   cs.finalize();
   auto t2 = std::chrono::steady_clock::now();
-  auto m = cs.to_matrices().at("R1CS");
+  const auto all = cs.to_matrices();
+  const auto& m = all.at("R1CS");
   auto t3 = std::chrono::steady_clock::now();
   size_t nnz = 0;
   for (int k = 0; k < 3; k++)
