@@ -170,3 +170,17 @@ def test_prove_batch_in_flight(gpu_lib, gpu_ctx, C):
     then a larger circuit with 4 in flight."""
     pc.prove_batch_case(gpu_lib, gpu_ctx, C, count=7, n=40, inflight=3)
     pc.prove_batch_case(gpu_lib, gpu_ctx, C, count=4, n=500, inflight=4)
+
+
+def test_sharded_prove_over_rccl():
+    """snark_amd.parallel.ShardedGroth16 over the RCCL backend (world_size 1 on a one-GPU box): partial sums gathered
+    from HBM with all_gather_into_tensor, combined by ark355_prove_combine, equal to the whole-key proof and to the
+    closed form.  Runs in its own process so that the process group cannot leak into other tests."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    out = subprocess.run([sys.executable, os.path.join(here, "rccl_single_rank.py")], capture_output=True, text=True,
+                         timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    assert "rccl_ok 1" in out.stdout
