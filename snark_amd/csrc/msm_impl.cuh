@@ -5,19 +5,23 @@
 // (SURVEY.md 3.1 HOT LOOP #5).  Same mathematics -- signed c-bit window digits, bucket
 // accumulation, running-sum bucket reduction, window combination -- laid out for the GPU:
 //
-//   K2 digits      one thread per scalar: Montgomery -> canonical (optional), signed digits,
-//                  key = window*B + |d|-1, histogram of bucket sizes (global atomics, L2 resident)
-//   K3 sort        exclusive scan of the histogram + scatter = counting sort of (key, base index|sign)
-//   K4 accumulate  THE dominant kernel: the sorted entry list is cut into fixed segments of L
-//                  entries, one lane per segment, so every lane performs exactly L mixed additions
-//                  (XYZZ += affine) whatever the bucket-size distribution; runs that cover a whole
+//   K2/K3 sort     signed c-bit digits of every scalar (key = bucket, value = table row | sign) and a two-level
+//                  counting sort of the (key, value) entries: level 1 groups by key >> 8 with per-workgroup LDS
+//                  histograms and private output ranges, level 2 places tiles of 4096 entries with LDS ranks and one
+//                  global atomic per (tile, key)  ("two-level counting sort" below; the one-pass version with
+//                  per-entry global atomics is kept as ARK355_SORT=legacy)
+//   K4 accumulate  THE dominant kernels: the sorted entry list is cut into fixed segments of L
+//                  entries, one lane per segment (two lanes for G2), so every lane performs exactly L mixed
+//                  additions (XYZZ += affine) whatever the bucket-size distribution; runs that cover a whole
 //                  bucket are written straight to the bucket array, the at most two partial runs
-//                  per segment go to head/tail slots
-//      merge       one thread per bucket that straddles segments adds its partial runs
+//                  per segment go to head/tail slots.  Resident keys: radix-2^28 kernels over window tables
+//                  (msm28_impl.cuh); ad-hoc bases: the 32-bit kernels of this file
+//      merge       one thread per bucket that straddles segments adds its partial runs (a workgroup for heavy ones)
 //   K5 reduce      per window sum_b (b+1) B_b: every lane takes K consecutive buckets (running sum),
 //                  adds (first index)*S via a short double-and-add, then wave-wide butterfly
 //                  reduction with __shfl_xor, one partial per workgroup
 //      combine     lane w sums window w's partials, doubles it c*w times, __shfl_xor tree over windows
+//                  (with window tables there is ONE bucket set and no doubling)
 //
 // Algorithmic bytes per term: 32 B scalar + affine base (G1 96 B / G2 192 B BLS12-381).
 #pragma once
