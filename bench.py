@@ -6,12 +6,21 @@ workload BASELINE.json's metric is quoted on: configs[1], the 2^20-constraint sy
 mulchain") over BLS12-381, literal n = 2^20 => domain N = 2^21.  Proving key, CSR matrices
 and the assignment z are resident in HBM when the timed region starts.
 
-N GPUs: one process per GPU, each proving independent instances (the path partitions by independent
-proofs -- no data-path collective), so `scaling` is "weak" and `value` is the whole-job aggregate.
+N GPUs, one process per GPU (`--gpus N` spawns the N ranks itself through torch.distributed.run when it is not
+already running under a launcher; under the driver's launcher WORLD_SIZE must equal --gpus):
+  --mode replica (default)  every rank proves independent instances: the path partitions by independent proofs, no
+                            data-path collective, `scaling` "weak", `value` = whole-job aggregate;
+  --mode shard              BASELINE configs[2]: ONE proof per step (default n = 2^22), its MSM term ranges sharded
+                            over the ranks (ark355_pk_load_shard), the partial sums exchanged by RCCL behind the C ABI
+                            (ark355_prove_sharded: all-gather, or --shard-exchange ring for the bucket-level ring
+                            reduce-scatter), `scaling` "strong".
 
 Prints ONE JSON line (rank 0).  `roofline` prices the dominant kernel (bucket accumulation) against the
-HBM roofline the north star mandates; `cpu_baseline` is the oracle's CPU restatement timed on a bounded
-sample of the same workload on this box's host cores (the only place the oracle is touched here).
+HBM roofline the north star mandates; `cpu_baseline` is the oracle's CPU restatement timed on the same workload on
+this box's host cores (the only place the oracle is touched here).
+
+--dry-run-emul (tests only): the same control flow over the CPU emulator build of the library and gloo, tiny n --
+checks the launcher / rank / JSON plumbing on a machine without GPUs; its numbers are not measurements and say so.
 """
 from __future__ import annotations
 
@@ -39,14 +48,38 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=12)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--log-n", type=int, default=20, help="log2 of the constraint count (default: BASELINE configs[1])")
+    ap.add_argument("--log-n", type=int, default=None,
+                    help="log2 of the constraint count (default: 20 = BASELINE configs[1]; 22 = configs[2] in --mode shard)")
+    ap.add_argument("--mode", default="replica", choices=["replica", "shard"])
+    ap.add_argument("--shard-exchange", default="window", choices=["window", "ring"])
+    ap.add_argument("--dry-run-emul", action="store_true", help="tests only: CPU emulator + gloo, not a measurement")
     ap.add_argument("--curve", default="bls12_381", choices=["bls12_381", "bn254"])
     ap.add_argument("--tight", action="store_true", help="domain-tight variant n = 2^k - 100 (N = 2^k)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true", help="skip the closed-form proof check")
     ap.add_argument("--inflight", type=int, default=4,
                     help="proofs in flight per GPU (independent contexts sharing the resident key; 1 = strictly serial)")
-    return ap.parse_args()
+    args = ap.parse_args()
+    if args.dry_run_emul:
+        args.inflight = 1                # the emulator is single-threaded
+    if args.log_n is None:
+        args.log_n = (8 if args.dry_run_emul else 22) if args.mode == "shard" else (6 if args.dry_run_emul else 20)
+    return args
+
+
+def spawn_ranks(args):
+    """`bench.py --gpus N` outside a launcher: start the N ranks (one per GPU) and relay rank 0's JSON line."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
 
 
 def cpu_baseline(curve_name, log_n_sample=None):
@@ -85,33 +118,79 @@ def pmc_traffic(n, curve):
 
 def main():
     args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, "--gpus %d but the launcher started %d ranks" % (args.gpus, world)
+    import numpy as np
     import torch
     import torch.distributed as dist
-    assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
-    torch.cuda.set_device(local_rank)
+    emul = args.dry_run_emul
+    if emul:
+        sys.path.insert(0, os.path.join(ROOT, "tests", "emul"))
+        import build_emul
+        from snark_amd._binding import Lib
+        backend_lib = Lib(build_emul.build())
+        dev_sync = lambda: None                                  # noqa: E731
+        xdev = "cpu"
+    else:
+        assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
+        torch.cuda.set_device(local_rank)
+        backend_lib = None                                       # snark_amd.lib(): libark355.so or a loud failure
+        dev_sync = torch.cuda.synchronize
+        xdev = "cuda:%d" % local_rank
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if emul:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # one collective over all ranks before anything else: the N ranks (and the RCCL ring over xGMI) exist
+        probe = torch.ones(1, dtype=torch.int64, device=xdev)
+        dist.all_reduce(probe)
+        assert int(probe.item()) == world
     from snark_amd import params, synthetic
     from snark_amd.groth16 import Groth16
     import random
 
+    shard = args.mode == "shard"
     cv = params.CURVES[args.curve]
     n = (1 << args.log_n) - (100 if args.tight else 0)
     t_prep = time.perf_counter()
-    g = Groth16(cv, device=local_rank)
-    r1, z = synthetic.mulchain(cv, n, seed=0x355 + rank)
-    rnd = random.Random(0x355 + rank)
+    dev_id = 0 if emul else local_rank                           # the emulator models one device
+    g = Groth16(cv, device=dev_id, lib=backend_lib)
+    # replica mode: independent instances per rank; shard mode: every rank holds the SAME statement and key
+    seed = 0x355 + (0 if shard else rank)
+    r1, z = synthetic.mulchain(cv, n, seed=seed)
+    rnd = random.Random(seed)
     pk, vk = g.circuit_specific_setup(r1, lambda: rnd.randrange(1, cv.r), keep_trapdoor=not args.no_check)
-    g.load_pk(pk)
+    sg = None
+    if shard:
+        from snark_amd.parallel import ShardedGroth16, SHARD_BUCKET_RING, SHARD_WINDOW
+        if world == 1 and not dist.is_initialized():
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            dist.init_process_group("gloo" if emul else "nccl", rank=0, world_size=1)
+        sg = ShardedGroth16(g, device=xdev)
+        sg.load_pk_shard(pk)
+        shard_mode = SHARD_BUCKET_RING if args.shard_exchange == "ring" else SHARD_WINDOW
+        args.inflight = 1                # one collective proof at a time
+    else:
+        g.load_pk(pk)
     g.load_r1cs(r1)
     zb = synthetic.z_to_mont_bytes(cv, z)
-    import numpy as np
-    z_dev = torch.from_numpy(np.frombuffer(zb, dtype=np.uint8).copy()).cuda()     # z resident in HBM
-    torch.cuda.synchronize()
+    if emul:
+        z_host = np.frombuffer(zb, dtype=np.uint8).copy()
+
+        class _Z:                                                # "device" memory of the emulator is host memory
+            def data_ptr(self):
+                return z_host.ctypes.data
+        z_dev = _Z()
+    else:
+        z_dev = torch.from_numpy(np.frombuffer(zb, dtype=np.uint8).copy()).cuda()     # z resident in HBM
+    dev_sync()
     prep_s = time.perf_counter() - t_prep
 
     # Throughput mode: `inflight` independent proving contexts (own streams and scratch) share the resident key and
@@ -119,11 +198,14 @@ def main():
     # the other keeps the CUs busy.  Every step is still one complete, independently randomised proof.
     import threading
     from snark_amd.groth16 import Proof
-    pkh, rh = g.load_pk(pk), g.load_r1cs(r1)
-    ctxs = [g.ctx] + [g.lib.ctx_create(local_rank) for _ in range(max(1, args.inflight) - 1)]
+    rh = g.load_r1cs(r1)
+    pkh = None if shard else g.load_pk(pk)
+    ctxs = [g.ctx] + [g.lib.ctx_create(dev_id) for _ in range(max(1, args.inflight) - 1)]
     lock = threading.Lock()
 
     def prove_on(ctx, r_, s_):
+        if shard:
+            return sg.prove(pk, r1, None, r_, s_, mode=shard_mode, z_device_ptr=z_dev.data_ptr())
         a, b, c = g.lib.prove(ctx, pkh, rh, z_dev.data_ptr(), r1.m, cv.fr_canon(r_), cv.fr_canon(s_), g.sizes,
                               z_is_device_ptr=True)
         return Proof(a, b, c)
@@ -173,10 +255,10 @@ def main():
     rec = [0.0, 0, 0]
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize()
+    dev_sync()
     t0 = time.perf_counter()
     results = run(args.steps, rec)
-    torch.cuda.synchronize()
+    dev_sync()
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
@@ -189,7 +271,7 @@ def main():
     last = results[-1]
     tim = g.lib.timings(g.ctx)
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device=xdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
@@ -198,7 +280,7 @@ def main():
         ok = all(proof == g.prove_closed_form(pk, z, r_, s_) for proof, r_, s_ in results)
         parity = "proof == trapdoor closed form" if ok else "MISMATCH"
         if world > 1:
-            f = torch.tensor([0 if ok else 1], device="cuda")
+            f = torch.tensor([0 if ok else 1], device=xdev)
             dist.all_reduce(f)
             if int(f.item()) != 0:
                 parity = "MISMATCH"
@@ -209,6 +291,8 @@ def main():
         m, w = r1.m, r1.w
         g1_terms = (N - 1) + (w + 1) + 2 * (m + 4)
         g2_terms = m + 4
+        if shard:                      # this rank's launches see 1/world of every query vector
+            g1_terms, g2_terms = g1_terms / world, g2_terms / world
         g1b, g2b = 32 + g.sizes["g1"], 32 + g.sizes["g2"]
         alg_bytes_per_proof = g1_terms * g1b + g2_terms * g2b       # dominant kernel only (5 launches)
         alg_bytes_per_launch = alg_bytes_per_proof / 5.0
@@ -225,15 +309,21 @@ def main():
         out = {
             "metric": "R1CS constraints/sec (Groth16 prove, BLS12-381)" if args.curve == "bls12_381"
                       else "R1CS constraints/sec (Groth16 prove, BN254)",
-            "value": world * n * args.steps / dt,
+            "value": (1 if shard else world) * n * args.steps / dt,
             "unit": "constraints/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u32", "data": "synthetic",
-            "config": {"workload": "S2 mulchain R1CS, n=%d constraints (N=2^%d), Groth16/%s, one independent proof "
-                                   "stream per GPU, pk+CSR+z resident in HBM" % (n, N.bit_length() - 1, args.curve),
-                       "parallelism": "replicas x%d (independent proofs, no collective), %d proofs in flight per GPU"
+            "higher_is_better": True, "scaling": "strong" if shard else "weak", "vs_baseline": None,
+            "dtype": "u32",
+            "data": "synthetic" if not emul else "synthetic -- EMULATOR DRY RUN on CPU (plumbing check, NOT a measurement)",
+            "config": {"workload": ("S2 mulchain R1CS, n=%d constraints (N=2^%d), Groth16/%s, " % (n, N.bit_length() - 1, args.curve))
+                                   + ("ONE proof per step, MSM term ranges sharded over the GPUs, pk shard+CSR+z resident in HBM"
+                                      if shard else "one independent proof stream per GPU, pk+CSR+z resident in HBM"),
+                       "parallelism": ("msm-shard x%d (RCCL behind the C ABI: %s)" % (
+                                           world, "bucket-level ring reduce-scatter + all-gather" if args.shard_exchange == "ring"
+                                           else "all-gather of 5 partial sums"))
+                                      if shard else
+                                      "replicas x%d (independent proofs, no collective), %d proofs in flight per GPU"
                                       % (world, len(ctxs))},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(n, args.curve),
@@ -250,16 +340,20 @@ def main():
             "phases_ms": tim,
             "prove_alg_bytes": prove_alg_bytes,
             "prove_hbm_frac": prove_alg_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS,
-            "msm_g1_mscalar_mul_per_s": (N - 1) / (tim["msm_h_ms"] * 1e-3) / 1e6 if tim["msm_h_ms"] > 0 else None,
+            # BASELINE's second metric, read inside the prover (H: N-1 G1 terms; B2: m+4 G2 terms of this rank's shard)
+            "msm_g1_mscalar_mul_per_s": (N - 1) / (world if shard else 1) / (tim["msm_h_ms"] * 1e-3) / 1e6 if tim["msm_h_ms"] > 0 else None,
+            "msm_g2_mscalar_mul_per_s": (m + 4) / (world if shard else 1) / (tim["msm_b_g2_ms"] * 1e-3) / 1e6 if tim["msm_b_g2_ms"] > 0 else None,
             "prep_s": prep_s,
         }
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and not emul:
             out["cpu_baseline"] = cpu_baseline(args.curve)
         print(json.dumps(out), flush=True)
     for c in ctxs[1:]:
         g.lib.ctx_destroy(c)
+    if sg is not None:
+        sg.close()
     g.close()
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

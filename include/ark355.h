@@ -18,8 +18,10 @@
  *    all-zero encoding (the shim maps `Affine::infinity == true` to zeros and back);
  *  - the caller owns all host buffers; the library copies during the call and never retains host
  *    pointers.  Handles are opaque and freed by the matching *_free / *_destroy;
- *  - `*_dev` variants take DEVICE pointers (HIP allocations of the calling process) and a HIP
- *    stream (void*, may be NULL for the context's own stream).
+ *  - `*_dev` variants take DEVICE pointers (HIP allocations of the calling process).  The library reads them on
+ *    its own streams: the CALLER must have completed (stream- or device-synchronised) whatever produced those
+ *    buffers before the call.  Only ark355_ntt_fr_dev takes the producer's stream (void*, NULL = the context's own)
+ *    and orders itself on it.
  */
 #ifndef ARK355_H
 #define ARK355_H
@@ -131,6 +133,35 @@ int32_t ark355_prove_shard(ark355_ctx* ctx, const ark355_pk* pk_shard, const ark
                            uint64_t z_len, const uint8_t r[32], const uint8_t s[32], uint8_t* out_partials);
 int32_t ark355_prove_combine(ark355_ctx* ctx, int32_t curve, const uint8_t* partials, uint64_t count,
                              const uint8_t r[32], const uint8_t s[32], ark355_proof_raw* out);
+
+/* ---- the exchange behind the ABI: RCCL communicator + collective sharded prove -----------------------------------
+ * The reference's parallel unit is one OS thread per proof (ConstraintSystemRef is Rc<RefCell<..>>,
+ * relations/src/gr1cs/constraint_system_ref.rs:33) behind SNARK::prove (snark/src/lib.rs:50-54); a single LARGE proof
+ * (BASELINE.json configs[2]) is instead split here by MSM term ranges over the GPUs of a node, one host process per GPU.
+ * Rank 0 obtains a communicator id (ark355_comm_unique_id) and hands it to the other ranks over whatever channel the
+ * host already has (the Rust shim: its own IPC; the Python mirror: torch.distributed's store); every rank then calls
+ * ark355_comm_init -- a collective, like ncclCommInitRank underneath.
+ * ark355_prove_sharded is collective too: every rank passes its key shard (ark355_pk_load_shard with the rank as shard
+ * index and the world size as shard count), the SAME full assignment z and the SAME r, s; every rank receives the same
+ * proof, byte-identical to ark355_prove with the whole key.  `mode`:
+ *   ARK355_SHARD_WINDOW       one ncclAllGather of the five XYZZ partial sums from HBM (default; latency-bound);
+ *   ARK355_SHARD_BUCKET_RING  ring reduce-scatter of the bucket arrays (ncclSend/ncclRecv + EC-add kernel) before the
+ *                             bucket reduction -- the literal "all-reduce of partial bucket sums" -- then the all-gather.
+ * RCCL failures return ARK355_ERCCL (ark355_last_error has RCCL's message). */
+typedef struct ark355_comm ark355_comm;
+#define ARK355_COMM_ID_BYTES 128
+enum { ARK355_SHARD_WINDOW = 0, ARK355_SHARD_BUCKET_RING = 1 };
+int32_t ark355_comm_unique_id(uint8_t id[ARK355_COMM_ID_BYTES]);
+int32_t ark355_comm_init(ark355_ctx* ctx, const uint8_t id[ARK355_COMM_ID_BYTES], int32_t rank, int32_t world,
+                         ark355_comm** out);
+void ark355_comm_destroy(ark355_comm* comm);
+int32_t ark355_prove_sharded(ark355_ctx* ctx, ark355_comm* comm, const ark355_pk* pk_shard, const ark355_r1cs* r1cs,
+                             const uint8_t* z, uint64_t z_len, const uint8_t r[32], const uint8_t s[32], int32_t mode,
+                             ark355_proof_raw* out);
+/* same, z already resident in this rank's HBM */
+int32_t ark355_prove_sharded_dev(ark355_ctx* ctx, ark355_comm* comm, const ark355_pk* pk_shard, const ark355_r1cs* r1cs,
+                                 const void* d_z, uint64_t z_len, const uint8_t r[32], const uint8_t s[32], int32_t mode,
+                                 ark355_proof_raw* out);
 
 /* ---- building blocks ---------------------------------------------------------------------- */
 /* R1CS -> QAP witness map h[0..N) (Montgomery), SURVEY Appendix A steps 1-5 */

@@ -408,3 +408,149 @@ int cb_prove(int curve, uint64_t n, uint64_t ell, uint64_t w, const uint64_t* rp
   free(zc);
   return 0;
 }
+
+/* ---- Groth16 generator scalars (ark-groth16 generator.rs generate_parameters_with_qap, R1CSToQAP::
+ * instance_map_with_evaluation; SURVEY.md Appendix A "Setup") for keys at sizes the Python oracle cannot reach.
+ * td: tau, alpha, beta, gamma, delta (canonical, 4 limbs each).  Outputs (canonical scalars, 4 limbs each):
+ *   u, v, w          m each            u_i(tau), v_i(tau), w_i(tau)
+ *   l_s              w                 (beta u_i + alpha v_i + w_i) / delta,  i >= ell
+ *   gabc_s           ell               (beta u_i + alpha v_i + w_i) / gamma,  i <  ell
+ *   h_s              N - 1             Z(tau) tau^i / delta
+ * The fixed-base multiplications are done by the caller with cb_fixed_base.  Checked against oracle/groth16.py
+ * (qap_scalars / setup) in tests/test_oracle_c.py. */
+static void fr_pow_u64(f4_t* r, const f4_t* a, uint64_t e, const f4_params* P) {
+  uint64_t el[1] = {e};
+  f4_pow(r, a, el, 1, P);
+}
+
+int cb_setup_scalars(int curve, uint64_t n, uint64_t ell, uint64_t wn, const uint64_t* rpa, const uint32_t* cola,
+                     const uint64_t* cfa, const uint64_t* rpb, const uint32_t* colb, const uint64_t* cfb,
+                     const uint64_t* rpc, const uint32_t* colc, const uint64_t* cfc, const uint64_t* td,
+                     uint64_t* u_out, uint64_t* v_out, uint64_t* w_out, uint64_t* l_out, uint64_t* gabc_out,
+                     uint64_t* h_out) {
+  curve_ctx* c = &g_curves[curve];
+  const f4_params* P = &c->fr;
+  const int lg = domain_log(n + ell);
+  if (lg > c->two_adicity) return -18;
+  const size_t N = (size_t)1 << lg, m = ell + wn;
+  f4_t tau, alpha, beta, gamma, delta, one;
+  f4_set_one(&one, P);
+  const f4_t* tdm[5] = {&tau, &alpha, &beta, &gamma, &delta};
+  for (int i = 0; i < 5; i++) {
+    f4_t t;
+    memcpy(t.l, td + 4 * i, 32);
+    f4_to_mont((f4_t*)tdm[i], &t, P);
+  }
+  f4_t omega, zt, ninv, cc;
+  fr_pow2k(&omega, &c->root, c->two_adicity - lg, P);
+  fr_pow_u64(&zt, &tau, (uint64_t)N, P);
+  f4_sub(&zt, &zt, &one, P);
+  {
+    f4_t nn, t;
+    uint64_t nl[4] = {(uint64_t)N, 0, 0, 0};
+    memcpy(t.l, nl, 32);
+    f4_to_mont(&nn, &t, P);
+    f4_inv(&ninv, &nn, P);
+  }
+  f4_mul(&cc, &zt, &ninv, P);
+  /* L_k(tau) = Z(tau)/N * omega^k / (tau - omega^k)  (tau outside H; the oracle never draws tau in H) */
+  f4_t* L = (f4_t*)malloc(sizeof(f4_t) * N);
+  f4_t* wk = (f4_t*)malloc(sizeof(f4_t) * N);
+  if (f4_is_zero(&zt)) {
+    free(L);
+    free(wk);
+    return -1;
+  }
+  const int nt = omp_get_max_threads();
+  const size_t chunk = (N + (size_t)nt - 1) / (size_t)nt;
+#pragma omp parallel for schedule(static, 1)
+  for (int t = 0; t < nt; t++) {
+    const size_t k0 = (size_t)t * chunk, k1 = (k0 + chunk < N) ? k0 + chunk : N;
+    if (k0 >= k1) continue;
+    f4_t p;
+    fr_pow_u64(&p, &omega, (uint64_t)k0, P);
+    /* dens -> L (prefix products), then one inversion per chunk */
+    f4_t acc = one;
+    for (size_t k = k0; k < k1; k++) {
+      wk[k] = p;
+      f4_t d;
+      f4_sub(&d, &tau, &p, P);
+      f4_mul(&acc, &acc, &d, P);
+      L[k] = acc;
+      f4_mul(&p, &p, &omega, P);
+    }
+    f4_t inv;
+    f4_inv(&inv, &acc, P);
+    for (size_t k = k1; k-- > k0;) {
+      f4_t d, iv;
+      f4_sub(&d, &tau, &wk[k], P);
+      if (k > k0) f4_mul(&iv, &inv, &L[k - 1], P);
+      else iv = inv;
+      f4_mul(&inv, &inv, &d, P);
+      f4_mul(&iv, &iv, &wk[k], P);
+      f4_mul(&L[k], &iv, &cc, P);
+    }
+  }
+  free(wk);
+  f4_t* uvw[3];
+  for (int k = 0; k < 3; k++) uvw[k] = (f4_t*)calloc(m ? m : 1, sizeof(f4_t));
+  for (uint64_t i = 0; i < ell; i++) uvw[0][i] = L[n + i];
+  const uint64_t* rps[3] = {rpa, rpb, rpc};
+  const uint32_t* cols[3] = {cola, colb, colc};
+  const f4_t* cfs[3] = {(const f4_t*)cfa, (const f4_t*)cfb, (const f4_t*)cfc};
+#pragma omp parallel for schedule(static, 1)
+  for (int k = 0; k < 3; k++) {
+    for (uint64_t i = 0; i < n; i++) {
+      for (uint64_t t = rps[k][i]; t < rps[k][i + 1]; t++) {
+        f4_t x;
+        if (f4_eq(&cfs[k][t], &one)) x = L[i];
+        else f4_mul(&x, &L[i], &cfs[k][t], P);
+        f4_t* dst = &uvw[k][cols[k][t]];
+        f4_add(dst, dst, &x, P);
+      }
+    }
+  }
+  free(L);
+  f4_t gi, di;
+  f4_inv(&gi, &gamma, P);
+  f4_inv(&di, &delta, P);
+#pragma omp parallel for schedule(static)
+  for (size_t i = 0; i < m; i++) {
+    f4_t a, b, t;
+    f4_mul(&a, &beta, &uvw[0][i], P);
+    f4_mul(&b, &alpha, &uvw[1][i], P);
+    f4_add(&a, &a, &b, P);
+    f4_add(&a, &a, &uvw[2][i], P);
+    if (i < ell) {
+      f4_mul(&t, &a, &gi, P);
+      f4_from_mont(&t, &t, P);
+      memcpy(gabc_out + 4 * i, t.l, 32);
+    } else {
+      f4_mul(&t, &a, &di, P);
+      f4_from_mont(&t, &t, P);
+      memcpy(l_out + 4 * (i - ell), t.l, 32);
+    }
+  }
+  to_canon(u_out, uvw[0], m, P);
+  to_canon(v_out, uvw[1], m, P);
+  to_canon(w_out, uvw[2], m, P);
+  for (int k = 0; k < 3; k++) free(uvw[k]);
+  f4_t h0;
+  f4_mul(&h0, &zt, &di, P);
+  const size_t hn = N - 1;
+  const size_t hchunk = (hn + (size_t)nt - 1) / (size_t)nt;
+#pragma omp parallel for schedule(static, 1)
+  for (int t = 0; t < nt; t++) {
+    const size_t k0 = (size_t)t * hchunk, k1 = (k0 + hchunk < hn) ? k0 + hchunk : hn;
+    if (k0 >= k1) continue;
+    f4_t p, x;
+    fr_pow_u64(&p, &tau, (uint64_t)k0, P);
+    f4_mul(&p, &p, &h0, P);
+    for (size_t k = k0; k < k1; k++) {
+      f4_from_mont(&x, &p, P);
+      memcpy(h_out + 4 * k, x.l, 32);
+      f4_mul(&p, &p, &tau, P);
+    }
+  }
+  return 0;
+}

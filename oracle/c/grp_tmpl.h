@@ -212,13 +212,25 @@ static void G(_msm)(G(_jac) * out, const G(_aff) * bases, const uint64_t* scalar
       digits[(size_t)w * n + i] = (int32_t)v;
     }
   }
-  G(_jac)* wsum = (G(_jac)*)malloc(sizeof(G(_jac)) * nwin);
+  /* Tasks = (window, chunk of the terms).  arkworks parallelises over windows (rayon); with ~18 windows that leaves
+   * most of a 128-thread host idle, while its Groth16 prover gets further parallelism from running the MSMs of a
+   * proof side by side.  Splitting every window's terms into chunks reaches the same occupancy inside one MSM; the
+   * per-window sum is the same group element whatever the partition. */
+  int nthreads = omp_get_max_threads();
+  size_t nchunks = ((size_t)2 * (size_t)nthreads + (size_t)nwin - 1) / (size_t)nwin;
+  if (nchunks * 4 * nb > n) nchunks = n / (4 * nb);      /* keep the bucket reduction of a task below ~half its work */
+  if (nchunks < 1) nchunks = 1;
+  const size_t ntasks = (size_t)nwin * nchunks;
+  G(_jac)* tsum = (G(_jac)*)malloc(sizeof(G(_jac)) * ntasks);
 #pragma omp parallel for schedule(dynamic, 1)
-  for (int w = 0; w < nwin; w++) {
+  for (size_t task = 0; task < ntasks; task++) {
+    const int w = (int)(task / nchunks);
+    const size_t ch = task % nchunks;
+    const size_t i0 = n * ch / nchunks, i1 = n * (ch + 1) / nchunks;
     G(_jac)* buckets = (G(_jac)*)malloc(sizeof(G(_jac)) * nb);
     for (size_t b = 0; b < nb; b++) G(_set_inf)(&buckets[b], P);
     const int32_t* dg = digits + (size_t)w * n;
-    for (size_t i = 0; i < n; i++) {
+    for (size_t i = i0; i < i1; i++) {
       int32_t d = dg[i];
       if (d > 0) {
         G(_madd)(&buckets[d - 1], &buckets[d - 1], &bases[i], P);
@@ -235,9 +247,15 @@ static void G(_msm)(G(_jac) * out, const G(_aff) * bases, const uint64_t* scalar
       G(_add)(&running, &running, &buckets[b], P);
       G(_add)(&res, &res, &running, P);
     }
-    wsum[w] = res;
+    tsum[task] = res;
     free(buckets);
   }
+  G(_jac)* wsum = (G(_jac)*)malloc(sizeof(G(_jac)) * nwin);
+  for (int w = 0; w < nwin; w++) {
+    G(_set_inf)(&wsum[w], P);
+    for (size_t ch = 0; ch < nchunks; ch++) G(_add)(&wsum[w], &wsum[w], &tsum[(size_t)w * nchunks + ch], P);
+  }
+  free(tsum);
   /* lowest + fold the rest from the top (Horner, c doublings per window) */
   G(_jac) total;
   G(_set_inf)(&total, P);

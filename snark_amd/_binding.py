@@ -23,6 +23,9 @@ ENODEV = -5
 E_ASSIGNMENT_MISSING = -16
 E_UNSATISFIABLE = -17
 E_POLY_DEGREE_TOO_LARGE = -18
+COMM_ID_BYTES = 128
+SHARD_WINDOW = 0
+SHARD_BUCKET_RING = 1
 
 _ERR_NAMES = {
     EINVAL: "EINVAL", ENOMEM: "ENOMEM", EHIP: "EHIP", ERCCL: "ERCCL", ENODEV: "ENODEV",
@@ -39,7 +42,8 @@ SYMBOLS = [
     "ark355_msm_g1", "ark355_msm_g2", "ark355_bases_load", "ark355_bases_free", "ark355_msm_dev",
     "ark355_msm_dev_partial", "ark355_xyzz_sum", "ark355_fixed_base_mul", "ark355_get_timings",
     "ark355_get_kernel_stats", "ark355_pk_load_shard", "ark355_partial_size", "ark355_prove_shard",
-    "ark355_prove_combine", "ark355_prove_batch",
+    "ark355_prove_combine", "ark355_prove_batch", "ark355_comm_unique_id", "ark355_comm_init", "ark355_comm_destroy",
+    "ark355_prove_sharded", "ark355_prove_sharded_dev",
 ]
 
 
@@ -130,6 +134,12 @@ class Lib:
         d.ark355_prove_shard.argtypes = [vp, vp, vp, vp, u64, vp, vp, vp]
         d.ark355_prove_combine.argtypes = [vp, i32, vp, u64, vp, vp, P(ProofRaw)]
         d.ark355_prove_batch.argtypes = [vp, vp, vp, vp, u64, vp, vp, u64, u32, vp]
+        d.ark355_comm_unique_id.argtypes = [vp]
+        d.ark355_comm_init.argtypes = [vp, vp, i32, i32, P(vp)]
+        d.ark355_comm_destroy.argtypes = [vp]
+        d.ark355_comm_destroy.restype = None
+        d.ark355_prove_sharded.argtypes = [vp, vp, vp, vp, vp, u64, vp, vp, i32, P(ProofRaw)]
+        d.ark355_prove_sharded_dev.argtypes = [vp, vp, vp, vp, vp, u64, vp, vp, i32, P(ProofRaw)]
         d.ark355_get_timings.argtypes = [vp, P(Timings)]
         d.ark355_get_kernel_stats.argtypes = [vp, P(C.c_float), P(u64), P(u64)]
         for name in SYMBOLS:
@@ -237,6 +247,35 @@ class Lib:
         rb, k2 = _buf(r)
         sb, k3 = _buf(s)
         self.check(ctx, self.dll.ark355_prove_combine(ctx, curve, pb, count, rb, sb, C.byref(out)))
+        return bytes(out.a)[:sizes["g1"]], bytes(out.b)[:sizes["g2"]], bytes(out.c)[:sizes["g1"]]
+
+    # ---- RCCL behind the ABI ----------------------------------------------------------------------------------
+    def comm_unique_id(self) -> bytes:
+        out = np.zeros(COMM_ID_BYTES, dtype=np.uint8)
+        self.check(None, self.dll.ark355_comm_unique_id(out.ctypes.data_as(C.c_void_p)))
+        return out.tobytes()
+
+    def comm_init(self, ctx, comm_id: bytes, rank: int, world: int):
+        h = C.c_void_p()
+        ib, k = _buf(comm_id)
+        self.check(ctx, self.dll.ark355_comm_init(ctx, ib, rank, world, C.byref(h)))
+        return h
+
+    def comm_destroy(self, comm):
+        self.dll.ark355_comm_destroy(comm)
+
+    def prove_sharded(self, ctx, comm, pk_shard, r1cs, z, z_len, r: bytes, s: bytes, sizes, mode=SHARD_WINDOW,
+                      z_is_device_ptr=False):
+        out = ProofRaw()
+        rb, k2 = _buf(r)
+        sb, k3 = _buf(s)
+        if z_is_device_ptr:
+            rc = self.dll.ark355_prove_sharded_dev(ctx, comm, pk_shard, r1cs, C.c_void_p(z), z_len, rb, sb, int(mode),
+                                                   C.byref(out))
+        else:
+            zb, k1 = _buf(z)
+            rc = self.dll.ark355_prove_sharded(ctx, comm, pk_shard, r1cs, zb, z_len, rb, sb, int(mode), C.byref(out))
+        self.check(ctx, rc)
         return bytes(out.a)[:sizes["g1"]], bytes(out.b)[:sizes["g2"]], bytes(out.c)[:sizes["g1"]]
 
     def witness_map(self, ctx, r1cs, z, z_len, fr_size):

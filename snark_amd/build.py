@@ -65,7 +65,9 @@ def build(force=False, verbose=True, resource_log=False):
 
     with ThreadPoolExecutor(len(SOURCES)) as ex:
         objs = list(ex.map(compile_one, SOURCES))
-    cmd = [cc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-Wl,-Bsymbolic", "-o", OUT, *objs]
+    # RCCL carries the cross-GPU exchange of the sharded prover (csrc/comm_impl.cuh)
+    cmd = [cc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-Wl,-Bsymbolic", "-o", OUT, *objs,
+           "-L/opt/rocm/lib", "-lrccl"]
     if verbose:
         print("[snark_amd.build]", " ".join(cmd), flush=True)
     subprocess.check_call(cmd)

@@ -52,8 +52,9 @@ struct Api {
   }
 
   static void prove(ark355_ctx* ctx, ProverScratch& sc, const PkDev& pk, const R1csDev& r1, const void* z,
-                    bool on_dev, const uint8_t* r, const uint8_t* s, ark355_proof_raw* out, uint8_t* partials = nullptr) {
-    prove_run<Curve>(ctx, sc, pk, r1, z, on_dev, r, s, out, partials);
+                    bool on_dev, const uint8_t* r, const uint8_t* s, ark355_proof_raw* out, uint8_t* partials = nullptr,
+                    CommDev* cm = nullptr, int shard_mode = 0) {
+    prove_run<Curve>(ctx, sc, pk, r1, z, on_dev, r, s, out, partials, cm, shard_mode);
   }
   static void combine(const uint8_t* partials, uint64_t count, const uint8_t* r, const uint8_t* s, ark355_proof_raw* out) {
     combine_partials_host<Curve>(partials, count, r, s, out);

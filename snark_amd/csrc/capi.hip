@@ -22,6 +22,9 @@ struct ark355_r1cs {
 struct ark355_bases {
   BasesDev* d;
 };
+struct ark355_comm {
+  CommDev* d;
+};
 
 namespace {
 struct CtxExtra {
@@ -290,6 +293,73 @@ int32_t ark355_prove_combine(ark355_ctx* ctx, int32_t curve, const uint8_t* part
                              const uint8_t r[32], const uint8_t s[32], ark355_proof_raw* out) {
   if (!ctx || !partials || !count || !r || !s || !out) return ARK355_EINVAL;
   return guarded(ctx, [&] { CURVE_DISPATCH(curve, A::combine(partials, count, r, s, out)); });
+}
+
+int32_t ark355_comm_unique_id(uint8_t id[ARK355_COMM_ID_BYTES]) {
+  if (!id) return ARK355_EINVAL;
+  static_assert(sizeof(ncclUniqueId) <= ARK355_COMM_ID_BYTES, "communicator id does not fit");
+  ncclUniqueId u;
+  if (ncclGetUniqueId(&u) != ncclSuccess) return ARK355_ERCCL;
+  memset(id, 0, ARK355_COMM_ID_BYTES);
+  memcpy(id, &u, sizeof(u));
+  return ARK355_OK;
+}
+
+int32_t ark355_comm_init(ark355_ctx* ctx, const uint8_t id[ARK355_COMM_ID_BYTES], int32_t rank, int32_t world,
+                         ark355_comm** out) {
+  if (!ctx || !id || !out || world < 1 || rank < 0 || rank >= world) return ARK355_EINVAL;
+  *out = nullptr;
+  return guarded(ctx, [&] {
+    auto* d = new CommDev();
+    d->rank = rank;
+    d->world = world;
+    d->device = ctx->device;
+    ncclUniqueId u;
+    memcpy(&u, id, sizeof(u));
+    const ncclResult_t r = ncclCommInitRank(&d->comm, world, u, rank);
+    if (r != ncclSuccess) {
+      d->comm = nullptr;
+      delete d;
+      throw HipError{ARK355_ERCCL, std::string("ncclCommInitRank: ") + ncclGetErrorString(r)};
+    }
+    *out = new ark355_comm{d};
+  });
+}
+
+void ark355_comm_destroy(ark355_comm* comm) {
+  if (!comm) return;
+  if (comm->d) (void)hipSetDevice(comm->d->device);
+  delete comm->d;
+  delete comm;
+}
+
+static int32_t prove_sharded_common(ark355_ctx* ctx, ark355_comm* comm, const ark355_pk* pk, const ark355_r1cs* r1,
+                                    const void* z, bool on_dev, uint64_t z_len, const uint8_t* r, const uint8_t* s,
+                                    int32_t mode, ark355_proof_raw* out) {
+  if (!ctx || !comm || !pk || !r1 || !z || !r || !s || !out) return ARK355_EINVAL;
+  if (mode != ARK355_SHARD_WINDOW && mode != ARK355_SHARD_BUCKET_RING) return ARK355_EINVAL;
+  if (z_len < r1->d->m) {
+    ctx->last_error = "assignment shorter than num_instance + num_witness";
+    return ARK355_E_ASSIGNMENT_MISSING;
+  }
+  if ((int)pk->d->shard_count != comm->d->world || (int)pk->d->shard_index != comm->d->rank) {
+    ctx->last_error = "key shard (index, count) does not match the communicator's (rank, world)";
+    return ARK355_EINVAL;
+  }
+  return guarded(ctx, [&] {
+    CtxExtra& ex = extra(ctx);
+    CURVE_DISPATCH(pk->d->curve, A::prove(ctx, ex.prover, *pk->d, *r1->d, z, on_dev, r, s, out, nullptr, comm->d, mode));
+  });
+}
+int32_t ark355_prove_sharded(ark355_ctx* ctx, ark355_comm* comm, const ark355_pk* pk, const ark355_r1cs* r1,
+                             const uint8_t* z, uint64_t z_len, const uint8_t r[32], const uint8_t s[32], int32_t mode,
+                             ark355_proof_raw* out) {
+  return prove_sharded_common(ctx, comm, pk, r1, z, false, z_len, r, s, mode, out);
+}
+int32_t ark355_prove_sharded_dev(ark355_ctx* ctx, ark355_comm* comm, const ark355_pk* pk, const ark355_r1cs* r1,
+                                 const void* d_z, uint64_t z_len, const uint8_t r[32], const uint8_t s[32], int32_t mode,
+                                 ark355_proof_raw* out) {
+  return prove_sharded_common(ctx, comm, pk, r1, d_z, true, z_len, r, s, mode, out);
 }
 
 int32_t ark355_witness_map(ark355_ctx* ctx, const ark355_r1cs* r1, const uint8_t* z, uint64_t z_len, uint8_t* h_out) {

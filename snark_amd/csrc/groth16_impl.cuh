@@ -25,6 +25,7 @@
 #include "common.h"
 #include "msm_impl.cuh"
 #include "witness_impl.cuh"
+#include "comm_impl.cuh"
 
 namespace ark355 {
 
@@ -52,9 +53,20 @@ struct ProverScratch {
   MsmSort sortZ, sortH;
   MsmBuckets bkA, bkB1, bkB2, bkL, bkH;
   hipStream_t sW = nullptr, sS = nullptr, sA = nullptr, sR = nullptr;
+  // events of one proof, created once per context (prove_run used to create and destroy 23 of them per proof)
+  static constexpr int N_EVENTS = 32;
+  hipEvent_t events[N_EVENTS] = {};
+  bool have_events = false;
+  void ensure_events() {
+    if (have_events) return;
+    for (auto& e : events) ARK_CHECK_HIP(hipEventCreate(&e));
+    have_events = true;
+  }
   ~ProverScratch() {
     for (hipStream_t st : {sW, sS, sA, sR})
       if (st) (void)hipStreamDestroy(st);
+    for (auto& e : events)
+      if (e) (void)hipEventDestroy(e);
   }
   WitnessScratch ws;
   DevBuf zx;        // extended scalar vector
@@ -196,22 +208,25 @@ static PkDev* pk_upload(const ark355_pk_desc* d, hipStream_t stream, uint32_t sh
     const uint64_t hn = pk->N ? pk->N - 1 : 0;
     shard_range(m + 4, shard_index, shard_count, &pk->z_lo, &pk->z_cnt);
     shard_range(hn, shard_index, shard_count, &pk->h_lo, &pk->h_cnt);
+    // every shard of a key uses the window size of the largest shard (see precomp_build)
+    const uint64_t z_plan = shard_count > 1 ? (m + 4 + shard_count - 1) / shard_count : 0;
+    const uint64_t h_plan = shard_count > 1 ? (hn + shard_count - 1) / shard_count : 0;
     ext(d->a_query, G1, d->alpha_g1, d->delta_g1, nullptr);
-    precomp_build<Fq, Fr>(pk->a_ext, (uint8_t*)stage.p + pk->z_lo * G1, pk->z_cnt, stream);
+    precomp_build<Fq, Fr>(pk->a_ext, (uint8_t*)stage.p + pk->z_lo * G1, pk->z_cnt, stream, z_plan);
     ext(d->b_g1_query, G1, d->beta_g1, nullptr, d->delta_g1);
-    precomp_build<Fq, Fr>(pk->b1_ext, (uint8_t*)stage.p + pk->z_lo * G1, pk->z_cnt, stream);
+    precomp_build<Fq, Fr>(pk->b1_ext, (uint8_t*)stage.p + pk->z_lo * G1, pk->z_cnt, stream, z_plan);
     ext(d->b_g2_query, G2, d->beta_g2, nullptr, d->delta_g2);
-    precomp_build<Fq2, Fr>(pk->b2_ext, (uint8_t*)stage.p + pk->z_lo * G2, pk->z_cnt, stream);
+    precomp_build<Fq2, Fr>(pk->b2_ext, (uint8_t*)stage.p + pk->z_lo * G2, pk->z_cnt, stream, z_plan);
     stage.ensure((pk->h_cnt ? pk->h_cnt : 1) * G1);
     if (pk->h_cnt) ARK_CHECK_HIP(hipMemcpy(stage.p, d->h_query + pk->h_lo * G1, pk->h_cnt * G1, hipMemcpyHostToDevice));
-    precomp_build<Fq, Fr>(pk->h_query, stage.p, pk->h_cnt, stream);
+    precomp_build<Fq, Fr>(pk->h_query, stage.p, pk->h_cnt, stream, h_plan);
     // l_ext aligned with zx: ell leading infinities (instance variables carry no l term), l_query, delta_1 at
     // the -rs slot, three trailing infinities
     stage.ensure((m + 4) * G1);
     ARK_CHECK_HIP(hipMemset(stage.p, 0, (m + 4) * G1));
     if (pk->w) ARK_CHECK_HIP(hipMemcpy((uint8_t*)stage.p + pk->ell * G1, d->l_query, pk->w * G1, hipMemcpyHostToDevice));
     ARK_CHECK_HIP(hipMemcpy((uint8_t*)stage.p + m * G1, d->delta_g1, G1, hipMemcpyHostToDevice));
-    precomp_build<Fq, Fr>(pk->l_ext, (uint8_t*)stage.p + pk->z_lo * G1, pk->z_cnt, stream);
+    precomp_build<Fq, Fr>(pk->l_ext, (uint8_t*)stage.p + pk->z_lo * G1, pk->z_cnt, stream, z_plan);
   } catch (...) {
     delete pk;
     throw;
@@ -231,7 +246,7 @@ static PkDev* pk_upload(const ark355_pk_desc* d, hipStream_t stream, uint32_t sh
 template <class Curve>
 static void prove_run(ark355_ctx* ctx, ProverScratch& sc, const PkDev& pk, const R1csDev& r1, const void* z_src,
                       bool z_on_device, const uint8_t r_canon[32], const uint8_t s_canon[32], ark355_proof_raw* out,
-                      uint8_t* partials_out = nullptr) {
+                      uint8_t* partials_out = nullptr, CommDev* cm = nullptr, int shard_mode = 0) {
   using Fr = typename Curve::Fr;
   using Fq = typename Curve::Fq;
   using Fq2 = typename Curve::Fq2;
@@ -277,21 +292,12 @@ static void prove_run(ark355_ctx* ctx, ProverScratch& sc, const PkDev& pk, const
               sR = one_stream ? sM : sc.sR;
   const uint64_t m = pk.m, ell = pk.ell;
   enum { E_START, E_Z, E_H, E_SORT0, E_SORT1, E_SORT2, E_ACC_DONE0, E_END = E_ACC_DONE0 + 5, E_COUNT };
-  hipEvent_t ev[E_COUNT];
-  hipEvent_t acc0[5], acc1[5];
-  for (auto& e : ev) ARK_CHECK_HIP(hipEventCreate(&e));
-  for (int i = 0; i < 5; i++) {
-    ARK_CHECK_HIP(hipEventCreate(&acc0[i]));
-    ARK_CHECK_HIP(hipEventCreate(&acc1[i]));
-  }
-  auto cleanup = [&] {
-    for (auto& e : ev) (void)hipEventDestroy(e);
-    for (int i = 0; i < 5; i++) {
-      (void)hipEventDestroy(acc0[i]);
-      (void)hipEventDestroy(acc1[i]);
-    }
-  };
-  try {
+  static_assert(E_COUNT + 10 <= ProverScratch::N_EVENTS, "event pool too small");
+  sc.ensure_events();
+  hipEvent_t* ev = sc.events;
+  hipEvent_t* acc0 = sc.events + E_COUNT;
+  hipEvent_t* acc1 = sc.events + E_COUNT + 5;
+  {
     // r, s -> Montgomery on the host (the library's own field code); tail = [-rs, 1, r, s]
     Fr rc, scn;
     memcpy(rc.l, r_canon, sizeof(Fr));
@@ -356,14 +362,38 @@ static void prove_run(ark355_ctx* ctx, ProverScratch& sc, const PkDev& pk, const
       }
       ARK_CHECK_HIP(hipEventRecord(ev[E_ACC_DONE0 + j], sA));
       ARK_CHECK_HIP(hipStreamWaitEvent(sR, ev[E_ACC_DONE0 + j], 0));
-      if (jb.g2) msm_reduce_phase<Fq2>(ctx, *jb.sort, *jb.bk, g2res, 0, sR);
-      else msm_reduce_phase<Fq>(ctx, *jb.sort, *jb.bk, g1res + jb.res, 0, sR);
+      if (cm && shard_mode == ARK355_SHARD_BUCKET_RING) {
+        // bucket-level exchange: the ranks run their MSMs in the same order, so the ring steps pair up
+        if (jb.g2)
+          msm_reduce_phase<Fq2>(ctx, *jb.sort, *jb.bk, g2res, 0, sR, [&](XYZZ<Fq2>* bk, uint32_t nb, hipStream_t st) {
+            ring_reduce_scatter_buckets<Fq2>(*cm, bk, nb, st);
+          });
+        else
+          msm_reduce_phase<Fq>(ctx, *jb.sort, *jb.bk, g1res + jb.res, 0, sR, [&](XYZZ<Fq>* bk, uint32_t nb, hipStream_t st) {
+            ring_reduce_scatter_buckets<Fq>(*cm, bk, nb, st);
+          });
+      } else if (jb.g2) {
+        msm_reduce_phase<Fq2>(ctx, *jb.sort, *jb.bk, g2res, 0, sR);
+      } else {
+        msm_reduce_phase<Fq>(ctx, *jb.sort, *jb.bk, g1res + jb.res, 0, sR);
+      }
       pts += (uint64_t)jb.sort->plan.windows * jb.sort->plan.n;
     }
 
     if (out) memset(out, 0, sizeof(*out));
     const char* dev_fin = getenv("ARK355_DEVICE_FINALIZE");
-    if (partials_out) {
+    if (cm) {
+      // sharded prove: all-gather of the five XYZZ partial sums (A, B1, L', H in G1, then B2 in G2) straight from HBM
+      // on the reduction stream, then the O(world) additions and the O(1) tail on the host -- on every rank
+      const size_t psz = 4 * sizeof(XYZZ<Fq>) + sizeof(XYZZ<Fq2>);
+      cm->gather.ensure(psz * (size_t)cm->world);
+      ARK_CHECK_NCCL(ncclAllGather(g1res, cm->gather.p, psz, ncclUint8, cm->comm, sR));
+      std::vector<uint8_t> all(psz * (size_t)cm->world);
+      ARK_CHECK_HIP(hipMemcpyAsync(all.data(), cm->gather.p, all.size(), hipMemcpyDeviceToHost, sR));
+      ARK_CHECK_HIP(hipEventRecord(ev[E_END], sR));
+      ARK_CHECK_HIP(hipStreamSynchronize(sR));
+      combine_partials_host<Curve>(all.data(), (uint64_t)cm->world, r_canon, s_canon, out);
+    } else if (partials_out) {
       // sharded prove: hand back the five XYZZ partial sums (A, B1, L', H in G1, then B2 in G2)
       ARK_CHECK_HIP(hipMemcpyAsync(partials_out, g1res, 4 * sizeof(XYZZ<Fq>) + sizeof(XYZZ<Fq2>), hipMemcpyDeviceToHost, sR));
       ARK_CHECK_HIP(hipEventRecord(ev[E_END], sR));
@@ -416,11 +446,7 @@ static void prove_run(ark355_ctx* ctx, ProverScratch& sc, const PkDev& pk, const
     ctx->acc_ms = acc_ms;
     ctx->acc_launches = 5;
     ctx->acc_points = pts;
-  } catch (...) {
-    cleanup();
-    throw;
   }
-  cleanup();
 }
 
 }  // namespace ark355

@@ -900,10 +900,13 @@ static inline bool msm_use_limb28(bool g2) {       // read when a table is built
   return e ? (e[0] == '1') : (ARK_LIMB28_DEFAULT != 0);
 }
 
+// plan_n: the length the window size is chosen for (0 = n).  The shards of one key pass the LARGEST shard length so
+// that every rank uses the same window size -- the bucket-level exchange adds bucket arrays of different ranks.
 template <class F, class Fr>
-static void precomp_build(PrecompTable& t, const void* d_bases, uint64_t n, hipStream_t stream) {
+static void precomp_build(PrecompTable& t, const void* d_bases, uint64_t n, hipStream_t stream, uint64_t plan_n = 0) {
   t.n = n;
-  t.plan = msm_plan(n, Fr::Params::BITS, /*precomp=*/true);
+  t.plan = msm_plan(n, Fr::Params::BITS, /*precomp=*/true,
+                    plan_n ? (int)msm_plan(plan_n, Fr::Params::BITS, /*precomp=*/true).c : 0);
   const MsmPlan& p = t.plan;
   ARK_REQUIRE((uint64_t)p.windows * n < (1ull << 31), ARK355_EINVAL, "window table too large for 31-bit indices");
   t.table.alloc((size_t)p.windows * (n ? n : 1) * sizeof(Affine<F>));
@@ -1117,31 +1120,42 @@ static void msm_accumulate_phase(ark355_ctx* ctx, const MsmSort& s, MsmBuckets& 
 // Phase 2: straddling-run merge, weighted bucket reduction, window combination; writes/accumulates the XYZZ
 // result into d_out.  Only a handful of workgroups and latency-bound, so the prover runs it on its own stream
 // underneath the next MSM's accumulation.
-template <class F>
+// after_merge (optional): called with the complete local bucket array between the merge and the weighted reduction
+// (the bucket-level cross-GPU exchange of comm_impl.cuh).
+template <class F, class Hook = std::nullptr_t>
 static void msm_reduce_phase(ark355_ctx* ctx, const MsmSort& s, MsmBuckets& b, XYZZ<F>* d_out, int accumulate,
-                             hipStream_t stream) {
+                             hipStream_t stream, Hook after_merge = nullptr) {
   const MsmPlan& p = s.plan;
+  constexpr bool HOOK = !std::is_same<Hook, std::nullptr_t>::value;
   if (p.n == 0) {
-    if (!accumulate) ARK_CHECK_HIP(hipMemsetAsync(d_out, 0, sizeof(XYZZ<F>), stream));
-    return;
+    if constexpr (HOOK) {
+      // an empty shard still takes part in the exchange: all-infinity bucket array
+      b.buckets.ensure((size_t)p.total_buckets * sizeof(XYZZ<F>));
+      ARK_CHECK_HIP(hipMemsetAsync(b.buckets.p, 0, (size_t)p.total_buckets * sizeof(XYZZ<F>), stream));
+    } else {
+      if (!accumulate) ARK_CHECK_HIP(hipMemsetAsync(d_out, 0, sizeof(XYZZ<F>), stream));
+      return;
+    }
+  } else {
+    const uint32_t segs = s.max_segments;
+    const uint32_t grid_b = (p.total_buckets + MSM_THREADS - 1) / MSM_THREADS;
+    // at most entries / (MSM_HEAVY_SPAN * segment length) buckets can be heavy
+    const uint32_t max_heavy = segs / MSM_HEAVY_SPAN + 1;
+    b.heavy_count.ensure(16);
+    b.heavy_list.ensure((size_t)max_heavy * 4);
+    ARK_CHECK_HIP(hipMemsetAsync(b.heavy_count.p, 0, 4, stream));
+    ARK_LAUNCH((msm_merge_kernel<F>), dim3(grid_b), dim3(MSM_THREADS), 0, stream, p.total_buckets,
+               s.offsets.as<uint32_t>(), s.counts.as<uint32_t>(), b.buckets.as<XYZZ<F>>(), b.head.as<XYZZ<F>>(),
+               b.head_key.as<uint32_t>(), b.tail.as<XYZZ<F>>(), b.tail_key.as<uint32_t>(),
+               b.heavy_count.as<uint32_t>(), b.heavy_list.as<uint32_t>(), p.seg_log);
+    ARK_CHECK_LAUNCH();
+    const uint32_t grid_h = max_heavy < ARK_MSM_HEAVY_GRID ? max_heavy : ARK_MSM_HEAVY_GRID;
+    ARK_LAUNCH((msm_merge_heavy_kernel<F>), dim3(grid_h), dim3(MSM_THREADS), 0, stream, b.heavy_count.as<uint32_t>(),
+               b.heavy_list.as<uint32_t>(), s.offsets.as<uint32_t>(), s.counts.as<uint32_t>(), b.buckets.as<XYZZ<F>>(),
+               b.head.as<XYZZ<F>>(), b.head_key.as<uint32_t>(), b.tail.as<XYZZ<F>>(), b.tail_key.as<uint32_t>(), p.seg_log);
+    ARK_CHECK_LAUNCH();
   }
-  const uint32_t segs = s.max_segments;
-  const uint32_t grid_b = (p.total_buckets + MSM_THREADS - 1) / MSM_THREADS;
-  // at most entries / (MSM_HEAVY_SPAN * segment length) buckets can be heavy
-  const uint32_t max_heavy = segs / MSM_HEAVY_SPAN + 1;
-  b.heavy_count.ensure(16);
-  b.heavy_list.ensure((size_t)max_heavy * 4);
-  ARK_CHECK_HIP(hipMemsetAsync(b.heavy_count.p, 0, 4, stream));
-  ARK_LAUNCH((msm_merge_kernel<F>), dim3(grid_b), dim3(MSM_THREADS), 0, stream, p.total_buckets,
-             s.offsets.as<uint32_t>(), s.counts.as<uint32_t>(), b.buckets.as<XYZZ<F>>(), b.head.as<XYZZ<F>>(),
-             b.head_key.as<uint32_t>(), b.tail.as<XYZZ<F>>(), b.tail_key.as<uint32_t>(),
-             b.heavy_count.as<uint32_t>(), b.heavy_list.as<uint32_t>(), p.seg_log);
-  ARK_CHECK_LAUNCH();
-  const uint32_t grid_h = max_heavy < ARK_MSM_HEAVY_GRID ? max_heavy : ARK_MSM_HEAVY_GRID;
-  ARK_LAUNCH((msm_merge_heavy_kernel<F>), dim3(grid_h), dim3(MSM_THREADS), 0, stream, b.heavy_count.as<uint32_t>(),
-             b.heavy_list.as<uint32_t>(), s.offsets.as<uint32_t>(), s.counts.as<uint32_t>(), b.buckets.as<XYZZ<F>>(),
-             b.head.as<XYZZ<F>>(), b.head_key.as<uint32_t>(), b.tail.as<XYZZ<F>>(), b.tail_key.as<uint32_t>(), p.seg_log);
-  ARK_CHECK_LAUNCH();
+  if constexpr (HOOK) after_merge(b.buckets.as<XYZZ<F>>(), p.total_buckets, stream);
 
   const uint32_t chunks = (p.buckets_per_window + MSM_RED_K - 1) / MSM_RED_K;
   const uint32_t blocks_per_window = (chunks + MSM_THREADS - 1) / MSM_THREADS;

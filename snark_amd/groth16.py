@@ -103,6 +103,21 @@ class ProvingKey:
     # retained only when setup is asked to keep the toxic waste (tests / benches: closed-form check)
     trapdoor: Optional[dict] = None
 
+    def check_lengths(self, sizes):
+        """The C ABI copies (ell+w), (N-1) and w points from bare pointers: every vector must really hold that many
+        (a malformed serialized key must fail here, not read out of bounds)."""
+        m, g1, g2 = self.ell + self.w, sizes["g1"], sizes["g2"]
+        want = (("a_query", m * g1), ("b_g1_query", m * g1), ("b_g2_query", m * g2), ("h_query", (self.N - 1) * g1),
+                ("l_query", self.w * g1), ("beta_g1", g1), ("delta_g1", g1))
+        for name, n in want:
+            if len(getattr(self, name)) != n:
+                raise ValueError("proving key: %s holds %d bytes, expected %d" % (name, len(getattr(self, name)), n))
+        for name, n in (("alpha_g1", g1), ("beta_g2", g2), ("delta_g2", g2)):
+            if len(getattr(self.vk, name)) != n:
+                raise ValueError("proving key: vk.%s holds %d bytes, expected %d" % (name, len(getattr(self.vk, name)), n))
+        if self.ell < 1 or self.N < 1 or (self.N & (self.N - 1)):
+            raise ValueError("proving key: bad dimensions")
+
 
 @dataclass
 class Proof:
@@ -153,12 +168,26 @@ class Groth16:
         self.lib = lib if lib is not None else _lib()
         self.ctx = self.lib.ctx_create(device)
         self.sizes = self.lib.sizes(self.curve.curve_id)
-        self._handles = {}
+        self._finalizers = []
+
+    # Device handles live ON the host object they image (attribute + weakref finalizer), never in a table keyed by
+    # id(obj): CPython reuses ids after collection, and a dropped 2^20 key must give its ~15 GB of HBM back.
+    def _track(self, obj, attr, value, free_fn, handle):
+        import weakref
+        setattr(obj, attr, value)
+        fin = weakref.finalize(obj, free_fn, handle)
+        fin.atexit = False
+        self._finalizers.append(fin)
+        self._finalizers = [f for f in self._finalizers if f.alive]
+
+    def _cached(self, obj, attr):
+        v = getattr(obj, attr, None)
+        return v[1] if (v is not None and v[0] is self) else None
 
     def close(self):
-        for kind, h in list(self._handles.values()):
-            (self.lib.dll.ark355_pk_free if kind == "pk" else self.lib.dll.ark355_r1cs_free)(h)
-        self._handles.clear()
+        for fin in self._finalizers:
+            fin()                                   # frees the handle once; a no-op if the object already died
+        self._finalizers = []
         if self.ctx is not None:
             self.lib.ctx_destroy(self.ctx)
             self.ctx = None
@@ -217,24 +246,25 @@ class Groth16:
 
     # ---- device residency ---------------------------------------------------------------------------------
     def load_pk(self, pk: ProvingKey):
-        key = ("pk", id(pk))
-        if key not in self._handles:
+        h = self._cached(pk, "_ark355_pk")
+        if h is None:
+            pk.check_lengths(self.sizes)
             h = self.lib.pk_load(self.ctx, self.curve.curve_id, pk.ell, pk.w, pk.N, pk.a_query, pk.b_g1_query,
                                  pk.b_g2_query, pk.h_query, pk.l_query, pk.vk.alpha_g1, pk.beta_g1, pk.delta_g1,
                                  pk.vk.beta_g2, pk.vk.delta_g2)
-            self._handles[key] = ("pk", h)
-        return self._handles[key][1]
+            self._track(pk, "_ark355_pk", (self, h), self.lib.dll.ark355_pk_free, h)
+        return h
 
     def load_r1cs(self, r1cs: R1CS):
-        key = ("r1cs", id(r1cs))
-        if key not in self._handles:
+        h = self._cached(r1cs, "_ark355_r1cs")
+        if h is None:
             try:
                 h = self.lib.r1cs_load(self.ctx, self.curve.curve_id, r1cs.n, r1cs.ell, r1cs.w,
                                        list(zip(r1cs.row_ptr, r1cs.col, r1cs.coeff)))
             except Ark355Error as e:
                 raise SynthesisError(str(e)) from e
-            self._handles[key] = ("r1cs", h)
-        return self._handles[key][1]
+            self._track(r1cs, "_ark355_r1cs", (self, h), self.lib.dll.ark355_r1cs_free, h)
+        return h
 
     # ---- SNARK::prove (snark/src/lib.rs:50-54) ---------------------------------------------------------------
     def prove(self, pk: ProvingKey, r1cs: R1CS, z, rng=None, r: Optional[int] = None, s: Optional[int] = None,
@@ -249,6 +279,13 @@ class Groth16:
         pkh, rh = self.load_pk(pk), self.load_r1cs(r1cs)
         try:
             if z_device_ptr is not None:
+                # The library reads z on its own streams: whatever produced it (e.g. torch's current stream) must have
+                # finished.  With torch loaded this is one device synchronisation; other producers synchronise
+                # themselves (include/ark355.h, "*_dev variants").
+                import sys
+                torch = sys.modules.get("torch")
+                if torch is not None and torch.cuda.is_available():
+                    torch.cuda.synchronize()
                 a, b, c = self.lib.prove(self.ctx, pkh, rh, z_device_ptr, r1cs.m, cv.fr_canon(r), cv.fr_canon(s),
                                          self.sizes, z_is_device_ptr=True)
             else:

@@ -155,6 +155,29 @@ def g2_serialize(curve: Curve, P, compressed=True) -> bytes:
     return bytes(b)
 
 
+def _g1_checked(curve: Curve, x, y):
+    """Uncompressed points get the on-curve test ark-serialize performs under Validate::Yes.  (Its prime-subgroup test
+    is a scalar multiplication per point; keys come from a trusted setup, proofs are checked by the verifier.)"""
+    q = curve.q
+    if x >= q or y >= q:
+        raise ValueError("coordinate not reduced")
+    if (y * y - x * x * x - _G1_B[curve.name]) % q:
+        raise ValueError("point not on curve")
+    return (x, y)
+
+
+def _g2_checked(curve: Curve, x, y):
+    q = curve.q
+    if max(x[0], x[1], y[0], y[1]) >= q:
+        raise ValueError("coordinate not reduced")
+    x3 = _fq2_mul(q, _fq2_mul(q, x, x), x)
+    bb = _g2_b(curve)
+    y2 = _fq2_mul(q, y, y)
+    if (y2[0] - x3[0] - bb[0]) % q or (y2[1] - x3[1] - bb[1]) % q:
+        raise ValueError("point not on curve")
+    return (x, y)
+
+
 def g1_deserialize(curve: Curve, b: bytes, compressed=True):
     q, nb = curve.q, curve.fq_bytes
     bls = curve.name == "bls12_381"
@@ -166,7 +189,7 @@ def g1_deserialize(curve: Curve, b: bytes, compressed=True):
             return None
         x = int.from_bytes(b[:nb], "big")
         if not compressed:
-            return (x, int.from_bytes(b[nb:2 * nb], "big"))
+            return _g1_checked(curve, x, int.from_bytes(b[nb:2 * nb], "big"))
         want_largest = bool(flags & 0x20)
     else:
         flags = b[-1] & 0xC0
@@ -175,8 +198,10 @@ def g1_deserialize(curve: Curve, b: bytes, compressed=True):
             return None
         x = int.from_bytes(b[:nb], "little")
         if not compressed:
-            return (x, int.from_bytes(b[nb:2 * nb], "little"))
+            return _g1_checked(curve, x, int.from_bytes(b[nb:2 * nb], "little"))
         want_largest = bool(flags & 0x80)
+    if x >= q:
+        raise ValueError("coordinate not reduced")
     y = _fq_sqrt(q, (x * x * x + _G1_B[curve.name]) % q)
     if y is None:
         raise ValueError("point not on curve")
@@ -196,7 +221,7 @@ def g2_deserialize(curve: Curve, b: bytes, compressed=True):
             return None
         x = (int.from_bytes(b[nb:2 * nb], "big"), int.from_bytes(b[:nb], "big"))
         if not compressed:
-            return (x, (int.from_bytes(b[3 * nb:4 * nb], "big"), int.from_bytes(b[2 * nb:3 * nb], "big")))
+            return _g2_checked(curve, x, (int.from_bytes(b[3 * nb:4 * nb], "big"), int.from_bytes(b[2 * nb:3 * nb], "big")))
         want_largest = bool(flags & 0x20)
     else:
         flags = b[-1] & 0xC0
@@ -207,7 +232,7 @@ def g2_deserialize(curve: Curve, b: bytes, compressed=True):
         v = [int.from_bytes(b[i * nb:(i + 1) * nb], "little") for i in range(n)]
         x = (v[0], v[1])
         if not compressed:
-            return (x, (v[2], v[3]))
+            return _g2_checked(curve, x, (v[2], v[3]))
         want_largest = bool(flags & 0x80)
     x3 = _fq2_mul(q, _fq2_mul(q, x, x), x)
     bb = _g2_b(curve)
@@ -278,19 +303,27 @@ class _Reader:
 
     def g1(self):
         n = g1_size(self.c, self.cmp)
+        if self.o + n > len(self.b):
+            raise ValueError("truncated proving key")
         p = g1_deserialize(self.c, self.b[self.o:self.o + n], self.cmp)
         self.o += n
         return g1_to_raw(self.c, p)
 
     def g2(self):
         n = g2_size(self.c, self.cmp)
+        if self.o + n > len(self.b):
+            raise ValueError("truncated proving key")
         p = g2_deserialize(self.c, self.b[self.o:self.o + n], self.cmp)
         self.o += n
         return g2_to_raw(self.c, p)
 
     def vec(self, fn):
+        if self.o + 8 > len(self.b):
+            raise ValueError("truncated proving key")
         n = int.from_bytes(self.b[self.o:self.o + 8], "little")
         self.o += 8
+        if n > len(self.b):                       # every element takes at least one byte
+            raise ValueError("vector length exceeds the stream")
         return b"".join(fn() for _ in range(n)), n
 
 
@@ -308,5 +341,11 @@ def pk_from_bytes(curve: Curve, b: bytes, compressed=False) -> ProvingKey:
     l, w = r.vec(r.g1)
     if r.o != len(b):
         raise ValueError("trailing bytes in proving key")
+    # ark355_pk_load copies (ell+w), (N-1) and w points from bare pointers: the five vectors must agree
+    if not (m == ell + w and len(b1) == len(a) and len(b2) // curve.g2_bytes == m and ell >= 1):
+        raise ValueError("proving key: inconsistent query lengths (a=%d, b_g1=%d, b_g2=%d, gamma_abc=%d, l=%d)"
+                         % (m, len(b1) // curve.g1_bytes, len(b2) // curve.g2_bytes, ell, w))
+    if (hn + 1) & hn:
+        raise ValueError("proving key: h_query length + 1 is not a power of two")
     return ProvingKey(vk=vk, beta_g1=beta1, delta_g1=delta1, a_query=a, b_g1_query=b1, b_g2_query=b2, h_query=h,
                       l_query=l, ell=ell, w=w, N=hn + 1)

@@ -12,7 +12,7 @@ ROOT = os.path.normpath(os.path.join(HERE, "..", ".."))
 CSRC = os.path.join(ROOT, "snark_amd", "csrc")
 OUT = os.path.join(HERE, "libark355_emul.so")
 SRCS = [os.path.join(CSRC, f) for f in ("capi.hip", "ark355_bls.hip", "ark355_bn.hip")] + [
-    os.path.join(HERE, "hip_emul.cpp")]
+    os.path.join(HERE, "hip_emul.cpp"), os.path.join(HERE, "rccl_emul.cpp")]
 
 
 def newest_src():
@@ -28,7 +28,7 @@ def build(force=False):
     if not force and os.path.exists(OUT) and os.path.getmtime(OUT) >= newest_src():
         return OUT
     objs = []
-    flags = ["-O1", "-g", "-std=c++17", "-fPIC", "-DARK_EMUL", "-DARK_MSM_HEAVY_SPAN=2", "-DARK_MSM_HEAVY_GRID=3u", "-I", HERE, "-I", CSRC, "-w"]
+    flags = ["-O2", "-std=c++17", "-fPIC", "-DARK_EMUL", "-DARK_MSM_HEAVY_SPAN=2", "-DARK_MSM_HEAVY_GRID=3u", "-I", HERE, "-I", CSRC, "-w"]
 
     def cc(src):
         obj = os.path.join(HERE, os.path.basename(src) + ".emul.o")
@@ -37,7 +37,7 @@ def build(force=False):
 
     with ThreadPoolExecutor(4) as ex:
         objs = list(ex.map(cc, SRCS))
-    subprocess.check_call(["g++", "-shared", "-Wl,-Bsymbolic", "-o", OUT, *objs, "-lpthread"])
+    subprocess.check_call(["g++", "-shared", "-Wl,-Bsymbolic", "-o", OUT, *objs, "-lpthread", "-lrt"])
     return OUT
 
 

@@ -1,0 +1,96 @@
+"""Checks of the C ABI against the independent C oracle (O3: oracle/c), shared by the GPU tier at BASELINE sizes
+(tests/test_gpu_o3_large.py) and the CPU-emulator tier at tiny sizes (tests/test_emul_o3.py).  The proving key comes
+from the ORACLE's generator (cbase.setup_raw_c), never from the product's setup."""
+import random
+
+import numpy as np
+
+from oracle import groth16 as G, serialize as Z, synthetic as S
+from oracle.c import cbase
+
+TD = G.Trapdoor(tau=0x1F3D5B79A8C6E4F2_0123456789ABCDEF, alpha=0xA1, beta=0xB2B2, gamma=0xC3C3C3, delta=0xD4D4D4D4)
+
+
+def load(lib, ctx, C, inst, pk):
+    n, ell, w, mats, z = inst
+    N = 1
+    while N < n + ell:
+        N <<= 1
+    pkh = lib.pk_load(ctx, C.curve_id, ell, w, N, pk["a_query"], pk["b_g1_query"], pk["b_g2_query"], pk["h_query"],
+                      pk["l_query"], pk["alpha_g1"], pk["beta_g1"], pk["delta_g1"], pk["beta_g2"], pk["delta_g2"])
+    rh = lib.r1cs_load(ctx, C.curve_id, n, ell, w, mats)
+    return pkh, rh
+
+
+def free(lib, pkh, rh):
+    lib.dll.ark355_pk_free(pkh)
+    lib.dll.ark355_r1cs_free(rh)
+
+
+def check_instance(lib, ctx, C, inst, rs_pairs, batch=0, inflight=4):
+    n, ell, w, mats, z = inst
+    pk, _ = cbase.setup_raw_c(C, n, ell, w, mats, TD)
+    zb = S._mont_bytes(C.r, z)
+    sizes = lib.sizes(C.curve_id)
+    pkh, rh = load(lib, ctx, C, inst, pk)
+    try:
+        assert lib.is_satisfied(ctx, rh, zb, len(z)) == -1
+        for r_, s_ in rs_pairs:
+            got = lib.prove(ctx, pkh, rh, zb, len(z), Z.fr_canon(C, r_), Z.fr_canon(C, s_), sizes)
+            exp = cbase.prove(C, n, ell, w, mats, zb, pk, r_, s_)
+            assert got == exp, (C.name, n, "ark355_prove vs oracle/c")
+        if batch:
+            rnd = random.Random(batch)
+            rs = [(rnd.randrange(C.r), rnd.randrange(C.r)) for _ in range(batch)]
+            outs = lib.prove_batch(ctx, pkh, rh, [zb] * batch, len(z), [Z.fr_canon(C, a) for a, _ in rs],
+                                   [Z.fr_canon(C, b) for _, b in rs], sizes, inflight=inflight)
+            for (r_, s_), got in zip(rs, outs):
+                assert got == cbase.prove(C, n, ell, w, mats, zb, pk, r_, s_), (C.name, n, "ark355_prove_batch")
+    finally:
+        free(lib, pkh, rh)
+
+
+def scalars(C, n, dist, seed):
+    """MSM micro-benchmark scalar distributions of SURVEY.md 8d, canonical 32-byte LE."""
+    rnd = random.Random(seed)
+    top = (1 << (C.r.bit_length() - 1 - 192)) - 1                        # values < 2^(bits-1) < r: canonical
+    if dist == "uniform":
+        raw = np.frombuffer(rnd.randbytes(32 * n), dtype="<u8").reshape(n, 4).copy()
+        raw[:, 3] &= top
+        return raw.tobytes()
+    if dist == "equal":
+        return Z.fr_canon(C, rnd.randrange(C.r)) * n
+    assert dist == "boolean"                                             # 90 % in {0, 1}, 10 % uniform
+    raw = np.zeros((n, 4), dtype="<u8")
+    kind = np.frombuffer(rnd.randbytes(n), dtype=np.uint8)
+    raw[:, 0] = (kind & 1)
+    uni = np.frombuffer(rnd.randbytes(32 * n), dtype="<u8").reshape(n, 4).copy()
+    uni[:, 3] &= top
+    sel = kind >= 230
+    raw[sel] = uni[sel]
+    return raw.tobytes()
+
+
+def bases(C, group, n):
+    """P_i = (i + 1) * G  (SURVEY.md 8d MSM micro-benchmark), from the oracle's fixed-base routine."""
+    ks = np.zeros((n, 4), dtype="<u8")
+    ks[:, 0] = np.arange(1, n + 1, dtype=np.uint64)
+    gen = Z.g1_raw(C, C.g1_gen) if group == 1 else Z.g2_raw(C, C.g2_gen)
+    return cbase.fixed_base(C, group, gen, ks.tobytes(), n)
+
+
+def check_resident_msm(lib, ctx, C, group, n, to_dev, seed=1):
+    """ark355_bases_load + ark355_msm_dev (window tables, radix-2^28 accumulation) vs cbase.msm for the three
+    distributions.  to_dev(bytes) -> (device pointer, keepalive)."""
+    sz = lib.sizes(C.curve_id)
+    psz = sz["g1"] if group == 1 else sz["g2"]
+    pts = bases(C, group, n)
+    bh = lib.bases_load(ctx, C.curve_id, group, pts, n)
+    try:
+        for dist in ("uniform", "equal", "boolean"):
+            sc = scalars(C, n, dist, seed=seed * 10 + group)
+            ptr, keep = to_dev(sc)
+            got = lib.msm_dev(ctx, bh, ptr, n, 0, psz)
+            assert got == cbase.msm(C, group, pts, sc, n), (group, n, dist)
+    finally:
+        lib.dll.ark355_bases_free(bh)

@@ -1,0 +1,48 @@
+"""bench.py's multi-rank plumbing on a machine without GPUs: `--gpus 2` outside a launcher must start two ranks itself,
+run a collective over them and print ONE JSON line with n_gpus == 2 -- in replica mode (weak scaling, independent
+proofs) and in shard mode (strong scaling, RCCL behind the C ABI; here its shared-memory emulation).  --dry-run-emul
+swaps libark355.so for the CPU emulator build of the same sources (checker); the numbers are not measurements."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+
+def _run(*extra):
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dry-run-emul", "--steps", "2", "--warmup", "1",
+                        *extra], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    return json.loads(lines[0])
+
+
+def test_bench_gpus_2_spawns_two_replica_ranks():
+    d = _run("--gpus", "2")
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["steps"] == 2 and d["warmup"] == 1
+    assert d["parity"] == "proof == trapdoor closed form"
+    assert "EMULATOR DRY RUN" in d["data"] and "replicas x2" in d["config"]["parallelism"]
+    for key in ("metric", "value", "unit", "ms_per_step", "higher_is_better", "vs_baseline", "dtype", "roofline"):
+        assert key in d
+
+
+@pytest.mark.parametrize("exchange", ["window", "ring"])
+def test_bench_shard_mode_two_ranks(exchange):
+    d = _run("--gpus", "2", "--mode", "shard", "--shard-exchange", exchange, "--log-n", "7")
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong"
+    assert d["parity"] == "proof == trapdoor closed form"
+    assert "msm-shard x2" in d["config"]["parallelism"]
+
+
+def test_bench_refuses_a_world_size_that_contradicts_gpus():
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dry-run-emul", "--gpus", "2"],
+                       capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert r.returncode != 0 and "--gpus 2 but the launcher started 1 ranks" in r.stderr

@@ -1,0 +1,24 @@
+"""The O3 checks of tests/o3_cases.py at tiny sizes over the CPU emulator build of the library's sources (checker
+only): keeps the logic of the BASELINE-size GPU tests (tests/test_gpu_o3_large.py) exercised on a machine without a GPU."""
+import numpy as np
+import pytest
+
+import o3_cases as O
+from oracle import synthetic as S
+from oracle.fields import BLS12_381, BN254
+
+
+@pytest.mark.parametrize("C", [BLS12_381, BN254], ids=lambda c: c.name)
+def test_instances_vs_o3_on_the_emulator(emul_lib, emul_ctx, C):
+    O.check_instance(emul_lib, emul_ctx, C, S.mulchain_csr(C.r, 70), [(5, 7)], batch=2, inflight=1)
+    O.check_instance(emul_lib, emul_ctx, C, S.dummy_csr(C.r, 64), [(0, 1)])
+    O.check_instance(emul_lib, emul_ctx, C, S.bench_lc_csr(C.r, 40), [(C.r - 1, C.r - 1)])
+
+
+@pytest.mark.parametrize("group", [1, 2])
+def test_resident_msm_vs_o3_on_the_emulator(emul_lib, emul_ctx, group):
+    def to_dev(b):
+        a = np.frombuffer(b, dtype=np.uint8).copy()
+        return a.ctypes.data, a
+
+    O.check_resident_msm(emul_lib, emul_ctx, BLS12_381, group, 200, to_dev)

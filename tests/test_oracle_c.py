@@ -69,3 +69,52 @@ def test_c_prover_equals_closed_form(C):
 def test_cpu_baseline_record_shape():
     rec = cbase.bench_prove("bls12_381", log_n=8, budget_s=2.0)
     assert rec["kind"] == "port" and rec["unit"] == "constraints/s" and rec["value"] > 0 and rec["cores"] >= 1
+
+
+@pytest.mark.parametrize("C", CURVES, ids=lambda c: c.name)
+def test_direct_csr_builders_match_the_constraint_system_path(C):
+    """The numpy builders used by the large GPU-vs-O3 checks produce exactly what the ConstraintSystem restatement
+    (oracle/r1cs.py) produces for the same circuits."""
+    for n in (5, 64):
+        for direct, via_cs in ((S.mulchain_csr(C.r, n), S.cs_to_instance(S.mulchain_cs(C.r, n))),
+                               (S.dummy_csr(C.r, max(n, 8)), S.cs_to_instance(S.dummy_cs(C.r, max(n, 8)))),
+                               (S.bench_lc_csr(C.r, n), S.cs_to_instance(S.bench_lc_cs(C.r, n)))):
+            nn, ell, w, mats, z = direct
+            A, B, Cm, z2, ell2 = via_cs
+            assert (nn, ell, z) == (len(A), ell2, z2) and w == len(z2) - ell2
+            for got, M in zip(mats, (A, B, Cm)):
+                exp = csr_from_rows(C, M)
+                assert got[0].tolist() == exp[0].tolist() and got[1].tolist() == exp[1].tolist() and got[2] == exp[2]
+
+
+@pytest.mark.parametrize("C", CURVES, ids=lambda c: c.name)
+def test_c_setup_scalars_equal_python_setup(C):
+    n, ell, w, mats, z = S.bench_lc_csr(C.r, 50)
+    A, B, Cm, z2, _ = S.cs_to_instance(S.bench_lc_cs(C.r, 50))
+    td = G.Trapdoor(tau=987654321987654321, alpha=3, beta=5, gamma=7, delta=11)
+    pk_py, sc_py = cbase.setup_raw(C, A, B, Cm, ell, ell + w, td)
+    pk_c, sc_c = cbase.setup_raw_c(C, n, ell, w, mats, td)
+    assert set(pk_py) == set(pk_c)
+    for k in pk_py:
+        assert pk_py[k] == pk_c[k], k
+    for k in "uvw":
+        assert sc_c[k] == b"".join(Z.fr_canon(C, x) for x in sc_py[k])
+
+
+def test_c_msm_is_independent_of_the_thread_partition():
+    C = BLS12_381
+    rnd = random.Random(5)
+    n = 3000
+    ss = b"".join(Z.fr_canon(C, rnd.randrange(C.r)) for _ in range(n))
+    ks = b"".join(Z.fr_canon(C, rnd.randrange(C.r)) for _ in range(n))
+    bases = cbase.fixed_base(C, 1, Z.g1_raw(C, C.g1_gen), ss, n)
+    L = cbase.lib()
+    nt = L.cb_num_threads()
+    try:
+        outs = []
+        for t in (1, 3, 64):
+            L.cb_set_threads(t)
+            outs.append(cbase.msm(C, 1, bases, ks, n))
+    finally:
+        L.cb_set_threads(nt)
+    assert outs[0] == outs[1] == outs[2]

@@ -63,3 +63,32 @@ def test_proof_and_key_bytes_match_oracle_and_round_trip(C, cv):
         assert (back.a_query, back.b_g2_query, back.h_query, back.l_query, back.ell, back.w, back.N) == (
             pk.a_query, pk.b_g2_query, pk.h_query, pk.l_query, pk.ell, pk.w, pk.N)
         assert back.vk == vk and back.beta_g1 == pk.beta_g1 and back.delta_g1 == pk.delta_g1
+
+
+def test_malformed_proving_keys_are_rejected_before_the_abi():
+    """pk vectors reach ark355_pk_load as bare pointers, so inconsistent lengths, truncated streams and
+    off-curve uncompressed points must fail in the loader (ark-serialize Validate::Yes behaviour)."""
+    import pytest
+    from snark_amd import params, serialize as PS
+    from snark_amd.groth16 import ProvingKey, VerifyingKey
+    cv = params.BLS12_381
+    g1, g2 = cv.g1_gen_raw(), cv.g2_gen_raw()
+    vk = VerifyingKey(g1, g2, g2, g2, g1 * 2)
+    pk = ProvingKey(vk=vk, beta_g1=g1, delta_g1=g1, a_query=g1 * 5, b_g1_query=g1 * 5, b_g2_query=g2 * 5,
+                    h_query=g1 * 7, l_query=g1 * 3, ell=2, w=3, N=8)
+    good = PS.pk_to_bytes(cv, pk)
+    back = PS.pk_from_bytes(cv, good)
+    assert (back.ell, back.w, back.N, back.a_query) == (2, 3, 8, pk.a_query)
+    back.check_lengths({"g1": cv.g1_bytes, "g2": cv.g2_bytes})
+    with pytest.raises(ValueError):
+        PS.pk_from_bytes(cv, good[:-5])
+    short = ProvingKey(vk=vk, beta_g1=g1, delta_g1=g1, a_query=g1 * 5, b_g1_query=g1 * 4, b_g2_query=g2 * 5,
+                       h_query=g1 * 7, l_query=g1 * 3, ell=2, w=3, N=8)
+    with pytest.raises(ValueError):
+        PS.pk_from_bytes(cv, PS.pk_to_bytes(cv, short))
+    with pytest.raises(ValueError):
+        short.check_lengths({"g1": cv.g1_bytes, "g2": cv.g2_bytes})
+    bad = bytearray(good)
+    bad[cv.fq_bytes + 3] ^= 1                     # y of alpha_g1: no longer on the curve
+    with pytest.raises(ValueError):
+        PS.pk_from_bytes(cv, bytes(bad))
