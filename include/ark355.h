@@ -163,6 +163,32 @@ int32_t ark355_prove_sharded_dev(ark355_ctx* ctx, ark355_comm* comm, const ark35
                                  const void* d_z, uint64_t z_len, const uint8_t r[32], const uint8_t s[32], int32_t mode,
                                  ark355_proof_raw* out);
 
+/* ---- ark-serialize wire formats (SNARK::{ProvingKey, VerifyingKey, Proof}: CanonicalSerialize +
+ *      CanonicalDeserialize, snark/src/lib.rs:25-36) ------------------------------------------------------------------
+ * Point encodings as upstream writes them: BLS12-381 zcash/IETF (big-endian, flags in the first byte), BN254 ark-ec
+ * SWFlags (little-endian, flags in the last byte); compressed != 0 selects the compressed form.  validate != 0 performs
+ * the on-curve test of Validate::Yes for uncompressed points (compressed points are on the curve by construction; the
+ * prime-subgroup test -- a scalar multiplication per point -- is left to the party that trusts the key). */
+/* bytes of one encoded point of `group` (1 | 2) */
+uint64_t ark355_point_size(int32_t curve, int32_t group, int32_t compressed);
+/* the byte stream of an ark_groth16::ProvingKey<E> (vk, beta_g1, delta_g1, a_query, b_g1_query, b_g2_query, h_query,
+ * l_query) -> resident key, exactly as ark355_pk_load would build it from the decoded vectors.  The points are decoded
+ * on the device (one lane per point; the compressed form costs a square root each).  ARK355_EINVAL for truncated /
+ * inconsistent streams and bad points (ark355_last_error names the vector and index). */
+int32_t ark355_pk_load_bytes(ark355_ctx* ctx, int32_t curve, const uint8_t* bytes, uint64_t len, int32_t compressed,
+                             int32_t validate, ark355_pk** out);
+/* dimensions of a resident key: num_instance (ell), num_witness (w), domain size N */
+int32_t ark355_pk_dims(const ark355_pk* pk, uint64_t* num_instance, uint64_t* num_witness, uint64_t* domain_size);
+/* n encoded points <-> n raw affine images (x || y Montgomery; the layout of every other entry point), on the device */
+int32_t ark355_points_decode(ark355_ctx* ctx, int32_t curve, int32_t group, const uint8_t* in, uint64_t n,
+                             int32_t compressed, int32_t validate, uint8_t* out_raw);
+int32_t ark355_points_encode(ark355_ctx* ctx, int32_t curve, int32_t group, const uint8_t* in_raw, uint64_t n,
+                             int32_t compressed, uint8_t* out);
+/* Proof = a || b || c; out must hold 2 * point_size(G1) + point_size(G2) bytes */
+int32_t ark355_proof_to_bytes(int32_t curve, const ark355_proof_raw* proof, int32_t compressed, uint8_t* out);
+int32_t ark355_proof_from_bytes(int32_t curve, const uint8_t* in, uint64_t len, int32_t compressed, int32_t validate,
+                                ark355_proof_raw* out);
+
 /* ---- building blocks ---------------------------------------------------------------------- */
 /* R1CS -> QAP witness map h[0..N) (Montgomery), SURVEY Appendix A steps 1-5 */
 int32_t ark355_witness_map(ark355_ctx* ctx, const ark355_r1cs* r1cs, const uint8_t* z, uint64_t z_len,

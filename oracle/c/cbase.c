@@ -109,9 +109,29 @@ static void fr_pow2k(f4_t* r, const f4_t* a, int k, const f4_params* P) {
   for (int i = 0; i < k; i++) f4_sqr(r, r, P);
 }
 
+/* p[i] = base^i * first, i < n, filled by chunks (each chunk starts from one exponentiation) */
+static void fr_powers(f4_t* p, size_t n, const f4_t* base, const f4_t* first, const f4_params* P) {
+  const int nt = omp_get_max_threads();
+  const size_t chunk = (n + (size_t)nt - 1) / (size_t)nt;
+#pragma omp parallel for schedule(static, 1)
+  for (int t = 0; t < nt; t++) {
+    const size_t k0 = (size_t)t * chunk, k1 = (k0 + chunk < n) ? k0 + chunk : n;
+    if (k0 >= k1) continue;
+    uint64_t e[1] = {(uint64_t)k0};
+    f4_t x;
+    f4_pow(&x, base, e, 1, P);
+    if (first) f4_mul(&x, &x, first, P);
+    for (size_t k = k0; k < k1; k++) {
+      p[k] = x;
+      f4_mul(&x, &x, base, P);
+    }
+  }
+}
+
 static void ntt_core(f4_t* a, int log_n, const f4_t* w, const f4_params* P) {
   const size_t n = (size_t)1 << log_n;
   /* bit reversal */
+#pragma omp parallel for schedule(static) if (n >= 4096)
   for (size_t i = 0; i < n; i++) {
     size_t j = 0;
     for (int b = 0; b < log_n; b++) j |= ((i >> b) & 1) << (log_n - 1 - b);
@@ -124,18 +144,19 @@ static void ntt_core(f4_t* a, int log_n, const f4_t* w, const f4_params* P) {
   f4_t* tw = (f4_t*)malloc(sizeof(f4_t) * (n / 2 ? n / 2 : 1));
   /* tw[k] = w^k, k < n/2 */
   f4_set_one(&tw[0], P);
-  for (size_t k = 1; k < n / 2; k++) f4_mul(&tw[k], &tw[k - 1], w, P);
+  if (n / 2 > 1) fr_powers(tw, n / 2, w, NULL, P);
   for (int s = 1; s <= log_n; s++) {
     const size_t len = (size_t)1 << s, half = len >> 1, step = n / len;
+    /* one flat index over (block, k): late stages have few blocks but long ones (arkworks' parallel FFT splits
+     * those as well) */
 #pragma omp parallel for schedule(static) if (n >= 4096)
-    for (size_t blk = 0; blk < n / len; blk++) {
+    for (size_t idx = 0; idx < n / 2; idx++) {
+      const size_t blk = idx / half, k = idx % half;
       f4_t* x = a + blk * len;
-      for (size_t k = 0; k < half; k++) {
-        f4_t u = x[k], v;
-        f4_mul(&v, &x[k + half], &tw[k * step], P);
-        f4_add(&x[k], &u, &v, P);
-        f4_sub(&x[k + half], &u, &v, P);
-      }
+      f4_t u = x[k], v;
+      f4_mul(&v, &x[k + half], &tw[k * step], P);
+      f4_add(&x[k], &u, &v, P);
+      f4_sub(&x[k + half], &u, &v, P);
     }
   }
   free(tw);
@@ -152,14 +173,12 @@ int cb_ntt(int curve, uint64_t* data, int log_n, int inverse, int coset) {
   fr_pow2k(&w, &c->root, c->two_adicity - log_n, P);
   f4_inv(&wi, &w, P);
   f4_inv(&gi, &c->gen, P);
+  f4_t* sc = (f4_t*)malloc(sizeof(f4_t) * n);
   if (!inverse) {
     if (coset) {
-      f4_t p;
-      f4_set_one(&p, P);
-      for (size_t i = 0; i < n; i++) {
-        f4_mul(&a[i], &a[i], &p, P);
-        f4_mul(&p, &p, &c->gen, P);
-      }
+      fr_powers(sc, n, &c->gen, NULL, P);
+#pragma omp parallel for schedule(static) if (n >= 4096)
+      for (size_t i = 0; i < n; i++) f4_mul(&a[i], &a[i], &sc[i], P);
     }
     ntt_core(a, log_n, &w, P);
   } else {
@@ -171,12 +190,16 @@ int cb_ntt(int curve, uint64_t* data, int log_n, int inverse, int coset) {
     f4_t acc;
     f4_set_one(&acc, P);
     for (int i = 0; i < log_n; i++) f4_mul(&acc, &acc, &ninv, P);
-    f4_t p = acc;
-    for (size_t i = 0; i < n; i++) {
-      f4_mul(&a[i], &a[i], &p, P);
-      if (coset) f4_mul(&p, &p, &gi, P);
+    if (coset) {
+      fr_powers(sc, n, &gi, &acc, P);
+#pragma omp parallel for schedule(static) if (n >= 4096)
+      for (size_t i = 0; i < n; i++) f4_mul(&a[i], &a[i], &sc[i], P);
+    } else {
+#pragma omp parallel for schedule(static) if (n >= 4096)
+      for (size_t i = 0; i < n; i++) f4_mul(&a[i], &a[i], &acc, P);
     }
   }
+  free(sc);
   return 0;
 }
 

@@ -217,6 +217,17 @@ def setup_raw_c(curve: CurveParams, n, ell, w, mats, td):
     return pk, dict(u=outs["u"][:m * 32].tobytes(), v=outs["v"][:m * 32].tobytes(), w=outs["w"][:m * 32].tobytes(), N=N)
 
 
+def _cpu_quota_note():
+    """The container's CPU bandwidth limit, if any (cgroup v2 cpu.max): fewer effective cores than threads."""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            return "; cgroup cpu.max = %.1f cores" % (float(q) / float(per))
+    except Exception:
+        pass
+    return ""
+
+
 def bench_prove(curve_name="bls12_381", log_n=None, budget_s=20.0):
     """cpu_baseline for bench.py: the C restatement on all host cores, on the benchmark's own configuration (S2
     mulchain, n = 2^20, N = 2^21) whenever the host has the cores to finish a proof in seconds (>= 32 threads);
@@ -254,11 +265,11 @@ def bench_prove(curve_name="bls12_381", log_n=None, budget_s=20.0):
     while len(times) < 5 and (len(times) < 2 or (time.perf_counter() - t_start) < budget_s):
         tm = {}
         prove(cv, n, ell, w, mats, zb, pk, int(rng.integers(1, 1 << 62)), int(rng.integers(1, 1 << 62)), timings=tm)
-        times.append(tm["total_s"])
+        times.append((tm["total_s"], tm["witness_map_s"], tm["msm_s"]))
     times.sort()
-    med = times[len(times) // 2]
+    med, med_w, med_m = times[len(times) // 2]
     return {"value": n / med, "unit": "constraints/s", "cores": cores, "kind": "port",
             "sample": "oracle/c (arkworks-algorithm C restatement; Pippenger tasks = window x term-chunk, OpenMP x%d): "
                       "median of %d Groth16/%s proofs of the S2 mulchain R1CS with n = 2^%d constraints (N = 2^%d), "
-                      "%.3f s each, assignment in host memory -> proof"
-                      % (cores, len(times), curve_name, log_n, N.bit_length() - 1, med)}
+                      "%.3f s each (witness map %.3f s, MSMs + tail %.3f s), assignment in host memory -> proof%s"
+                      % (cores, len(times), curve_name, log_n, N.bit_length() - 1, med, med_w, med_m, _cpu_quota_note())}

@@ -43,7 +43,8 @@ SYMBOLS = [
     "ark355_msm_dev_partial", "ark355_xyzz_sum", "ark355_fixed_base_mul", "ark355_get_timings",
     "ark355_get_kernel_stats", "ark355_pk_load_shard", "ark355_partial_size", "ark355_prove_shard",
     "ark355_prove_combine", "ark355_prove_batch", "ark355_comm_unique_id", "ark355_comm_init", "ark355_comm_destroy",
-    "ark355_prove_sharded", "ark355_prove_sharded_dev",
+    "ark355_prove_sharded", "ark355_prove_sharded_dev", "ark355_point_size", "ark355_pk_load_bytes", "ark355_pk_dims",
+    "ark355_points_decode", "ark355_points_encode", "ark355_proof_to_bytes", "ark355_proof_from_bytes",
 ]
 
 
@@ -140,6 +141,14 @@ class Lib:
         d.ark355_comm_destroy.restype = None
         d.ark355_prove_sharded.argtypes = [vp, vp, vp, vp, vp, u64, vp, vp, i32, P(ProofRaw)]
         d.ark355_prove_sharded_dev.argtypes = [vp, vp, vp, vp, vp, u64, vp, vp, i32, P(ProofRaw)]
+        d.ark355_point_size.argtypes = [i32, i32, i32]
+        d.ark355_point_size.restype = u64
+        d.ark355_pk_load_bytes.argtypes = [vp, i32, vp, u64, i32, i32, P(vp)]
+        d.ark355_pk_dims.argtypes = [vp, P(u64), P(u64), P(u64)]
+        d.ark355_points_decode.argtypes = [vp, i32, i32, vp, u64, i32, i32, vp]
+        d.ark355_points_encode.argtypes = [vp, i32, i32, vp, u64, i32, vp]
+        d.ark355_proof_to_bytes.argtypes = [i32, P(ProofRaw), i32, vp]
+        d.ark355_proof_from_bytes.argtypes = [i32, vp, u64, i32, i32, P(ProofRaw)]
         d.ark355_get_timings.argtypes = [vp, P(Timings)]
         d.ark355_get_kernel_stats.argtypes = [vp, P(C.c_float), P(u64), P(u64)]
         for name in SYMBOLS:
@@ -248,6 +257,55 @@ class Lib:
         sb, k3 = _buf(s)
         self.check(ctx, self.dll.ark355_prove_combine(ctx, curve, pb, count, rb, sb, C.byref(out)))
         return bytes(out.a)[:sizes["g1"]], bytes(out.b)[:sizes["g2"]], bytes(out.c)[:sizes["g1"]]
+
+    # ---- ark-serialize wire formats behind the ABI ------------------------------------------------------------
+    def point_size(self, curve, group, compressed):
+        return int(self.dll.ark355_point_size(curve, group, int(bool(compressed))))
+
+    def pk_load_bytes(self, ctx, curve, data: bytes, compressed=False, validate=True):
+        h = C.c_void_p()
+        db, k = _buf(data)
+        self.check(ctx, self.dll.ark355_pk_load_bytes(ctx, curve, db, len(data), int(bool(compressed)), int(bool(validate)),
+                                                      C.byref(h)))
+        return h
+
+    def pk_dims(self, pk):
+        a, b, c = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+        self.check(None, self.dll.ark355_pk_dims(pk, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
+
+    def points_decode(self, ctx, curve, group, data: bytes, n, compressed, validate, raw_size):
+        out = np.zeros(max(1, n * raw_size), dtype=np.uint8)
+        db, k = _buf(data if n else None)
+        self.check(ctx, self.dll.ark355_points_decode(ctx, curve, group, db, n, int(bool(compressed)), int(bool(validate)),
+                                                      out.ctypes.data_as(C.c_void_p)))
+        return out.tobytes()[:n * raw_size]
+
+    def points_encode(self, ctx, curve, group, raw: bytes, n, compressed):
+        sz = self.point_size(curve, group, compressed)
+        out = np.zeros(max(1, n * sz), dtype=np.uint8)
+        rb, k = _buf(raw if n else None)
+        self.check(ctx, self.dll.ark355_points_encode(ctx, curve, group, rb, n, int(bool(compressed)),
+                                                      out.ctypes.data_as(C.c_void_p)))
+        return out.tobytes()[:n * sz]
+
+    def proof_to_bytes(self, curve, a: bytes, b: bytes, c: bytes, compressed=True) -> bytes:
+        p = ProofRaw()
+        C.memmove(p.a, a, len(a))
+        C.memmove(p.b, b, len(b))
+        C.memmove(p.c, c, len(c))
+        n = 2 * self.point_size(curve, 1, compressed) + self.point_size(curve, 2, compressed)
+        out = np.zeros(n, dtype=np.uint8)
+        self.check(None, self.dll.ark355_proof_to_bytes(curve, C.byref(p), int(bool(compressed)), out.ctypes.data_as(C.c_void_p)))
+        return out.tobytes()
+
+    def proof_from_bytes(self, curve, data: bytes, sizes, compressed=True, validate=True):
+        p = ProofRaw()
+        db, k = _buf(data)
+        rc = self.dll.ark355_proof_from_bytes(curve, db, len(data), int(bool(compressed)), int(bool(validate)), C.byref(p))
+        if rc != OK:
+            raise Ark355Error(rc, "ark355_proof_from_bytes")
+        return bytes(p.a)[:sizes["g1"]], bytes(p.b)[:sizes["g2"]], bytes(p.c)[:sizes["g1"]]
 
     # ---- RCCL behind the ABI ----------------------------------------------------------------------------------
     def comm_unique_id(self) -> bytes:

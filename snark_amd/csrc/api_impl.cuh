@@ -2,6 +2,7 @@
 #pragma once
 #include "common.h"
 #include "groth16_impl.cuh"
+#include "wire_impl.cuh"
 
 namespace ark355 {
 
@@ -234,6 +235,172 @@ struct Api {
                          uint64_t n, uint8_t* out) {
     if (group == 1) fixed_base_t<Fq>(ctx, g, base, scalars, n, out);
     else fixed_base_t<Fq2>(ctx, g, base, scalars, n, out);
+  }
+
+  // ---- ark-serialize wire formats (wire_impl.cuh) ------------------------------------------------------------------
+  using W = Wire<Curve>;
+  static size_t point_size(int group, bool compressed) { return group == 1 ? W::g1_size(compressed) : W::g2_size(compressed); }
+  static size_t raw_size(int group) { return group == 1 ? sizeof(Affine<Fq>) : sizeof(Affine<Fq2>); }
+
+  // d_in: device byte stream of n encoded points -> d_out: n raw affine images (device).  Throws on a bad point.
+  static void decode_dev(int group, const uint8_t* d_in, uint64_t n, bool compressed, bool validate, void* d_out,
+                         DevBuf& errbuf, hipStream_t st, const char* what) {
+    if (n == 0) return;
+    errbuf.ensure(8);
+    ARK_CHECK_HIP(hipMemsetAsync(errbuf.p, 0, 8, st));
+    const dim3 grid((uint32_t)((n + 127) / 128));
+    if (group == 1)
+      ARK_LAUNCH((wire_decode_kernel<Curve, 1>), grid, dim3(128), 0, st, d_in, n, compressed ? 1 : 0, validate ? 1 : 0, d_out,
+                 errbuf.as<unsigned long long>());
+    else
+      ARK_LAUNCH((wire_decode_kernel<Curve, 2>), grid, dim3(128), 0, st, d_in, n, compressed ? 1 : 0, validate ? 1 : 0, d_out,
+                 errbuf.as<unsigned long long>());
+    ARK_CHECK_LAUNCH();
+    unsigned long long e = 0;
+    ARK_CHECK_HIP(hipMemcpyAsync(&e, errbuf.p, 8, hipMemcpyDeviceToHost, st));
+    ARK_CHECK_HIP(hipStreamSynchronize(st));
+    if (e != 0)
+      throw HipError{ARK355_EINVAL, std::string(what) + "[" + std::to_string((e >> 4) - 1) + "]: " + wire_status_name((int)(e & 15))};
+  }
+
+  static void points_decode(ark355_ctx* ctx, GenericScratch& g, int group, const uint8_t* in, uint64_t n, bool compressed,
+                            bool validate, uint8_t* out_raw) {
+    hipStream_t st = ctx->stream;
+    if (n == 0) return;
+    g.a.ensure(n * point_size(group, compressed));
+    g.b.ensure(n * raw_size(group));
+    ARK_CHECK_HIP(hipMemcpyAsync(g.a.p, in, n * point_size(group, compressed), hipMemcpyHostToDevice, st));
+    decode_dev(group, g.a.as<uint8_t>(), n, compressed, validate, g.b.p, g.c, st, "point");
+    ARK_CHECK_HIP(hipMemcpyAsync(out_raw, g.b.p, n * raw_size(group), hipMemcpyDeviceToHost, st));
+    ARK_CHECK_HIP(hipStreamSynchronize(st));
+  }
+
+  static void points_encode(ark355_ctx* ctx, GenericScratch& g, int group, const uint8_t* in_raw, uint64_t n,
+                            bool compressed, uint8_t* out) {
+    hipStream_t st = ctx->stream;
+    if (n == 0) return;
+    g.a.ensure(n * raw_size(group));
+    g.b.ensure(n * point_size(group, compressed));
+    ARK_CHECK_HIP(hipMemcpyAsync(g.a.p, in_raw, n * raw_size(group), hipMemcpyHostToDevice, st));
+    const dim3 grid((uint32_t)((n + 127) / 128));
+    if (group == 1)
+      ARK_LAUNCH((wire_encode_kernel<Curve, 1>), grid, dim3(128), 0, st, (const void*)g.a.p, n, compressed ? 1 : 0, g.b.as<uint8_t>());
+    else
+      ARK_LAUNCH((wire_encode_kernel<Curve, 2>), grid, dim3(128), 0, st, (const void*)g.a.p, n, compressed ? 1 : 0, g.b.as<uint8_t>());
+    ARK_CHECK_LAUNCH();
+    ARK_CHECK_HIP(hipMemcpyAsync(out, g.b.p, n * point_size(group, compressed), hipMemcpyDeviceToHost, st));
+    ARK_CHECK_HIP(hipStreamSynchronize(st));
+  }
+
+  // Proof = a || b || c (three points: host code)
+  static void proof_to_bytes(const ark355_proof_raw* p, bool compressed, uint8_t* out) {
+    Affine<Fq> a, c;
+    Affine<Fq2> b;
+    memcpy(&a, p->a, sizeof(a));
+    memcpy(&b, p->b, sizeof(b));
+    memcpy(&c, p->c, sizeof(c));
+    W::g1_encode(a, compressed, out);
+    W::g2_encode(b, compressed, out + W::g1_size(compressed));
+    W::g1_encode(c, compressed, out + W::g1_size(compressed) + W::g2_size(compressed));
+  }
+  static void proof_from_bytes(const uint8_t* in, uint64_t len, bool compressed, bool validate, ark355_proof_raw* out) {
+    ARK_REQUIRE(len == 2 * W::g1_size(compressed) + W::g2_size(compressed), ARK355_EINVAL, "bad proof length");
+    Affine<Fq> a, c;
+    Affine<Fq2> b;
+    int st = W::g1_decode(in, compressed, validate, &a);
+    if (st == WIRE_OK) st = W::g2_decode(in + W::g1_size(compressed), compressed, validate, &b);
+    if (st == WIRE_OK) st = W::g1_decode(in + W::g1_size(compressed) + W::g2_size(compressed), compressed, validate, &c);
+    if (st != WIRE_OK) throw HipError{ARK355_EINVAL, std::string("proof: ") + wire_status_name(st)};
+    memset(out, 0, sizeof(*out));
+    memcpy(out->a, &a, sizeof(a));
+    memcpy(out->b, &b, sizeof(b));
+    memcpy(out->c, &c, sizeof(c));
+  }
+
+  // ark_groth16::ProvingKey<E> stream (vk {alpha_g1, beta_g2, gamma_g2, delta_g2, gamma_abc_g1}, beta_g1, delta_g1,
+  // a_query, b_g1_query, b_g2_query, h_query, l_query; Vec = u64 LE length + elements) -> resident key.  The host walks
+  // the structure, the device decodes the points.
+  static PkDev* pk_load_bytes(ark355_ctx* ctx, const uint8_t* bytes, uint64_t len, bool compressed, bool validate) {
+    hipStream_t st = ctx->stream;
+    const size_t s1 = W::g1_size(compressed), s2 = W::g2_size(compressed);
+    uint64_t off = 0;
+    auto need = [&](uint64_t k) { ARK_REQUIRE(k <= len && off <= len - k, ARK355_EINVAL, "truncated proving key"); };
+    struct Span {
+      uint64_t off = 0, n = 0;
+      int group = 1;
+    };
+    auto single = [&](int group) {
+      Span sp;
+      sp.group = group;
+      sp.off = off;
+      sp.n = 1;
+      need(group == 1 ? s1 : s2);
+      off += group == 1 ? s1 : s2;
+      return sp;
+    };
+    auto vec = [&](int group) {
+      need(8);
+      uint64_t n = 0;
+      memcpy(&n, bytes + off, 8);
+      off += 8;
+      const uint64_t sz = group == 1 ? s1 : s2;
+      ARK_REQUIRE(n <= (len - off) / sz, ARK355_EINVAL, "vector length exceeds the stream");
+      Span sp;
+      sp.group = group;
+      sp.off = off;
+      sp.n = n;
+      off += n * sz;
+      return sp;
+    };
+    const Span alpha = single(1), beta2 = single(2), gamma2 = single(2), delta2 = single(2), gabc = vec(1);
+    const Span beta1 = single(1), delta1 = single(1), aq = vec(1), b1q = vec(1), b2q = vec(2), hq = vec(1), lq = vec(1);
+    (void)gamma2;
+    ARK_REQUIRE(off == len, ARK355_EINVAL, "trailing bytes in proving key");
+    const uint64_t ell = gabc.n, m = aq.n, w = lq.n, N = hq.n + 1;
+    ARK_REQUIRE(ell >= 1 && m == ell + w && b1q.n == m && b2q.n == m && (N & (N - 1)) == 0, ARK355_EINVAL,
+                "proving key: inconsistent query lengths");
+    DevBuf d_bytes(len), d_err;
+    ARK_CHECK_HIP(hipMemcpyAsync(d_bytes.p, bytes, len, hipMemcpyHostToDevice, st));
+    auto decode_vec = [&](const Span& sp, DevBuf& out, const char* what) {
+      out.alloc((sp.n ? sp.n : 1) * raw_size(sp.group));
+      decode_dev(sp.group, d_bytes.as<uint8_t>() + sp.off, sp.n, compressed, validate, out.p, d_err, st, what);
+    };
+    DevBuf d_a, d_b1, d_b2, d_h, d_l;
+    decode_vec(aq, d_a, "a_query");
+    decode_vec(b1q, d_b1, "b_g1_query");
+    decode_vec(b2q, d_b2, "b_g2_query");
+    decode_vec(hq, d_h, "h_query");
+    decode_vec(lq, d_l, "l_query");
+    Affine<Fq> h_alpha, h_beta1, h_delta1;
+    Affine<Fq2> h_beta2, h_delta2;
+    auto dec1 = [&](const Span& sp, Affine<Fq>* o, const char* what) {
+      const int e = W::g1_decode(bytes + sp.off, compressed, validate, o);
+      if (e != WIRE_OK) throw HipError{ARK355_EINVAL, std::string(what) + ": " + wire_status_name(e)};
+    };
+    auto dec2 = [&](const Span& sp, Affine<Fq2>* o, const char* what) {
+      const int e = W::g2_decode(bytes + sp.off, compressed, validate, o);
+      if (e != WIRE_OK) throw HipError{ARK355_EINVAL, std::string(what) + ": " + wire_status_name(e)};
+    };
+    dec1(alpha, &h_alpha, "alpha_g1");
+    dec1(beta1, &h_beta1, "beta_g1");
+    dec1(delta1, &h_delta1, "delta_g1");
+    dec2(beta2, &h_beta2, "beta_g2");
+    dec2(delta2, &h_delta2, "delta_g2");
+    ark355_pk_desc d{};
+    d.num_instance = ell;
+    d.num_witness = w;
+    d.domain_size = N;
+    d.a_query = d_a.as<uint8_t>();            // device pointers: pk_upload copies with hipMemcpyDefault
+    d.b_g1_query = d_b1.as<uint8_t>();
+    d.b_g2_query = d_b2.as<uint8_t>();
+    d.h_query = d_h.as<uint8_t>();
+    d.l_query = d_l.as<uint8_t>();
+    d.alpha_g1 = reinterpret_cast<const uint8_t*>(&h_alpha);
+    d.beta_g1 = reinterpret_cast<const uint8_t*>(&h_beta1);
+    d.delta_g1 = reinterpret_cast<const uint8_t*>(&h_delta1);
+    d.beta_g2 = reinterpret_cast<const uint8_t*>(&h_beta2);
+    d.delta_g2 = reinterpret_cast<const uint8_t*>(&h_delta2);
+    return pk_upload<Curve>(&d, st);
   }
 };
 

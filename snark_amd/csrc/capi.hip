@@ -479,6 +479,65 @@ int32_t ark355_fixed_base_mul(ark355_ctx* ctx, int32_t curve, int32_t group, con
   });
 }
 
+uint64_t ark355_point_size(int32_t curve, int32_t group, int32_t compressed) {
+  if (group != 1 && group != 2) return 0;
+  size_t n = 0;
+  try {
+    CURVE_DISPATCH(curve, n = A::point_size(group, compressed != 0));
+  } catch (...) {
+    return 0;
+  }
+  return n;
+}
+
+int32_t ark355_pk_load_bytes(ark355_ctx* ctx, int32_t curve, const uint8_t* bytes, uint64_t len, int32_t compressed,
+                             int32_t validate, ark355_pk** out) {
+  if (!ctx || !bytes || !out) return ARK355_EINVAL;
+  *out = nullptr;
+  return guarded(ctx, [&] {
+    PkDev* d = nullptr;
+    CURVE_DISPATCH(curve, d = A::pk_load_bytes(ctx, bytes, len, compressed != 0, validate != 0));
+    *out = new ark355_pk{d};
+  });
+}
+
+int32_t ark355_pk_dims(const ark355_pk* pk, uint64_t* num_instance, uint64_t* num_witness, uint64_t* domain_size) {
+  if (!pk || !pk->d) return ARK355_EINVAL;
+  if (num_instance) *num_instance = pk->d->ell;
+  if (num_witness) *num_witness = pk->d->w;
+  if (domain_size) *domain_size = pk->d->N;
+  return ARK355_OK;
+}
+
+int32_t ark355_points_decode(ark355_ctx* ctx, int32_t curve, int32_t group, const uint8_t* in, uint64_t n,
+                             int32_t compressed, int32_t validate, uint8_t* out_raw) {
+  if (!ctx || (group != 1 && group != 2) || (n && (!in || !out_raw))) return ARK355_EINVAL;
+  return guarded(ctx, [&] {
+    CtxExtra& ex = extra(ctx);
+    CURVE_DISPATCH(curve, A::points_decode(ctx, ex.generic, group, in, n, compressed != 0, validate != 0, out_raw));
+  });
+}
+
+int32_t ark355_points_encode(ark355_ctx* ctx, int32_t curve, int32_t group, const uint8_t* in_raw, uint64_t n,
+                             int32_t compressed, uint8_t* out) {
+  if (!ctx || (group != 1 && group != 2) || (n && (!in_raw || !out))) return ARK355_EINVAL;
+  return guarded(ctx, [&] {
+    CtxExtra& ex = extra(ctx);
+    CURVE_DISPATCH(curve, A::points_encode(ctx, ex.generic, group, in_raw, n, compressed != 0, out));
+  });
+}
+
+int32_t ark355_proof_to_bytes(int32_t curve, const ark355_proof_raw* proof, int32_t compressed, uint8_t* out) {
+  if (!proof || !out) return ARK355_EINVAL;
+  return guarded(nullptr, [&] { CURVE_DISPATCH(curve, A::proof_to_bytes(proof, compressed != 0, out)); });
+}
+
+int32_t ark355_proof_from_bytes(int32_t curve, const uint8_t* in, uint64_t len, int32_t compressed, int32_t validate,
+                                ark355_proof_raw* out) {
+  if (!in || !out) return ARK355_EINVAL;
+  return guarded(nullptr, [&] { CURVE_DISPATCH(curve, A::proof_from_bytes(in, len, compressed != 0, validate != 0, out)); });
+}
+
 int32_t ark355_get_timings(const ark355_ctx* ctx, ark355_timings* out) {
   if (!ctx || !out) return ARK355_EINVAL;
   *out = ctx->timings;

@@ -195,7 +195,7 @@ static PkDev* pk_upload(const ark355_pk_desc* d, hipStream_t stream, uint32_t sh
     auto ext = [&](const uint8_t* query, size_t psz, const uint8_t* t1, const uint8_t* t2, const uint8_t* t3) {
       // [query (m), O, t1, t2, t3]; null tail pointers mean infinity
       stage.ensure((m + 4) * psz);
-      ARK_CHECK_HIP(hipMemcpy(stage.p, query, m * psz, hipMemcpyHostToDevice));
+      ARK_CHECK_HIP(hipMemcpy(stage.p, query, m * psz, hipMemcpyDefault));      // host, or device (pk_load_bytes)
       std::vector<uint8_t> tail(4 * psz, 0);
       if (t1) memcpy(tail.data() + 1 * psz, t1, psz);
       if (t2) memcpy(tail.data() + 2 * psz, t2, psz);
@@ -218,13 +218,13 @@ static PkDev* pk_upload(const ark355_pk_desc* d, hipStream_t stream, uint32_t sh
     ext(d->b_g2_query, G2, d->beta_g2, nullptr, d->delta_g2);
     precomp_build<Fq2, Fr>(pk->b2_ext, (uint8_t*)stage.p + pk->z_lo * G2, pk->z_cnt, stream, z_plan);
     stage.ensure((pk->h_cnt ? pk->h_cnt : 1) * G1);
-    if (pk->h_cnt) ARK_CHECK_HIP(hipMemcpy(stage.p, d->h_query + pk->h_lo * G1, pk->h_cnt * G1, hipMemcpyHostToDevice));
+    if (pk->h_cnt) ARK_CHECK_HIP(hipMemcpy(stage.p, d->h_query + pk->h_lo * G1, pk->h_cnt * G1, hipMemcpyDefault));
     precomp_build<Fq, Fr>(pk->h_query, stage.p, pk->h_cnt, stream, h_plan);
     // l_ext aligned with zx: ell leading infinities (instance variables carry no l term), l_query, delta_1 at
     // the -rs slot, three trailing infinities
     stage.ensure((m + 4) * G1);
     ARK_CHECK_HIP(hipMemset(stage.p, 0, (m + 4) * G1));
-    if (pk->w) ARK_CHECK_HIP(hipMemcpy((uint8_t*)stage.p + pk->ell * G1, d->l_query, pk->w * G1, hipMemcpyHostToDevice));
+    if (pk->w) ARK_CHECK_HIP(hipMemcpy((uint8_t*)stage.p + pk->ell * G1, d->l_query, pk->w * G1, hipMemcpyDefault));
     ARK_CHECK_HIP(hipMemcpy((uint8_t*)stage.p + m * G1, d->delta_g1, G1, hipMemcpyHostToDevice));
     precomp_build<Fq, Fr>(pk->l_ext, (uint8_t*)stage.p + pk->z_lo * G1, pk->z_cnt, stream, z_plan);
   } catch (...) {
