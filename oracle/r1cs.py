@@ -459,23 +459,44 @@ def dummy_circuit(cs: ConstraintSystem, a, b, num_variables, num_constraints):
     cs.enforce_r1cs_constraint(lambda: LC(p), lambda: LC(p), lambda: LC(p))
 
 
-def satisfiable_example(cs: ConstraintSystem, x, y):
-    """examples/satisfiable.rs:7-32 flavour: an 8-constraint arithmetic circuit.
-
-    (x + y)^2-style chain; restated shape only (the example's own assertion is is_satisfied)."""
+def example_circuit(cs: ConstraintSystem, satisfiable=True):
+    """The reference's two example programs, exactly: /root/reference/relations/examples/satisfiable.rs:7-32 (inputs
+    3, 4, 6, 7 and the expected result 198; witnesses 2, 5, 8, 9) with its gates (:36-150), and
+    examples/non_satisfiable.rs:10-44, whose enforce_addition assigns left * right to the sum (:150-166) so that the
+    second constraint -- the first addition gate -- is the one `which_is_unsatisfied` reports.
+    8 constraints, 6 instance variables (with One), 11 witnesses."""
     p = cs.p
-    vx = cs.new_witness_variable(lambda: x)
-    vy = cs.new_witness_variable(lambda: y)
-    cur_val = (x + y) % p
-    cur = cs.new_lc(lambda: LC(p) + vx + vy)
-    out = None
-    for i in range(8):
-        nxt_val = cur_val * cur_val % p
-        if i == 7:
-            out = cs.new_input_variable(lambda v=nxt_val: v)
-            nxt = out
-        else:
-            nxt = cs.new_witness_variable(lambda v=nxt_val: v)
-        cs.enforce_r1cs_constraint(lambda c=cur: LC(p) + c, lambda c=cur: LC(p) + c,
-                                   lambda n=nxt: LC(p) + n)
-        cur, cur_val = nxt, nxt_val
+    p1 = cs.new_input_variable(lambda: 3)
+    p2 = cs.new_input_variable(lambda: 4)
+    p3 = cs.new_input_variable(lambda: 6)
+    p4 = cs.new_input_variable(lambda: 7)
+    w1 = cs.new_witness_variable(lambda: 2)
+    w2 = cs.new_witness_variable(lambda: 5)
+    w3 = cs.new_witness_variable(lambda: 8)
+    w4 = cs.new_witness_variable(lambda: 9)
+    expected = cs.new_input_variable(lambda: 198)
+
+    def mul(left, right):
+        prod = cs.new_witness_variable(lambda: cs.assigned_value(left) * cs.assigned_value(right) % p)
+        cs.enforce_r1cs_constraint(lambda: LC(p) + left, lambda: LC(p) + right, lambda: LC(p) + prod)
+        return prod
+
+    def add(left, right):
+        if satisfiable:
+            s = cs.new_witness_variable(lambda: (cs.assigned_value(left) + cs.assigned_value(right)) % p)
+        else:       # "Instead of + we use *, This is intentionally made to fail" (non_satisfiable.rs:150-156)
+            s = cs.new_witness_variable(lambda: cs.assigned_value(left) * cs.assigned_value(right) % p)
+        cs.enforce_r1cs_constraint(lambda: LC(p) + left + right, lambda: LC(p) + VAR_ONE, lambda: LC(p) + s)
+        return s
+
+    # subcircuit 1: (w1 + w2) * (p1 * p2)
+    product = mul(p1, p2)
+    sm = add(w1, w2)
+    r1 = mul(sm, product)
+    # subcircuit 2: p3 * p4 + w3 * w4
+    product1 = mul(p3, p4)
+    product2 = mul(w3, w4)
+    r2 = add(product1, product2)
+    final = add(r1, r2)
+    cs.enforce_r1cs_constraint(lambda: LC(p) + final, lambda: LC(p) + VAR_ONE, lambda: LC(p) + expected)
+    return final

@@ -452,6 +452,13 @@ class ConstraintSystemRef {
     if (!cs.should_construct_matrices()) return;
     cs.enforce_r1cs_constraint(a, b, c);
   }
+  // constraint_system_ref.rs `assigned_value`: None when the cs is None or the variable has no assignment
+  bool assigned_value(Variable v, F* out) const { return p_ ? p_->assigned_value(v, out) : false; }
+  F assigned_value(Variable v) const {                  // the `.unwrap()` form the reference's examples use
+    F x;
+    if (!assigned_value(v, &x)) throw SynthesisError(SynthesisErrorKind::AssignmentMissing);
+    return x;
+  }
   void finalize() const { borrow().finalize(); }
   bool is_satisfied() const { return borrow().is_satisfied(); }
   std::string which_is_unsatisfied() const { return borrow().which_is_unsatisfied(); }

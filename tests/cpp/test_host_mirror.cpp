@@ -62,6 +62,46 @@ struct DummyCircuit : ConstraintSynthesizer<F> {
   }
 };
 
+// relations/examples/satisfiable.rs:7-150 (satisfiable = true) and examples/non_satisfiable.rs:10-166, whose
+// enforce_addition assigns left * right to the sum ("intentionally made to fail").
+template <class F>
+struct ExampleCircuit : ConstraintSynthesizer<F> {
+  bool satisfiable;
+  explicit ExampleCircuit(bool sat = true) : satisfiable(sat) {}
+  void generate_constraints(ConstraintSystemRef<F> cs) override {
+    using L = LinearCombination<F>;
+    Variable p1 = cs.new_input_variable([] { return F::from_u64(3); });
+    Variable p2 = cs.new_input_variable([] { return F::from_u64(4); });
+    Variable p3 = cs.new_input_variable([] { return F::from_u64(6); });
+    Variable p4 = cs.new_input_variable([] { return F::from_u64(7); });
+    Variable w1 = cs.new_witness_variable([] { return F::from_u64(2); });
+    Variable w2 = cs.new_witness_variable([] { return F::from_u64(5); });
+    Variable w3 = cs.new_witness_variable([] { return F::from_u64(8); });
+    Variable w4 = cs.new_witness_variable([] { return F::from_u64(9); });
+    Variable expected = cs.new_input_variable([] { return F::from_u64(198); });
+    auto mul = [&](Variable l, Variable r) {
+      Variable prod = cs.new_witness_variable([&] { return cs.assigned_value(l) * cs.assigned_value(r); });
+      cs.enforce_r1cs_constraint([&] { return L() + l; }, [&] { return L() + r; }, [&] { return L() + prod; });
+      return prod;
+    };
+    auto add = [&](Variable l, Variable r) {
+      Variable sum = cs.new_witness_variable([&] {
+        return satisfiable ? cs.assigned_value(l) + cs.assigned_value(r) : cs.assigned_value(l) * cs.assigned_value(r);
+      });
+      cs.enforce_r1cs_constraint([&] { return L() + l + r; }, [&] { return L() + Variable::One(); }, [&] { return L() + sum; });
+      return sum;
+    };
+    Variable product = mul(p1, p2);
+    Variable sum = add(w1, w2);
+    Variable r1 = mul(sum, product);
+    Variable product1 = mul(p3, p4);
+    Variable product2 = mul(w3, w4);
+    Variable r2 = add(product1, product2);
+    Variable fin = add(r1, r2);
+    cs.enforce_r1cs_constraint([&] { return L() + fin; }, [&] { return L() + Variable::One(); }, [&] { return L() + expected; });
+  }
+};
+
 // S2 "mulchain"  with the seed values handed in
 template <class F>
 struct MulChain : ConstraintSynthesizer<F> {
@@ -324,6 +364,18 @@ static void test_modes_and_quirks() {
   CHECK(threw);
 }
 
+// relations/examples/satisfiable.rs:29 (`assert!(cs.is_satisfied().unwrap())`), non_satisfiable.rs:41 (`which_is_unsatisfied`)
+static void test_reference_examples() {
+  auto cs = ConstraintSystemRef<Fr>::new_ref();
+  ExampleCircuit<Fr>(true).generate_constraints(cs);
+  CHECK(cs.num_constraints() == 8 && cs.num_instance_variables() == 6 && cs.num_witness_variables() == 11);
+  CHECK(cs.is_satisfied());
+  auto bad = ConstraintSystemRef<Fr>::new_ref();
+  ExampleCircuit<Fr>(false).generate_constraints(bad);
+  CHECK(!bad.is_satisfied());
+  CHECK(bad.which_is_unsatisfied() == "R1CS - 1");
+}
+
 static void hex(const char* name, const std::vector<uint8_t>& b) {
   printf("%s=", name);
   for (uint8_t x : b) printf("%02x", x);
@@ -343,6 +395,7 @@ static int run_prove(const std::string& circuit, size_t n) {
   std::unique_ptr<ConstraintSynthesizer<F>> circ;
   if (circuit == "dummy") circ.reset(new DummyCircuit<F>(F::from_u64(3), F::from_u64(5), n, n));
   else if (circuit == "benchlc") circ.reset(new BenchLc<F>(n));
+  else if (circuit == "example") circ.reset(new ExampleCircuit<F>(true));
   else circ.reset(new MulChain<F>(F::from_u64(0x355), F::from_u64(0x356), n));
   auto keys = groth.circuit_specific_setup(*circ, rng);
   auto proof = groth.prove(keys.first, *circ, rng);
@@ -398,6 +451,7 @@ int main(int argc, char** argv) {
   test_variable_ordering();
   test_dummy_circuit_synthesizes();
   test_modes_and_quirks();
+  test_reference_examples();
   printf("host mirror: all CPU checks passed\n");
   return 0;
 }

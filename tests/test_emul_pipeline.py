@@ -146,3 +146,20 @@ def test_host_mirror_setup_prove_over_emulator(emul_lib):
 def test_prove_batch(emul_lib, emul_ctx):
     """ark355_prove_batch over the emulator (runs its proofs one after another there)."""
     pc.prove_batch_case(emul_lib, emul_ctx, BN254, count=3, n=6)
+
+
+def test_reference_example_circuit_on_the_emulator(emul_lib, emul_ctx):
+    """relations/examples/satisfiable.rs / non_satisfiable.rs through the C ABI (GPU twin: test_gpu_parity.py)."""
+    from helpers import r1cs_load_from_rows, z_bytes
+    from oracle import r1cs as R
+    C = BLS12_381
+    cs = R.ConstraintSystem(C.r)
+    R.example_circuit(cs, satisfiable=True)
+    A, B, Cm, z, ell = S.cs_to_instance(cs)
+    pc.prove_case(emul_lib, emul_ctx, C, A, B, Cm, z, ell, verify=True)
+    bad = R.ConstraintSystem(C.r)
+    R.example_circuit(bad, satisfiable=False)
+    A2, B2, C2, z2, _ = S.cs_to_instance(bad)
+    rh = r1cs_load_from_rows(emul_lib, emul_ctx, C, A2, B2, C2, ell, len(z2) - ell)
+    assert emul_lib.is_satisfied(emul_ctx, rh, z_bytes(C, z2), len(z2)) == 1
+    emul_lib.dll.ark355_r1cs_free(rh)

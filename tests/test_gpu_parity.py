@@ -8,6 +8,7 @@ import random
 import pytest
 
 import parity_cases as pc
+from helpers import r1cs_load_from_rows, z_bytes
 from oracle import groth16 as G, serialize as Z, synthetic as S
 from oracle.fields import BLS12_381, BN254
 
@@ -111,6 +112,27 @@ def test_prove_dummy_circuit_config1(gpu_lib, gpu_ctx):
     C = BLS12_381
     A, B, Cm, z, ell = S.cs_to_instance(S.dummy_cs(C.r, 1 << 10))
     pc.prove_case(gpu_lib, gpu_ctx, C, A, B, Cm, z, ell, verify=True)
+
+
+@pytest.mark.parametrize("C", CURVES, ids=lambda c: c.name)
+def test_prove_reference_example_circuit_config0(gpu_lib, gpu_ctx, C):
+    """BASELINE.json configs[0]: the reference's own example program (relations/examples/satisfiable.rs:7-150, inputs
+    3, 4, 6, 7 -> 198) proven on the GPU, byte-equal to the oracle and accepted by its pairing check; the
+    non_satisfiable.rs witness is reported at constraint 1 by the device check and still proves nothing valid."""
+    from oracle import r1cs as R
+    cs = R.ConstraintSystem(C.r)
+    R.example_circuit(cs, satisfiable=True)
+    A, B, Cm, z, ell = S.cs_to_instance(cs)
+    pc.prove_case(gpu_lib, gpu_ctx, C, A, B, Cm, z, ell, verify=True)
+    bad = R.ConstraintSystem(C.r)
+    R.example_circuit(bad, satisfiable=False)
+    A2, B2, C2, z2, _ = S.cs_to_instance(bad)
+    rh = r1cs_load_from_rows(gpu_lib, gpu_ctx, C, A2, B2, C2, ell, len(z2) - ell)
+    try:
+        assert gpu_lib.is_satisfied(gpu_ctx, rh, z_bytes(C, z2), len(z2)) == 1
+        assert gpu_lib.is_satisfied(gpu_ctx, rh, z_bytes(C, z), len(z)) == -1
+    finally:
+        gpu_lib.dll.ark355_r1cs_free(rh)
 
 
 def _host_mirror_case(curve_name, n, seed):

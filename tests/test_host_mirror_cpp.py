@@ -17,9 +17,17 @@ def exe():
     build.build(verbose=False)
     src = os.path.join(CPP_DIR, "test_host_mirror.cpp")
     deps = [src] + [os.path.join(ROOT, "snark_amd", "host", f) for f in ("relations.hpp", "snark.hpp")]
-    if not os.path.exists(EXE) or os.path.getmtime(EXE) < max(os.path.getmtime(d) for d in deps):
+    # rebuild whenever the sources differ from what the binary was built from (content hash, not mtime: a stale binary
+    # from another checkout must never run in place of the current sources)
+    import hashlib
+    h = hashlib.sha256()
+    for d in deps + [os.path.join(ROOT, "include", "ark355.h")]:
+        h.update(open(d, "rb").read())
+    stamp = EXE + ".srchash"
+    if not os.path.exists(EXE) or not os.path.exists(stamp) or open(stamp).read() != h.hexdigest():
         subprocess.check_call(["g++", "-O1", "-std=c++17", src, "-o", EXE, "-L" + os.path.join(ROOT, "snark_amd"),
                                "-lark355", "-Wl,-rpath," + os.path.join(ROOT, "snark_amd")])
+        open(stamp, "w").write(h.hexdigest())
     return EXE
 
 
@@ -51,7 +59,8 @@ def _parse(out):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("curve_name,circuit,n", [("bls12_381", "dummy", 64), ("bls12_381", "mulchain", 100),
-                                                  ("bn254", "mulchain", 37), ("bls12_381", "benchlc", 40)])
+                                                  ("bn254", "mulchain", 37), ("bls12_381", "benchlc", 40),
+                                                  ("bls12_381", "example", 8), ("bn254", "example", 8)])
 def test_cpp_snark_trait_prove_matches_oracle(exe, curve_name, circuit, n):
     from oracle import groth16 as G, serialize as Z, synthetic as S
     from oracle.fields import CURVES
@@ -60,7 +69,12 @@ def test_cpp_snark_trait_prove_matches_oracle(exe, curve_name, circuit, n):
     assert r.returncode == 0, r.stderr
     assert "batch_ok 1" in r.stdout          # Groth16::prove_batch (ark355_prove_batch) agreed with single proofs
     got = _parse(r.stdout)
-    if circuit == "dummy":
+    if circuit == "example":            # relations/examples/satisfiable.rs, BASELINE configs[0]
+        from oracle import r1cs as R
+        cs = R.ConstraintSystem(C.r)
+        R.example_circuit(cs, satisfiable=True)
+        A, B, Cm, z, ell = S.cs_to_instance(cs)
+    elif circuit == "dummy":
         A, B, Cm, z, ell = S.cs_to_instance(S.dummy_cs(C.r, n))
     elif circuit == "benchlc":          # S3: random coefficients, repeated columns (same splitmix64 stream in C++)
         A, B, Cm, z, ell = S.cs_to_instance(S.bench_lc_cs(C.r, n))

@@ -100,3 +100,28 @@ def test_bench_lc_satisfiable_and_rows_compact():
     zb = list(z)
     zb[-1] = (zb[-1] + 1) % P
     assert R.first_unsatisfied_r1cs(A, B, C, zb, P) == 39
+
+
+def test_reference_example_programs():
+    """relations/examples/satisfiable.rs (assert!(cs.is_satisfied())) and non_satisfiable.rs (which_is_unsatisfied is
+    Some): the fixtures the reference holds for BASELINE configs[0]."""
+    from oracle import r1cs as R
+    from oracle.fields import BLS12_381 as C
+    cs = R.ConstraintSystem(C.r)
+    final = R.example_circuit(cs, satisfiable=True)
+    assert cs.num_constraints() == 8 and cs.num_instance_variables == 6 and cs.num_witness_variables == 11
+    assert cs.assigned_value(final) == 198
+    assert cs.is_satisfied()
+    cs.finalize()
+    A, B, Cm = cs.to_matrices()[R.R1CS_PREDICATE_LABEL]
+    z = cs.full_assignment()
+    assert z[:6] == [1, 3, 4, 6, 7, 198] and z[6:10] == [2, 5, 8, 9]
+    assert R.first_unsatisfied_r1cs(A, B, Cm, z, C.r) == -1
+    bad = R.ConstraintSystem(C.r)
+    R.example_circuit(bad, satisfiable=False)
+    assert not bad.is_satisfied()
+    assert bad.which_is_unsatisfied() == "R1CS - 1"          # the first addition gate: 2 + 5 != 2 * 5
+    bad.finalize()
+    A2, B2, C2 = bad.to_matrices()[R.R1CS_PREDICATE_LABEL]
+    assert (A2, B2, C2) == (A, B, Cm)                        # same circuit, different witness
+    assert R.first_unsatisfied_r1cs(A2, B2, C2, bad.full_assignment(), C.r) == 1
