@@ -1,0 +1,205 @@
+//! Device residency: one `ark355_ctx` per proving thread and the (proving key, R1CS) handles that live in HBM.
+//!
+//! `ConstraintSystemRef` is `Rc<RefCell<..>>` (relations/src/gr1cs/constraint_system_ref.rs:33), so the reference's
+//! parallel unit is one OS thread per proof; accordingly every thread owns its context (the library serialises the
+//! calls of one context internally).  Key handles are shared between threads: they are immutable after load.
+//! The cache key is a fingerprint of the verifying key's serialized bytes plus the query lengths -- two different
+//! proving keys never share it, and a dropped key's ~15 GB of window tables are released with `evict`.
+use std::{
+    cell::RefCell,
+    collections::HashMap,
+    sync::{Arc, Mutex, OnceLock},
+};
+
+use ark_ec::short_weierstrass::{Affine, SWCurveConfig};
+use ark_ff::{Field, PrimeField};
+use ark_groth16::ProvingKey;
+use ark_relations::gr1cs::Matrix;
+use ark_serialize::CanonicalSerialize;
+
+use crate::{
+    ffi,
+    marshal::{csr_from_matrix, flatten_key, scalars_image, Mi355xCurve},
+    Mi355xError,
+};
+
+/// Owning wrapper of an `ark355_ctx*`.
+pub struct Ctx(pub *mut ffi::ark355_ctx);
+impl Drop for Ctx {
+    fn drop(&mut self) {
+        unsafe { ffi::ark355_ctx_destroy(self.0) }
+    }
+}
+
+thread_local! {
+    static CTX: RefCell<Option<(i32, Ctx)>> = const { RefCell::new(None) };
+}
+
+/// GPU this thread proves on (default: `ARK355_DEVICE` or 0).  Call before the first proof of the thread.
+pub fn set_device(device_id: i32) {
+    CTX.with(|c| {
+        let mut c = c.borrow_mut();
+        if c.as_ref().map(|(d, _)| *d) != Some(device_id) {
+            *c = None;
+        }
+        DEVICE.with(|d| *d.borrow_mut() = Some(device_id));
+    });
+}
+thread_local! {
+    static DEVICE: RefCell<Option<i32>> = const { RefCell::new(None) };
+}
+
+pub fn last_error(ctx: *const ffi::ark355_ctx) -> String {
+    unsafe {
+        let p = ffi::ark355_last_error(ctx);
+        if p.is_null() {
+            String::new()
+        } else {
+            core::ffi::CStr::from_ptr(p).to_string_lossy().into_owned()
+        }
+    }
+}
+
+pub fn check(ctx: *const ffi::ark355_ctx, rc: i32) -> Result<(), Mi355xError> {
+    if rc == ffi::ARK355_OK {
+        Ok(())
+    } else {
+        Err(Mi355xError::from_code(rc, last_error(ctx)))
+    }
+}
+
+/// Run `f` with this thread's context (created on first use).
+pub fn with_ctx<T>(f: impl FnOnce(*mut ffi::ark355_ctx) -> Result<T, Mi355xError>) -> Result<T, Mi355xError> {
+    CTX.with(|c| {
+        let mut c = c.borrow_mut();
+        if c.is_none() {
+            let dev = DEVICE
+                .with(|d| *d.borrow())
+                .or_else(|| std::env::var("ARK355_DEVICE").ok().and_then(|v| v.parse().ok()))
+                .unwrap_or(0);
+            let mut raw = core::ptr::null_mut();
+            let rc = unsafe { ffi::ark355_ctx_create(dev, &mut raw) };
+            if rc != ffi::ARK355_OK {
+                return Err(Mi355xError::from_code(rc, "ark355_ctx_create".into()));
+            }
+            *c = Some((dev, Ctx(raw)));
+        }
+        f(c.as_ref().unwrap().1 .0)
+    })
+}
+
+/// Resident key + matrices of one circuit.
+pub struct Resident {
+    pub pk: *mut ffi::ark355_pk,
+    pub r1cs: *mut ffi::ark355_r1cs,
+    pub num_instance: usize,
+    pub num_witness: usize,
+    pub num_constraints: usize,
+}
+// SAFETY: the handles are immutable after load and the library allows concurrent readers (include/ark355.h).
+unsafe impl Send for Resident {}
+unsafe impl Sync for Resident {}
+impl Drop for Resident {
+    fn drop(&mut self) {
+        unsafe {
+            ffi::ark355_pk_free(self.pk);
+            ffi::ark355_r1cs_free(self.r1cs);
+        }
+    }
+}
+
+type Key = [u8; 32];
+fn registry() -> &'static Mutex<HashMap<Key, Arc<Resident>>> {
+    static R: OnceLock<Mutex<HashMap<Key, Arc<Resident>>>> = OnceLock::new();
+    R.get_or_init(|| Mutex::new(HashMap::new()))
+}
+
+/// Fingerprint of a proving key: FNV-1a-style mixing (4 lanes) over the compressed verifying key, the two prover-only
+/// points and the query lengths.  Collisions would need two keys with identical verifying keys.
+pub fn fingerprint<E: Mi355xCurve>(pk: &ProvingKey<E>) -> Key {
+    let mut bytes = Vec::new();
+    pk.vk.serialize_compressed(&mut bytes).expect("vk serialization");
+    pk.beta_g1.serialize_compressed(&mut bytes).expect("point serialization");
+    pk.delta_g1.serialize_compressed(&mut bytes).expect("point serialization");
+    for n in [pk.a_query.len(), pk.h_query.len(), pk.l_query.len(), E::CURVE_ID as usize] {
+        bytes.extend_from_slice(&(n as u64).to_le_bytes());
+    }
+    let mut lanes = [0xcbf29ce484222325u64, 0x84222325cbf29ce4, 0x9e3779b97f4a7c15, 0xd6e8feb86659fd93];
+    for (i, b) in bytes.iter().enumerate() {
+        let l = &mut lanes[i & 3];
+        *l = (*l ^ (*b as u64)).wrapping_mul(0x100000001b3);
+        *l ^= *l >> 29;
+    }
+    let mut out = [0u8; 32];
+    for (i, l) in lanes.iter().enumerate() {
+        out[8 * i..8 * i + 8].copy_from_slice(&l.to_le_bytes());
+    }
+    out
+}
+
+pub fn lookup<E: Mi355xCurve>(pk: &ProvingKey<E>) -> Option<Arc<Resident>> {
+    registry().lock().unwrap().get(&fingerprint(pk)).cloned()
+}
+
+/// Release the HBM of a key (window tables: ~15 GB at n = 2^20) once no proof uses it any more.
+pub fn evict<E: Mi355xCurve>(pk: &ProvingKey<E>) {
+    registry().lock().unwrap().remove(&fingerprint(pk));
+}
+
+/// First proof of a circuit: upload the key (the library builds its per-window tables in HBM) and the three R1CS
+/// matrices of `ConstraintSystem::to_matrices()["R1CS"]` (relations/src/gr1cs/constraint_system.rs:768-774).
+pub fn load<E, P1, P2>(
+    pk: &ProvingKey<E>,
+    matrices: &[Matrix<E::ScalarField>],
+    num_constraints: usize,
+    num_instance: usize,
+    num_witness: usize,
+) -> Result<Arc<Resident>, Mi355xError>
+where
+    E: Mi355xCurve<G1Affine = Affine<P1>, G2Affine = Affine<P2>>,
+    P1: SWCurveConfig,
+    P2: SWCurveConfig,
+    <P1::BaseField as Field>::BasePrimeField: PrimeField,
+    <P2::BaseField as Field>::BasePrimeField: PrimeField,
+{
+    if matrices.len() != 3 {
+        return Err(Mi355xError::InvalidArgument("the R1CS predicate has three matrices".into()));
+    }
+    let flat = flatten_key::<E, P1, P2>(pk)?;
+    if flat.num_instance as usize != num_instance || flat.num_witness as usize != num_witness {
+        return Err(Mi355xError::InvalidArgument("proving key and constraint system dimensions differ".into()));
+    }
+    let csr: Vec<_> = matrices.iter().map(csr_from_matrix).collect();
+    let res = with_ctx(|ctx| {
+        let desc = flat.desc();
+        let mut pk_h = core::ptr::null_mut();
+        check(ctx, unsafe { ffi::ark355_pk_load(ctx, E::CURVE_ID, &desc, &mut pk_h) })?;
+        let row_ptr = [csr[0].row_ptr.as_ptr(), csr[1].row_ptr.as_ptr(), csr[2].row_ptr.as_ptr()];
+        let col = [csr[0].col.as_ptr(), csr[1].col.as_ptr(), csr[2].col.as_ptr()];
+        let coeff =
+            [scalars_image(&csr[0].coeff).as_ptr(), scalars_image(&csr[1].coeff).as_ptr(), scalars_image(&csr[2].coeff).as_ptr()];
+        let mut r1_h = core::ptr::null_mut();
+        let rc = unsafe {
+            ffi::ark355_r1cs_load(
+                ctx,
+                E::CURVE_ID,
+                num_constraints as u64,
+                num_instance as u64,
+                num_witness as u64,
+                row_ptr.as_ptr(),
+                col.as_ptr(),
+                coeff.as_ptr(),
+                &mut r1_h,
+            )
+        };
+        if rc != ffi::ARK355_OK {
+            let e = Mi355xError::from_code(rc, last_error(ctx));
+            unsafe { ffi::ark355_pk_free(pk_h) };
+            return Err(e);
+        }
+        Ok(Resident { pk: pk_h, r1cs: r1_h, num_instance, num_witness, num_constraints })
+    })?;
+    let res = Arc::new(res);
+    registry().lock().unwrap().insert(fingerprint(pk), res.clone());
+    Ok(res)
+}
