@@ -12,10 +12,16 @@
 // resident and synthesis runs in the witness-only mode of SURVEY.md 3.2
 // (SynthesisMode::Prove{construct_matrices: false, generate_lc_assignments: false}).
 #pragma once
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
 #include <cstring>
+#include <deque>
 #include <functional>
 #include <memory>
+#include <mutex>
 #include <stdexcept>
+#include <thread>
 #include <vector>
 
 #include "../../include/ark355.h"
@@ -96,13 +102,14 @@ struct BackendError : std::runtime_error {
 // RAII device context shared by keys
 class Backend {
  public:
-  explicit Backend(int device = 0) {
+  explicit Backend(int device = 0) : device_(device) {
     int rc = ark355_ctx_create(device, &ctx_);
     if (rc != ARK355_OK) throw BackendError(rc, "ark355_ctx_create failed (no GPU? the backend has no CPU fallback)");
   }
   ~Backend() { ark355_ctx_destroy(ctx_); }
   Backend(const Backend&) = delete;
   ark355_ctx* ctx() const { return ctx_; }
+  int device() const { return device_; }
   void check(int rc) const {
     if (rc == ARK355_OK) return;
     if (rc == ARK355_E_ASSIGNMENT_MISSING) throw ark_relations::SynthesisError(ark_relations::SynthesisErrorKind::AssignmentMissing);
@@ -113,6 +120,7 @@ class Backend {
 
  private:
   ark355_ctx* ctx_ = nullptr;
+  int device_ = 0;
 };
 
 template <class C>
@@ -284,7 +292,7 @@ class Groth16 {
   // constraint system is single-threaded by construction, constraint_system_ref.rs:33), then all assignments are
   // proved with up to `inflight` proofs sharing the GPU.  Randomisers are drawn as r_0, s_0, r_1, s_1, ...
   std::vector<Proof> prove_batch(ProvingKey& pk, const std::vector<Circuit*>& circuits, const Rng& rng,
-                                 uint32_t inflight = 3) const {
+                                 uint32_t inflight = 3, double* device_seconds = nullptr) const {
     namespace g = ark_relations::gr1cs;
     std::vector<std::vector<Fr>> zs;
     std::vector<uint8_t> rc(32 * circuits.size(), 0), sc(32 * circuits.size(), 0);
@@ -308,13 +316,148 @@ class Groth16 {
     }
     std::vector<ark355_proof_raw> raw(circuits.size());
     if (circuits.empty()) return {};
+    const auto t_dev = std::chrono::steady_clock::now();
     be_->check(ark355_prove_batch(be_->ctx(), pk.resident->pk, pk.resident->r1cs, zp.data(), z_len, rc.data(), sc.data(),
                                   circuits.size(), inflight, raw.data()));
+    if (device_seconds) *device_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_dev).count();
     std::vector<Proof> out(circuits.size());
     for (size_t i = 0; i < circuits.size(); i++) {
       out[i].a.assign(raw[i].a, raw[i].a + G1);
       out[i].b.assign(raw[i].b, raw[i].b + G2);
       out[i].c.assign(raw[i].c, raw[i].c + G1);
+    }
+    return out;
+  }
+
+  // End-to-end SNARK::prove for MANY instances of one circuit, synthesis included and overlapped with the GPU:
+  // the reference's parallel unit is one OS thread per proof because ConstraintSystemRef is Rc<RefCell<..>>
+  // (relations/src/gr1cs/constraint_system_ref.rs:33), so `synth_threads` host threads each run
+  // generate_constraints on their OWN constraint system (witness-only mode once the matrices are resident,
+  // constraint_system_ref.rs:241-243) and hand the finished assignment to one of `inflight` prover threads, each with
+  // its own device context over the shared resident key (the same arrangement ark355_prove_batch uses inside the
+  // library).  A bounded queue keeps at most 2 * inflight assignments waiting.  make_circuit(i) builds instance i on
+  // the synthesis thread; randomisers[i] = (r_i, s_i).  Returns the proofs in order; stats (optional) receives the
+  // wall time and the summed synthesis / device times.
+  struct PipelineStats {
+    double wall_s = 0, synth_s = 0, prove_s = 0;
+  };
+  std::vector<Proof> prove_pipelined(ProvingKey& pk, size_t count,
+                                     const std::function<std::unique_ptr<Circuit>(size_t)>& make_circuit,
+                                     const std::vector<std::pair<Fr, Fr>>& randomisers, uint32_t synth_threads,
+                                     uint32_t inflight, PipelineStats* stats = nullptr) const {
+    namespace g = ark_relations::gr1cs;
+    if (count == 0) return {};
+    if (randomisers.size() < count) throw std::logic_error("one (r, s) pair per proof");
+    if (!(pk.resident && pk.resident->r1cs)) {          // first instance: matrices + key upload (sequential)
+      CSRef cs = CSRef::new_ref();
+      cs.set_optimization_goal(g::OptimizationGoal::Constraints);
+      auto c0 = make_circuit(0);
+      c0->generate_constraints(cs);
+      cs.finalize();
+      load(pk, cs);
+    }
+    if (synth_threads < 1) synth_threads = 1;
+    if (inflight < 1) inflight = 1;
+    struct Item {
+      size_t index;
+      std::vector<Fr> z;
+    };
+    std::deque<Item> queue;
+    std::mutex mu;
+    std::condition_variable cv_not_empty, cv_not_full;
+    const size_t cap = 2 * (size_t)inflight;
+    std::atomic<size_t> next{0};
+    std::atomic<uint32_t> producers_left{synth_threads};
+    std::vector<Proof> out(count);
+    std::exception_ptr first_error;
+    std::atomic<bool> failed{false};
+    std::atomic<uint64_t> synth_ns{0}, prove_ns{0};
+    auto fail = [&](std::exception_ptr e) {
+      std::lock_guard<std::mutex> lk(mu);
+      if (!first_error) first_error = e;
+      failed = true;
+      cv_not_empty.notify_all();
+      cv_not_full.notify_all();
+    };
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto producer = [&] {
+      try {
+        for (;;) {
+          const size_t i = next.fetch_add(1);
+          if (i >= count || failed) break;
+          const auto t0 = now();
+          CSRef cs = CSRef::new_ref();
+          cs.set_optimization_goal(g::OptimizationGoal::Constraints);
+          cs.set_mode(g::SynthesisMode::prove(false, false));
+          auto c = make_circuit(i);
+          c->generate_constraints(cs);
+          cs.finalize();
+          Item it{i, cs.borrow().full_assignment()};
+          synth_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(now() - t0).count();
+          std::unique_lock<std::mutex> lk(mu);
+          cv_not_full.wait(lk, [&] { return queue.size() < cap || failed; });
+          if (failed) break;
+          queue.push_back(std::move(it));
+          cv_not_empty.notify_one();
+        }
+      } catch (...) {
+        fail(std::current_exception());
+      }
+      if (--producers_left == 0) {
+        std::lock_guard<std::mutex> lk(mu);
+        cv_not_empty.notify_all();
+      }
+    };
+    auto consumer = [&](ark355_ctx* ctx) {
+      try {
+        for (;;) {
+          Item it;
+          {
+            std::unique_lock<std::mutex> lk(mu);
+            cv_not_empty.wait(lk, [&] { return !queue.empty() || producers_left == 0 || failed; });
+            if (failed || queue.empty()) break;
+            it = std::move(queue.front());
+            queue.pop_front();
+            cv_not_full.notify_one();
+          }
+          uint8_t rc[32] = {0}, sc[32] = {0};
+          randomisers[it.index].first.to_canonical_bytes(rc);
+          randomisers[it.index].second.to_canonical_bytes(sc);
+          ark355_proof_raw raw;
+          const auto t0 = now();
+          const int e = ark355_prove(ctx, pk.resident->pk, pk.resident->r1cs, reinterpret_cast<const uint8_t*>(it.z.data()),
+                                     it.z.size(), rc, sc, &raw);
+          prove_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(now() - t0).count();
+          if (e != ARK355_OK) throw BackendError(e, ark355_last_error(ctx));
+          Proof& p = out[it.index];
+          p.a.assign(raw.a, raw.a + G1);
+          p.b.assign(raw.b, raw.b + G2);
+          p.c.assign(raw.c, raw.c + G1);
+        }
+      } catch (...) {
+        fail(std::current_exception());
+      }
+    };
+    // prover contexts: the backend's own plus inflight - 1 more on the same device
+    std::vector<ark355_ctx*> extra_ctx;
+    for (uint32_t k = 1; k < inflight; k++) {
+      ark355_ctx* c = nullptr;
+      if (ark355_ctx_create(be_->device(), &c) != ARK355_OK) break;
+      extra_ctx.push_back(c);
+    }
+    const auto t_start = now();
+    std::vector<std::thread> th;
+    for (uint32_t k = 0; k < synth_threads; k++) th.emplace_back(producer);
+    for (ark355_ctx* c : extra_ctx) th.emplace_back(consumer, c);
+    consumer(be_->ctx());
+    for (auto& t : th) t.join();
+    const double wall = std::chrono::duration<double>(now() - t_start).count();
+    for (ark355_ctx* c : extra_ctx) ark355_ctx_destroy(c);
+    if (first_error) std::rethrow_exception(first_error);
+    if (stats) {
+      stats->wall_s = wall;
+      stats->synth_s = synth_ns.load() * 1e-9;
+      stats->prove_s = prove_ns.load() * 1e-9;
     }
     return out;
   }

@@ -429,6 +429,60 @@ static int run_prove(const std::string& circuit, size_t n) {
   return 0;
 }
 
+// End-to-end SNARK::prove including synthesis: `count` instances of the S2 mulchain circuit with
+// different seeds, K synthesis threads feeding `inflight` in-flight GPU proofs (Groth16::prove_pipelined), next to the
+// device-only figure (the same assignments already synthesised, ark355_prove_batch).  Prints constraints/s for both
+// and checks every pipelined proof against the batch proof with the same randomisers.
+template <class C>
+static int run_e2e(size_t n, size_t count, uint32_t synth_threads, uint32_t inflight) {
+  using G = ark_snark::Groth16<C>;
+  using F = typename G::Fr;
+  auto be = std::make_shared<ark_snark::Backend>(0);
+  G groth(be);
+  uint64_t seq[] = {0x1234567, 11, 22, 33, 44};
+  size_t pos = 0;
+  typename G::Rng rng = [&]() { return F::from_u64(seq[pos++ % 5]); };
+  auto make = [n](size_t i) -> std::unique_ptr<ConstraintSynthesizer<F>> {
+    return std::unique_ptr<ConstraintSynthesizer<F>>(new MulChain<F>(F::from_u64(0x355 + 2 * i), F::from_u64(0x356 + 2 * i), n));
+  };
+  auto c0 = make(0);
+  auto t0 = std::chrono::steady_clock::now();
+  auto keys = groth.circuit_specific_setup(*c0, rng);
+  auto secs = [](auto a, auto b) { return std::chrono::duration<double>(b - a).count(); };
+  printf("e2e_setup_s=%.3f\n", secs(t0, std::chrono::steady_clock::now()));
+  std::vector<std::pair<F, F>> rs;
+  for (size_t i = 0; i < count; i++) rs.emplace_back(F::from_u64(0x1000 + i), F::from_u64(0x2000 + i));
+  // warm-up: loads key + matrices, touches every prover context
+  typename G::PipelineStats st;
+  groth.prove_pipelined(keys.first, std::min<size_t>(count, 2 * inflight), make, rs, synth_threads, inflight, &st);
+  auto proofs = groth.prove_pipelined(keys.first, count, make, rs, synth_threads, inflight, &st);
+  printf("e2e_wall_s=%.4f\ne2e_constraints_per_s=%.0f\ne2e_synth_cpu_s=%.4f\ne2e_prove_call_s=%.4f\n", st.wall_s,
+         (double)n * count / st.wall_s, st.synth_s, st.prove_s);
+  // device-only: the same circuits, synthesised up front on this thread, then ark355_prove_batch
+  std::vector<std::unique_ptr<ConstraintSynthesizer<F>>> owned;
+  std::vector<ConstraintSynthesizer<F>*> ptrs;
+  for (size_t i = 0; i < count; i++) {
+    owned.push_back(make(i));
+    ptrs.push_back(owned.back().get());
+  }
+  size_t p2 = 0;
+  typename G::Rng rng2 = [&]() {
+    const size_t i = p2++;
+    return (i & 1) ? rs[i / 2].second : rs[i / 2].first;
+  };
+  double dev_s = 0;
+  auto batch = groth.prove_batch(keys.first, ptrs, rng2, inflight, &dev_s);
+  printf("device_only_s=%.4f\ndevice_only_constraints_per_s=%.0f\n", dev_s, (double)n * count / dev_s);
+  for (size_t i = 0; i < count; i++) {
+    if (proofs[i].a != batch[i].a || proofs[i].b != batch[i].b || proofs[i].c != batch[i].c) {
+      fprintf(stderr, "pipelined proof %zu differs from the batch proof\n", i);
+      return 3;
+    }
+  }
+  printf("e2e_ratio=%.3f\ne2e_ok 1\n", dev_s / st.wall_s);
+  return 0;
+}
+
 int main(int argc, char** argv) {
   if (argc >= 5 && std::string(argv[1]) == "--prove") {
     std::string curve = argv[2], circuit = argv[3];
@@ -436,6 +490,18 @@ int main(int argc, char** argv) {
     try {
       if (curve == "bn254") return run_prove<ark_snark::BnCurveTag>(circuit, n);
       return run_prove<ark_snark::BlsCurveTag>(circuit, n);
+    } catch (const std::exception& e) {
+      fprintf(stderr, "error: %s\n", e.what());
+      return 2;
+    }
+  }
+  if (argc >= 7 && std::string(argv[1]) == "--e2e") {
+    // --e2e <curve> <n> <count> <synth_threads> <inflight>
+    const size_t n = strtoull(argv[3], nullptr, 10), count = strtoull(argv[4], nullptr, 10);
+    const uint32_t k = (uint32_t)atoi(argv[5]), inflight = (uint32_t)atoi(argv[6]);
+    try {
+      if (std::string(argv[2]) == "bn254") return run_e2e<ark_snark::BnCurveTag>(n, count, k, inflight);
+      return run_e2e<ark_snark::BlsCurveTag>(n, count, k, inflight);
     } catch (const std::exception& e) {
       fprintf(stderr, "error: %s\n", e.what());
       return 2;

@@ -107,3 +107,14 @@ def test_madd28_chains_match_32bit_formulas():
     out = subprocess.run([exe28], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "all chains agree" in out.stdout
+
+
+@pytest.mark.gpu
+def test_cpp_end_to_end_pipelined_prove_matches_batch(exe):
+    """Groth16::prove_pipelined (synthesis threads feeding in-flight GPU proofs) == ark355_prove_batch proofs with the
+    same randomisers; reports end-to-end constraints/s next to the device-only figure."""
+    r = subprocess.run([exe, "--e2e", "bls12_381", "3000", "6", "3", "2"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    assert "e2e_ok 1" in r.stdout
+    kv = dict(line.split("=", 1) for line in r.stdout.strip().splitlines() if "=" in line)
+    assert float(kv["e2e_constraints_per_s"]) > 0 and float(kv["device_only_constraints_per_s"]) > 0
