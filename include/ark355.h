@@ -60,6 +60,13 @@ uint32_t ark355_version(void);
 /* sizes in bytes for `curve`: what[0]=Fr, [1]=Fq, [2]=G1 affine, [3]=G2 affine */
 int32_t ark355_sizes(int32_t curve, uint32_t what[4]);
 
+/* Page-locked host memory for assignments / key vectors handed to the entry points below: H2D copies from pinned
+ * memory run at PCIe rate (~55 GB/s) and truly asynchronously; pageable memory is staged by the runtime at a fraction
+ * of that (a 32 MiB assignment at n = 2^20: ~0.6 ms pinned vs several ms pageable).  Optional: every entry point accepts
+ * ordinary memory too. */
+int32_t ark355_host_alloc(uint64_t bytes, void** out);
+void ark355_host_free(void* p);
+
 /* ---- proving key (replaces holding ark_groth16::ProvingKey<E> on the host; SNARK::ProvingKey,
  *      snark/src/lib.rs:25) ------------------------------------------------------------------- */
 typedef struct {

@@ -87,6 +87,9 @@ extern "C" {
     pub fn ark355_version() -> u32;
     pub fn ark355_sizes(curve: i32, what: *mut u32) -> i32;
 
+    pub fn ark355_host_alloc(bytes: u64, out: *mut *mut c_void) -> i32;
+    pub fn ark355_host_free(p: *mut c_void);
+
     pub fn ark355_pk_load(ctx: *mut ark355_ctx, curve: i32, desc: *const ark355_pk_desc, out: *mut *mut ark355_pk) -> i32;
     pub fn ark355_pk_free(pk: *mut ark355_pk);
 

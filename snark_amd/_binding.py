@@ -36,6 +36,7 @@ _ERR_NAMES = {
 # every symbol include/ark355.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
     "ark355_ctx_create", "ark355_ctx_destroy", "ark355_last_error", "ark355_version", "ark355_sizes",
+    "ark355_host_alloc", "ark355_host_free",
     "ark355_pk_load", "ark355_pk_free", "ark355_r1cs_load", "ark355_r1cs_free",
     "ark355_r1cs_domain_size", "ark355_prove", "ark355_prove_dev", "ark355_witness_map",
     "ark355_is_satisfied", "ark355_r1cs_mat_vec", "ark355_ntt_fr", "ark355_ntt_fr_dev",
@@ -105,6 +106,9 @@ class Lib:
         d.ark355_last_error.restype = C.c_char_p
         d.ark355_version.restype = u32
         d.ark355_sizes.argtypes = [i32, P(u32 * 4)]
+        d.ark355_host_alloc.argtypes = [u64, P(vp)]
+        d.ark355_host_free.argtypes = [vp]
+        d.ark355_host_free.restype = None
         d.ark355_pk_load.argtypes = [vp, i32, P(PkDesc), P(vp)]
         d.ark355_pk_free.argtypes = [vp]
         d.ark355_pk_free.restype = None

@@ -131,6 +131,28 @@ void ark355_ctx_destroy(ark355_ctx* ctx) {
   delete ctx;
 }
 
+int32_t ark355_host_alloc(uint64_t bytes, void** out) {
+  if (!out) return ARK355_EINVAL;
+  *out = nullptr;
+  void* p = nullptr;
+#if defined(ARK_EMUL)
+  p = malloc(bytes ? bytes : 1);
+  if (!p) return ARK355_ENOMEM;
+#else
+  if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) return ARK355_ENOMEM;
+#endif
+  *out = p;
+  return ARK355_OK;
+}
+void ark355_host_free(void* p) {
+  if (!p) return;
+#if defined(ARK_EMUL)
+  free(p);
+#else
+  (void)hipHostFree(p);
+#endif
+}
+
 const char* ark355_last_error(const ark355_ctx* ctx) { return ctx ? ctx->last_error.c_str() : "null context"; }
 
 int32_t ark355_pk_load(ark355_ctx* ctx, int32_t curve, const ark355_pk_desc* desc, ark355_pk** out) {

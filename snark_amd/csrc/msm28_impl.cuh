@@ -138,16 +138,15 @@ msm_accumulate28_kernel(const Affine28<P>* __restrict__ bases, const uint32_t* _
                         const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ counts,
                         XYZZ<Fp<P>>* __restrict__ buckets, XYZZ<Fp<P>>* __restrict__ head,
                         uint32_t* __restrict__ head_key, XYZZ<Fp<P>>* __restrict__ tail,
-                        uint32_t* __restrict__ tail_key, uint32_t seg_log) {
+                        uint32_t* __restrict__ tail_key, uint32_t seg_len) {
   using F = Fp28<P>;
   using Fq = Fp<P>;
   constexpr int Q = Affine28<P>::Q;
   const uint32_t seg = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t total = *total_ptr;
-  const uint64_t start64 = (uint64_t)seg << seg_log;
+  const uint64_t start64 = (uint64_t)seg * seg_len;
   if (start64 >= total) return;
   const uint32_t start = (uint32_t)start64;
-  const uint32_t seg_len = 1u << seg_log;
   const uint32_t end = (start + seg_len < total) ? start + seg_len : total;
   uint32_t cur_key = sorted_keys[start];
   uint32_t run_start = start;
@@ -405,7 +404,7 @@ msm_accumulate_g2l28_kernel(const Affine28G2<P>* __restrict__ bases, const uint3
                             const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ counts,
                             XYZZ<Fp2<P>>* __restrict__ buckets, XYZZ<Fp2<P>>* __restrict__ head,
                             uint32_t* __restrict__ head_key, XYZZ<Fp2<P>>* __restrict__ tail,
-                            uint32_t* __restrict__ tail_key, uint32_t seg_log) {
+                            uint32_t* __restrict__ tail_key, uint32_t seg_len) {
   using F = Fp28<P>;
   using Fq = Fp<P>;
   using L = Pair28<P>;
@@ -413,10 +412,9 @@ msm_accumulate_g2l28_kernel(const Affine28G2<P>* __restrict__ bases, const uint3
   const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t seg = gid >> 1, par = gid & 1u;       // blockDim is even: par == lane parity
   const uint32_t total = *total_ptr;
-  const uint64_t start64 = (uint64_t)seg << seg_log;
+  const uint64_t start64 = (uint64_t)seg * seg_len;
   if (start64 >= total) return;                        // both lanes of a pair leave together
   const uint32_t start = (uint32_t)start64;
-  const uint32_t seg_len = 1u << seg_log;
   const uint32_t end = (start + seg_len < total) ? start + seg_len : total;
   uint32_t cur_key = sorted_keys[start];
   uint32_t run_start = start;

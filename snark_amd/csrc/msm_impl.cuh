@@ -36,15 +36,9 @@ constexpr uint32_t MSM_INVALID = 0xFFFFFFFFu;
 #else
 #define ARK_TBL_MASK 0x7FFFFFFFu
 #endif
-// entries per accumulate lane = 2^seg_log, chosen per MSM (MsmPlan::seg_log): 32 keeps small MSMs wide enough to
-// fill the chip, 64 halves the partial runs (merge work, tail latency) of the 2^24-entry MSMs of a 2^20 proof
-// (measured on MI355X: 53.7 / 52.6 / 52.3 ms per proof for 32 / 64 / 128)
-#ifndef ARK_MSM_SEG_LOG_SMALL
-#define ARK_MSM_SEG_LOG_SMALL 5
-#endif
-#ifndef ARK_MSM_SEG_LOG_LARGE
-#define ARK_MSM_SEG_LOG_LARGE 6
-#endif
+// entries per accumulate lane: msm_seg_len() below (32 keeps small MSMs wide enough to fill the chip; ~64 halves the
+// partial runs of the 2^24-entry MSMs of a 2^20 proof -- measured on MI355X: 53.7 / 52.6 / 52.3 ms per proof for
+// 32 / 64 / 128)
 constexpr uint32_t MSM_RED_K = 4;         // buckets per reduce lane (latency-bound kernel: short chains, many lanes)
 constexpr uint32_t MSM_THREADS = 256;
 #ifndef ARK_G1_PREFETCH
@@ -63,8 +57,39 @@ struct MsmPlan {
   // window combination disappear from the per-proof path.
   bool precomp = false;
   uint32_t key_windows = 0;     // bucket sets: 1 with precomp, `windows` without
-  uint32_t seg_log = ARK_MSM_SEG_LOG_SMALL;
 };
+
+// Entries per accumulation lane ("segment length").  The accumulation kernels keep CUs x 2 workgroups x 256 lanes
+// resident (2 waves per SIMD), so a launch runs in whole ROUNDS of that many lanes: 2^20 terms x 16 windows / 64 = 1024
+// workgroups = exactly two rounds, but 13 windows (c = 20) / 64 = 832 workgroups still take two rounds -- the second
+// 62 % full -- and the saved additions buy nothing (measured in round 1: -19 % entries, -5 % time).  The length is
+// therefore chosen so that the segments fill a whole number of rounds: nearest round count at ~64 entries per lane,
+// then ceil(entries / (slots x rounds)).  Small MSMs keep 32 so that they stay wide.  pair_lanes: the G2 kernels use two
+// lanes per segment.  ARK355_MSM_SEG=<len> overrides (A/B, tests).
+static inline uint32_t msm_seg_len(uint64_t entries, bool pair_lanes) {
+  if (const char* e = getenv("ARK355_MSM_SEG")) {
+    const int v = atoi(e);
+    if (v >= 1 && v <= 4096) return (uint32_t)v;
+  }
+#if defined(ARK_EMUL)
+  const uint64_t cus = 1;
+#else
+  static const uint64_t cus = [] {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+      n = 256;
+    return (uint64_t)n;
+  }();
+#endif
+  const uint64_t slots = cus * 2 * MSM_THREADS / (pair_lanes ? 2 : 1);
+  if (entries <= slots * 48) return 32;
+  uint64_t rounds = (entries + slots * 32) / (slots * 64);
+  if (rounds < 1) rounds = 1;
+  uint64_t len = (entries + slots * rounds - 1) / (slots * rounds);
+  if (len < 32) len = 32;
+  if (len > 160) len = 160;
+  return (uint32_t)len;
+}
 
 inline MsmPlan msm_plan(uint64_t n, uint32_t scalar_bits, bool precomp = false, int force_c = 0) {
   MsmPlan p;
@@ -99,10 +124,8 @@ inline MsmPlan msm_plan(uint64_t n, uint32_t scalar_bits, bool precomp = false, 
   }
   if (precomp && !force_c) {
     // tuning knob for resident keys (window tables): ARK355_MSM_C=<bits>
-    static const int env_c = [] {
-      const char* e = getenv("ARK355_MSM_C");
-      return e ? atoi(e) : 0;
-    }();
+    const char* e = getenv("ARK355_MSM_C");        // read per plan (key load), not cached: tests flip it
+    const int env_c = e ? atoi(e) : 0;
     if (env_c >= 4 && env_c <= 24 && n >= 1024) c = env_c;
   }
   if (force_c) c = force_c;     // an MSM over window tables must use the window size the tables were built for
@@ -112,7 +135,6 @@ inline MsmPlan msm_plan(uint64_t n, uint32_t scalar_bits, bool precomp = false, 
   p.buckets_per_window = 1u << (p.c - 1);
   p.key_windows = precomp ? 1u : p.windows;
   p.total_buckets = p.key_windows * p.buckets_per_window;
-  p.seg_log = ((uint64_t)p.windows * n >= (1ull << 23)) ? ARK_MSM_SEG_LOG_LARGE : ARK_MSM_SEG_LOG_SMALL;
   return p;
 }
 
@@ -466,11 +488,11 @@ msm_accumulate_kernel(const Affine<F>* __restrict__ bases, const uint32_t* __res
                       const uint32_t* __restrict__ sorted_vals, const uint32_t* __restrict__ total_ptr,
                       const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ counts,
                       XYZZ<F>* __restrict__ buckets, XYZZ<F>* __restrict__ head, uint32_t* __restrict__ head_key,
-                      XYZZ<F>* __restrict__ tail, uint32_t* __restrict__ tail_key, uint32_t seg_log) {
+                      XYZZ<F>* __restrict__ tail, uint32_t* __restrict__ tail_key, uint32_t seg_len) {
   const uint32_t seg = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t total = *total_ptr;
-  const uint32_t MSM_SEG = 1u << seg_log;
-  const uint64_t start64 = (uint64_t)seg << seg_log;
+  const uint32_t MSM_SEG = seg_len;
+  const uint64_t start64 = (uint64_t)seg * seg_len;
   if (start64 >= total) return;
   const uint32_t start = (uint32_t)start64;
   const uint32_t end = (start + MSM_SEG < total) ? start + MSM_SEG : total;
@@ -565,16 +587,15 @@ msm_accumulate_g2l_kernel(const Affine<Fp2<P>>* __restrict__ bases, const uint32
                           const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ counts,
                           XYZZ<Fp2<P>>* __restrict__ buckets, XYZZ<Fp2<P>>* __restrict__ head,
                           uint32_t* __restrict__ head_key, XYZZ<Fp2<P>>* __restrict__ tail,
-                          uint32_t* __restrict__ tail_key, uint32_t seg_log) {
+                          uint32_t* __restrict__ tail_key, uint32_t seg_len) {
   using FL = Fp2L<P>;
   using Fq = Fp<P>;
   const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t seg = gid >> 1, par = gid & 1u;       // blockDim is even: par == lane parity
   const uint32_t total = *total_ptr;
-  const uint64_t start64 = (uint64_t)seg << seg_log;
+  const uint64_t start64 = (uint64_t)seg * seg_len;
   if (start64 >= total) return;                        // both lanes of a pair leave together
   const uint32_t start = (uint32_t)start64;
-  const uint32_t seg_len = 1u << seg_log;
   const uint32_t end = (start + seg_len < total) ? start + seg_len : total;
   uint32_t cur_key = sorted_keys[start];
   uint32_t run_start = start;
@@ -666,13 +687,13 @@ __global__ void __launch_bounds__(MSM_THREADS)
 msm_merge_kernel(uint32_t total_buckets, const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ counts,
                  XYZZ<F>* __restrict__ buckets, const XYZZ<F>* __restrict__ head, const uint32_t* __restrict__ head_key,
                  const XYZZ<F>* __restrict__ tail, const uint32_t* __restrict__ tail_key,
-                 uint32_t* __restrict__ heavy_count, uint32_t* __restrict__ heavy_list, uint32_t seg_log) {
+                 uint32_t* __restrict__ heavy_count, uint32_t* __restrict__ heavy_list, uint32_t seg_len) {
   const uint32_t key = blockIdx.x * blockDim.x + threadIdx.x;
   if (key >= total_buckets) return;
   const uint32_t cnt = counts[key];
   if (cnt == 0) return;
   const uint32_t o = offsets[key];
-  const uint32_t t0 = o >> seg_log, t1 = (o + cnt - 1) >> seg_log;
+  const uint32_t t0 = o / seg_len, t1 = (o + cnt - 1) / seg_len;
   if (t0 == t1) return;   // the single run was complete and already written
   if (t1 - t0 > MSM_HEAVY_SPAN) {
     heavy_list[atomicAdd(heavy_count, 1u)] = key;
@@ -714,14 +735,14 @@ msm_merge_heavy_kernel(const uint32_t* __restrict__ heavy_count, const uint32_t*
                        const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ counts,
                        XYZZ<F>* __restrict__ buckets, const XYZZ<F>* __restrict__ head,
                        const uint32_t* __restrict__ head_key, const XYZZ<F>* __restrict__ tail,
-                       const uint32_t* __restrict__ tail_key, uint32_t seg_log) {
+                       const uint32_t* __restrict__ tail_key, uint32_t seg_len) {
   __shared__ uint32_t wave_out[(MSM_THREADS / 64) * (sizeof(XYZZ<F>) / 4)];
   constexpr int WORDS = sizeof(XYZZ<F>) / 4;
   const uint32_t nheavy = *heavy_count;
   for (uint32_t h = blockIdx.x; h < nheavy; h += gridDim.x) {
     const uint32_t key = heavy_list[h];
     const uint32_t o = offsets[key], cnt = counts[key];
-    const uint32_t t0 = o >> seg_log, t1 = (o + cnt - 1) >> seg_log;
+    const uint32_t t0 = o / seg_len, t1 = (o + cnt - 1) / seg_len;
     XYZZ<F> sum = XYZZ<F>::inf();
     for (uint32_t t = t0 + threadIdx.x; t <= t1; t += blockDim.x) {
       if (head_key[t] == key) sum = xyzz_add(sum, head[t]);
@@ -791,6 +812,77 @@ msm_reduce_kernel(const XYZZ<F>* __restrict__ buckets, uint32_t buckets_per_wind
       sum = xyzz_add(sum, t);
     }
     partials[w * gridDim.x + blockIdx.x] = sum;
+  }
+}
+
+// ---- two-level bucket reduction for large bucket sets (window sizes c >= 18 over window tables) ---------------------
+// sum_b (b+1) B_b with b = K j + i:  sum_j [ W_j + K j T_j ],  T_j = sum_i B_{Kj+i},  W_j = sum_i (i+1) B_{Kj+i}.
+// Level 1 gives every lane K consecutive buckets (two additions per bucket, no scalar multiplication at all); level 2
+// is the weighted sum of the T_j -- the same shape as msm_reduce_kernel, 1/K of its size -- plus the plain sum of the
+// W_j.  The one-level kernel pays a double-and-add by the chunk's first index (~28 group operations per 4 buckets); at
+// 2^19 buckets that alone was 40 % of the accumulation work (round-1 measurement: c = 20 saved 5 % of the accumulation
+// and lost 14 ms in the reduction), which is what kept the window size at 16.
+constexpr uint32_t MSM_RED_L1 = 16;       // buckets per level-1 lane (power of two: K T is log2 K doublings)
+constexpr uint32_t MSM_RED_L1_LOG = 4;
+template <class F>
+__global__ void __launch_bounds__(MSM_THREADS)
+msm_reduce_l1_kernel(const XYZZ<F>* __restrict__ buckets, uint32_t nbuckets, XYZZ<F>* __restrict__ T,
+                     XYZZ<F>* __restrict__ W) {
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t first = (uint64_t)j * MSM_RED_L1;
+  if (first >= nbuckets) return;
+  const uint32_t last = (first + MSM_RED_L1 < nbuckets) ? (uint32_t)first + MSM_RED_L1 : nbuckets;
+  XYZZ<F> running = XYZZ<F>::inf(), acc = XYZZ<F>::inf();
+  for (uint32_t b = last; b-- > (uint32_t)first;) {
+    running = xyzz_add(running, buckets[b]);
+    acc = xyzz_add(acc, running);
+  }
+  T[j] = running;
+  W[j] = acc;
+}
+
+// Output: partials[blockIdx.x] = sum over this workgroup's lanes of  sum_j W_j + K * sum_j j T_j
+template <class F>
+__global__ void __launch_bounds__(MSM_THREADS)
+msm_reduce_l2_kernel(const XYZZ<F>* __restrict__ T, const XYZZ<F>* __restrict__ W, uint32_t items,
+                     XYZZ<F>* __restrict__ partials) {
+  __shared__ uint32_t wave_out[(MSM_THREADS / 64) * (sizeof(XYZZ<F>) / 4)];
+  const uint32_t chunk = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t first = (uint64_t)chunk * MSM_RED_K;
+  XYZZ<F> contrib = XYZZ<F>::inf();
+  if (first < items) {
+    const uint32_t last = (first + MSM_RED_K < items) ? (uint32_t)first + MSM_RED_K : items;
+    XYZZ<F> running = XYZZ<F>::inf(), acc = XYZZ<F>::inf(), wsum = XYZZ<F>::inf();
+    for (uint32_t j = last; j-- > (uint32_t)first;) {
+      acc = xyzz_add(acc, running);             // acc = sum (j - first) T_j
+      running = xyzz_add(running, T[j]);
+      wsum = xyzz_add(wsum, W[j]);
+    }
+    if (first != 0 && !running.is_inf()) {
+      uint32_t k = (uint32_t)first;
+      acc = xyzz_add(acc, xyzz_mul_scalar(running, &k, 1));
+    }
+    if (!acc.is_inf())
+      for (uint32_t d = 0; d < MSM_RED_L1_LOG; d++) acc = xyzz_dbl(acc);
+    contrib = xyzz_add(wsum, acc);
+  }
+  contrib = wave_reduce_sum(contrib);
+  constexpr int WORDS = sizeof(XYZZ<F>) / 4;
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) {
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(&contrib);
+    for (int i = 0; i < WORDS; i++) wave_out[wave * WORDS + i] = src[i];
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    XYZZ<F> sum = XYZZ<F>::inf();
+    for (uint32_t v = 0; v < blockDim.x / 64; v++) {
+      XYZZ<F> t;
+      uint32_t* dst = reinterpret_cast<uint32_t*>(&t);
+      for (int i = 0; i < WORDS; i++) dst[i] = wave_out[v * WORDS + i];
+      sum = xyzz_add(sum, t);
+    }
+    partials[blockIdx.x] = sum;
   }
 }
 
@@ -953,7 +1045,6 @@ static void precomp_build(PrecompTable& t, const void* d_bases, uint64_t n, hipS
 struct MsmSort {
   MsmPlan plan;
   DevBuf keys, vals, counts, offsets, cursor, sorted_keys, sorted_vals, total, hist, hist_scanned;
-  uint32_t max_segments = 0;
 };
 
 template <class Fr>
@@ -976,7 +1067,6 @@ static void msm_sort(ark355_ctx* ctx, MsmSort& s, const void* d_scalars, uint64_
   s.offsets.ensure((size_t)p.total_buckets * 4);
   s.cursor.ensure((size_t)p.total_buckets * 4);
   s.total.ensure(16);
-  s.max_segments = (uint32_t)((entries + (1u << p.seg_log) - 1) >> p.seg_log);
   if (n == 0) {
     ARK_CHECK_HIP(hipMemsetAsync(s.total.p, 0, 4, stream));
     ARK_CHECK_HIP(hipMemsetAsync(s.counts.p, 0, (size_t)p.total_buckets * 4, stream));
@@ -1041,7 +1131,8 @@ static void msm_sort(ark355_ctx* ctx, MsmSort& s, const void* d_scalars, uint64_
 
 // Scratch for the bucket phase of one group type.
 struct MsmBuckets {
-  DevBuf buckets, head, tail, head_key, tail_key, partials, heavy_count, heavy_list;
+  DevBuf buckets, head, tail, head_key, tail_key, partials, heavy_count, heavy_list, lvl_t, lvl_w;
+  uint32_t seg_len = 32, segs = 0;      // of the last accumulation over this bucket set (G1 and G2 differ)
 };
 
 // Phase 1 of the bucket method over an existing sort: bucket accumulation (the chip-filling kernel).
@@ -1051,7 +1142,10 @@ static void msm_accumulate_phase(ark355_ctx* ctx, const MsmSort& s, MsmBuckets& 
                                  bool bases28 = false) {
   const MsmPlan& p = s.plan;
   if (p.n == 0) return;
-  const uint32_t segs = s.max_segments;
+  const uint64_t entries = (uint64_t)p.windows * p.n;
+  b.seg_len = msm_seg_len(entries, is_fp2<F>::value);
+  b.segs = (uint32_t)((entries + b.seg_len - 1) / b.seg_len);
+  const uint32_t segs = b.segs;
   b.buckets.ensure((size_t)p.total_buckets * sizeof(XYZZ<F>));
   b.head.ensure((size_t)segs * sizeof(XYZZ<F>));
   b.tail.ensure((size_t)segs * sizeof(XYZZ<F>));
@@ -1074,7 +1168,7 @@ static void msm_accumulate_phase(ark355_ctx* ctx, const MsmSort& s, MsmBuckets& 
     ARK_LAUNCH((msm_accumulate_kernel<F, NI>), dim3(grid_s), dim3(MSM_THREADS), 0, stream, d_bases,
                s.sorted_keys.as<uint32_t>(), s.sorted_vals.as<uint32_t>(), s.total.as<uint32_t>(),
                s.offsets.as<uint32_t>(), s.counts.as<uint32_t>(), b.buckets.as<XYZZ<F>>(), b.head.as<XYZZ<F>>(),
-               b.head_key.as<uint32_t>(), b.tail.as<XYZZ<F>>(), b.tail_key.as<uint32_t>(), p.seg_log);
+               b.head_key.as<uint32_t>(), b.tail.as<XYZZ<F>>(), b.tail_key.as<uint32_t>(), b.seg_len);
   };
   if constexpr (is_fp2<F>::value) {
     // G2: lane-split kernel (two lanes per segment).  ARK355_G2_WHOLE=1 selects the whole-element kernel
@@ -1090,14 +1184,14 @@ static void msm_accumulate_phase(ark355_ctx* ctx, const MsmSort& s, MsmBuckets& 
                  reinterpret_cast<const Affine28G2<P>*>(d_bases), s.sorted_keys.as<uint32_t>(),
                  s.sorted_vals.as<uint32_t>(), s.total.as<uint32_t>(), s.offsets.as<uint32_t>(),
                  s.counts.as<uint32_t>(), b.buckets.as<XYZZ<F>>(), b.head.as<XYZZ<F>>(), b.head_key.as<uint32_t>(),
-                 b.tail.as<XYZZ<F>>(), b.tail_key.as<uint32_t>(), p.seg_log);
+                 b.tail.as<XYZZ<F>>(), b.tail_key.as<uint32_t>(), b.seg_len);
     } else if (!g2_whole) {
       using P = typename F::Base::Params;
       const uint32_t grid_l = (2 * segs + MSM_THREADS - 1) / MSM_THREADS;
       ARK_LAUNCH((msm_accumulate_g2l_kernel<P>), dim3(grid_l), dim3(MSM_THREADS), 0, stream, d_bases,
                  s.sorted_keys.as<uint32_t>(), s.sorted_vals.as<uint32_t>(), s.total.as<uint32_t>(),
                  s.offsets.as<uint32_t>(), s.counts.as<uint32_t>(), b.buckets.as<XYZZ<F>>(), b.head.as<XYZZ<F>>(),
-                 b.head_key.as<uint32_t>(), b.tail.as<XYZZ<F>>(), b.tail_key.as<uint32_t>(), p.seg_log);
+                 b.head_key.as<uint32_t>(), b.tail.as<XYZZ<F>>(), b.tail_key.as<uint32_t>(), b.seg_len);
     } else if (g2_inline) {
       launch(std::false_type{});
     } else {
@@ -1109,7 +1203,7 @@ static void msm_accumulate_phase(ark355_ctx* ctx, const MsmSort& s, MsmBuckets& 
                reinterpret_cast<const Affine28<P>*>(d_bases), s.sorted_keys.as<uint32_t>(),
                s.sorted_vals.as<uint32_t>(), s.total.as<uint32_t>(), s.offsets.as<uint32_t>(),
                s.counts.as<uint32_t>(), b.buckets.as<XYZZ<F>>(), b.head.as<XYZZ<F>>(), b.head_key.as<uint32_t>(),
-               b.tail.as<XYZZ<F>>(), b.tail_key.as<uint32_t>(), p.seg_log);
+               b.tail.as<XYZZ<F>>(), b.tail_key.as<uint32_t>(), b.seg_len);
   } else {
     launch(std::false_type{});
   }
@@ -1137,7 +1231,7 @@ static void msm_reduce_phase(ark355_ctx* ctx, const MsmSort& s, MsmBuckets& b, X
       return;
     }
   } else {
-    const uint32_t segs = s.max_segments;
+    const uint32_t segs = b.segs;
     const uint32_t grid_b = (p.total_buckets + MSM_THREADS - 1) / MSM_THREADS;
     // at most entries / (MSM_HEAVY_SPAN * segment length) buckets can be heavy
     const uint32_t max_heavy = segs / MSM_HEAVY_SPAN + 1;
@@ -1147,16 +1241,37 @@ static void msm_reduce_phase(ark355_ctx* ctx, const MsmSort& s, MsmBuckets& b, X
     ARK_LAUNCH((msm_merge_kernel<F>), dim3(grid_b), dim3(MSM_THREADS), 0, stream, p.total_buckets,
                s.offsets.as<uint32_t>(), s.counts.as<uint32_t>(), b.buckets.as<XYZZ<F>>(), b.head.as<XYZZ<F>>(),
                b.head_key.as<uint32_t>(), b.tail.as<XYZZ<F>>(), b.tail_key.as<uint32_t>(),
-               b.heavy_count.as<uint32_t>(), b.heavy_list.as<uint32_t>(), p.seg_log);
+               b.heavy_count.as<uint32_t>(), b.heavy_list.as<uint32_t>(), b.seg_len);
     ARK_CHECK_LAUNCH();
     const uint32_t grid_h = max_heavy < ARK_MSM_HEAVY_GRID ? max_heavy : ARK_MSM_HEAVY_GRID;
     ARK_LAUNCH((msm_merge_heavy_kernel<F>), dim3(grid_h), dim3(MSM_THREADS), 0, stream, b.heavy_count.as<uint32_t>(),
                b.heavy_list.as<uint32_t>(), s.offsets.as<uint32_t>(), s.counts.as<uint32_t>(), b.buckets.as<XYZZ<F>>(),
-               b.head.as<XYZZ<F>>(), b.head_key.as<uint32_t>(), b.tail.as<XYZZ<F>>(), b.tail_key.as<uint32_t>(), p.seg_log);
+               b.head.as<XYZZ<F>>(), b.head_key.as<uint32_t>(), b.tail.as<XYZZ<F>>(), b.tail_key.as<uint32_t>(), b.seg_len);
     ARK_CHECK_LAUNCH();
   }
   if constexpr (HOOK) after_merge(b.buckets.as<XYZZ<F>>(), p.total_buckets, stream);
 
+#ifndef ARK_MSM_TWO_LEVEL_MIN
+#define ARK_MSM_TWO_LEVEL_MIN (1u << 17)        // bucket count from which the two-level reduction is used (tests: small)
+#endif
+  if (p.key_windows == 1 && p.total_buckets >= ARK_MSM_TWO_LEVEL_MIN) {
+    const uint32_t items = (p.total_buckets + MSM_RED_L1 - 1) / MSM_RED_L1;
+    b.lvl_t.ensure((size_t)items * sizeof(XYZZ<F>));
+    b.lvl_w.ensure((size_t)items * sizeof(XYZZ<F>));
+    ARK_LAUNCH((msm_reduce_l1_kernel<F>), dim3((items + MSM_THREADS - 1) / MSM_THREADS), dim3(MSM_THREADS), 0, stream,
+               (const XYZZ<F>*)b.buckets.as<XYZZ<F>>(), p.total_buckets, b.lvl_t.as<XYZZ<F>>(), b.lvl_w.as<XYZZ<F>>());
+    ARK_CHECK_LAUNCH();
+    const uint32_t chunks2 = (items + MSM_RED_K - 1) / MSM_RED_K;
+    const uint32_t blocks2 = (chunks2 + MSM_THREADS - 1) / MSM_THREADS;
+    b.partials.ensure((size_t)blocks2 * sizeof(XYZZ<F>));
+    ARK_LAUNCH((msm_reduce_l2_kernel<F>), dim3(blocks2), dim3(MSM_THREADS), 0, stream, (const XYZZ<F>*)b.lvl_t.as<XYZZ<F>>(),
+               (const XYZZ<F>*)b.lvl_w.as<XYZZ<F>>(), items, b.partials.as<XYZZ<F>>());
+    ARK_CHECK_LAUNCH();
+    ARK_LAUNCH((msm_combine_kernel<F>), dim3(1), dim3(64), 0, stream, b.partials.as<XYZZ<F>>(), blocks2, 1u, p.c, d_out,
+               accumulate);
+    ARK_CHECK_LAUNCH();
+    return;
+  }
   const uint32_t chunks = (p.buckets_per_window + MSM_RED_K - 1) / MSM_RED_K;
   const uint32_t blocks_per_window = (chunks + MSM_THREADS - 1) / MSM_THREADS;
   b.partials.ensure((size_t)blocks_per_window * p.key_windows * sizeof(XYZZ<F>));

@@ -192,9 +192,8 @@ static void* witness_map_run(ark355_ctx* ctx, const R1csDev& r, const void* d_z,
   for (int v = 0; v < 3; v++) {
     cur[v] = ws.buf[2 * v].p;
     oth[v] = ws.buf[2 * v + 1].p;
-    void* res = ntt_run<Curve>(ctx, cur[v], oth[v], r.log_n, /*inverse=*/true, /*coset=*/false, stream);
-    if (res != cur[v]) { oth[v] = cur[v]; cur[v] = res; }
-    res = ntt_run<Curve>(ctx, cur[v], oth[v], r.log_n, /*inverse=*/false, /*coset=*/true, stream);
+    // evaluations on H -> evaluations on g H: inverse NTT and coset NTT with the seam fused (ntt_impl.cuh)
+    void* res = ntt_inverse_then_coset<Curve>(ctx, cur[v], oth[v], r.log_n, stream);
     if (res != cur[v]) { oth[v] = cur[v]; cur[v] = res; }
   }
   const uint32_t grid = (uint32_t)((r.N + 255) / 256);

@@ -358,9 +358,38 @@ class Groth16 {
     }
     if (synth_threads < 1) synth_threads = 1;
     if (inflight < 1) inflight = 1;
+    // assignments travel in page-locked buffers (ark355_host_alloc): the H2D copy inside ark355_prove then runs at
+    // PCIe rate instead of being staged through the runtime's bounce buffers
+    struct Pinned {
+      Fr* p = nullptr;
+      size_t n = 0;
+    };
     struct Item {
       size_t index;
-      std::vector<Fr> z;
+      Pinned z;
+    };
+    std::vector<Pinned> pool;
+    std::mutex pool_mu;
+    auto take_buf = [&](size_t n) {
+      {
+        std::lock_guard<std::mutex> lk(pool_mu);
+        for (size_t k = 0; k < pool.size(); k++)
+          if (pool[k].n >= n) {
+            Pinned b = pool[k];
+            pool.erase(pool.begin() + k);
+            return b;
+          }
+      }
+      Pinned b;
+      void* raw = nullptr;
+      if (ark355_host_alloc(n * sizeof(Fr), &raw) != ARK355_OK) throw std::bad_alloc();
+      b.p = static_cast<Fr*>(raw);
+      b.n = n;
+      return b;
+    };
+    auto give_buf = [&](Pinned b) {
+      std::lock_guard<std::mutex> lk(pool_mu);
+      pool.push_back(b);
     };
     std::deque<Item> queue;
     std::mutex mu;
@@ -392,7 +421,12 @@ class Groth16 {
           auto c = make_circuit(i);
           c->generate_constraints(cs);
           cs.finalize();
-          Item it{i, cs.borrow().full_assignment()};
+          const auto& inner = cs.borrow();
+          const size_t zi = inner.instance_assignment.size(), zw = inner.witness_assignment.size();
+          Item it{i, take_buf(zi + zw)};
+          std::memcpy(it.z.p, inner.instance_assignment.data(), zi * sizeof(Fr));       // z = instance || witness
+          std::memcpy(it.z.p + zi, inner.witness_assignment.data(), zw * sizeof(Fr));
+          it.z.n = zi + zw;
           synth_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(now() - t0).count();
           std::unique_lock<std::mutex> lk(mu);
           cv_not_full.wait(lk, [&] { return queue.size() < cap || failed; });
@@ -425,9 +459,10 @@ class Groth16 {
           randomisers[it.index].second.to_canonical_bytes(sc);
           ark355_proof_raw raw;
           const auto t0 = now();
-          const int e = ark355_prove(ctx, pk.resident->pk, pk.resident->r1cs, reinterpret_cast<const uint8_t*>(it.z.data()),
-                                     it.z.size(), rc, sc, &raw);
+          const int e = ark355_prove(ctx, pk.resident->pk, pk.resident->r1cs, reinterpret_cast<const uint8_t*>(it.z.p),
+                                     it.z.n, rc, sc, &raw);
           prove_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(now() - t0).count();
+          give_buf(it.z);
           if (e != ARK355_OK) throw BackendError(e, ark355_last_error(ctx));
           Proof& p = out[it.index];
           p.a.assign(raw.a, raw.a + G1);
@@ -453,6 +488,8 @@ class Groth16 {
     for (auto& t : th) t.join();
     const double wall = std::chrono::duration<double>(now() - t_start).count();
     for (ark355_ctx* c : extra_ctx) ark355_ctx_destroy(c);
+    for (auto& it : queue) pool.push_back(it.z);
+    for (auto& b : pool) ark355_host_free(b.p);
     if (first_error) std::rethrow_exception(first_error);
     if (stats) {
       stats->wall_s = wall;

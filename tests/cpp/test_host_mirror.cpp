@@ -455,7 +455,20 @@ static int run_e2e(size_t n, size_t count, uint32_t synth_threads, uint32_t infl
   // warm-up: loads key + matrices, touches every prover context
   typename G::PipelineStats st;
   groth.prove_pipelined(keys.first, std::min<size_t>(count, 2 * inflight), make, rs, synth_threads, inflight, &st);
+  // optional sweep over the number of synthesis threads (ARK355_E2E_SWEEP="4,6,12"): one line each
+  if (const char* sw = getenv("ARK355_E2E_SWEEP")) {
+    for (const char* q = sw; *q;) {
+      const uint32_t k = (uint32_t)strtoul(q, const_cast<char**>(&q), 10);
+      if (*q == ',') q++;
+      if (!k) break;
+      typename G::PipelineStats s2;
+      groth.prove_pipelined(keys.first, count, make, rs, k, inflight, &s2);
+      printf("sweep synth_threads=%u inflight=%u wall_s=%.4f constraints_per_s=%.0f synth_cpu_s=%.3f prove_call_s=%.3f\n", k,
+             inflight, s2.wall_s, (double)n * count / s2.wall_s, s2.synth_s, s2.prove_s);
+    }
+  }
   auto proofs = groth.prove_pipelined(keys.first, count, make, rs, synth_threads, inflight, &st);
+  printf("e2e_synth_threads=%u\ne2e_inflight=%u\n", synth_threads, inflight);
   printf("e2e_wall_s=%.4f\ne2e_constraints_per_s=%.0f\ne2e_synth_cpu_s=%.4f\ne2e_prove_call_s=%.4f\n", st.wall_s,
          (double)n * count / st.wall_s, st.synth_s, st.prove_s);
   // device-only: the same circuits, synthesised up front on this thread, then ark355_prove_batch

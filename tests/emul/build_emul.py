@@ -28,7 +28,7 @@ def build(force=False):
     if not force and os.path.exists(OUT) and os.path.getmtime(OUT) >= newest_src():
         return OUT
     objs = []
-    flags = ["-O2", "-std=c++17", "-fPIC", "-DARK_EMUL", "-DARK_MSM_HEAVY_SPAN=2", "-DARK_MSM_HEAVY_GRID=3u", "-I", HERE, "-I", CSRC, "-w"]
+    flags = ["-O2", "-std=c++17", "-fPIC", "-DARK_EMUL", "-DARK_MSM_HEAVY_SPAN=2", "-DARK_MSM_HEAVY_GRID=3u", "-DARK_MSM_TWO_LEVEL_MIN=64u", "-I", HERE, "-I", CSRC, "-w"]
 
     def cc(src):
         obj = os.path.join(HERE, os.path.basename(src) + ".emul.o")

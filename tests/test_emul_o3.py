@@ -22,3 +22,18 @@ def test_resident_msm_vs_o3_on_the_emulator(emul_lib, emul_ctx, group):
         return a.ctypes.data, a
 
     O.check_resident_msm(emul_lib, emul_ctx, BLS12_381, group, 200, to_dev)
+
+
+def test_large_window_two_level_reduction_and_odd_segments(emul_lib, emul_ctx, monkeypatch):
+    """Window size 13 over window tables (4096 buckets: the two-level bucket reduction, level 1 with 16 buckets per
+    lane) and a segment length that is not a power of two, against oracle/c -- the configuration the GPU reaches with
+    ARK355_MSM_C=20 at 2^20 terms."""
+    monkeypatch.setenv("ARK355_MSM_C", "13")
+    monkeypatch.setenv("ARK355_MSM_SEG", "37")
+
+    def to_dev(b):
+        a = np.frombuffer(b, dtype=np.uint8).copy()
+        return a.ctypes.data, a
+
+    O.check_resident_msm(emul_lib, emul_ctx, BLS12_381, 1, 1024, to_dev, seed=7)
+    O.check_resident_msm(emul_lib, emul_ctx, BN254, 2, 1024, to_dev, seed=8)

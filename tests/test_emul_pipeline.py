@@ -163,3 +163,34 @@ def test_reference_example_circuit_on_the_emulator(emul_lib, emul_ctx):
     rh = r1cs_load_from_rows(emul_lib, emul_ctx, C, A2, B2, C2, ell, len(z2) - ell)
     assert emul_lib.is_satisfied(emul_ctx, rh, z_bytes(C, z2), len(z2)) == 1
     emul_lib.dll.ark355_r1cs_free(rh)
+
+
+@pytest.mark.parametrize("rmax", ["9", "3", "2"])
+def test_ntt_every_radix_and_pass_count(emul_lib, emul_ctx, rmax, monkeypatch):
+    """Register-resident radix-8 groups, LDS re-deals, direct inter-pass tables, the fused inverse->coset seam and the
+    pointwise fusion, for every pass radix 2^1..2^9 and for 1..5 passes (ARK355_NTT_RMAX shrinks the largest radix so
+    that small vectors take many passes), all four transform modes against the oracle; then the witness map."""
+    monkeypatch.setenv("ARK355_NTT_RMAX", rmax)
+    C = BLS12_381
+    for log_n in (range(1, 11) if rmax != "9" else (2, 3, 5, 6, 7, 8, 10, 12)):
+        pc.ntt_case(emul_lib, emul_ctx, C, log_n, seed=int(rmax))
+    # 3000 / 9000 constraints: domains of 2^12 (radices 6, 6) and 2^14 (7, 7) -- the fused inverse -> coset seam kernel
+    for n in (5, 60, 250, 900) + ((3000, 9000) if rmax == "9" else ()):
+        A, B, Cm, z, ell = S.mulchain_direct(C.r, n)
+        pc.r1cs_case(emul_lib, emul_ctx, C, A, B, Cm, z, ell)
+    pc.ntt_case(emul_lib, emul_ctx, BN254, 7, seed=3)
+
+
+def test_ntt_without_direct_twiddle_tables(emul_lib, emul_ctx, monkeypatch):
+    """Domains beyond 2^23 points have no direct inter-pass table for their first pass: the composed twiddle is applied
+    by an elementwise kernel after the pass.  Forced here on small vectors (fresh context: tables are cached)."""
+    monkeypatch.setenv("ARK355_NTT_DIRECT_MAX", "4")
+    monkeypatch.setenv("ARK355_NTT_RMAX", "3")
+    ctx = emul_lib.ctx_create(0)
+    try:
+        for log_n in (7, 9, 10):
+            pc.ntt_case(emul_lib, ctx, BLS12_381, log_n, seed=5)
+        A, B, Cm, z, ell = S.mulchain_direct(BLS12_381.r, 300)
+        pc.r1cs_case(emul_lib, ctx, BLS12_381, A, B, Cm, z, ell)
+    finally:
+        emul_lib.ctx_destroy(ctx)

@@ -25,7 +25,7 @@ def exe():
         h.update(open(d, "rb").read())
     stamp = EXE + ".srchash"
     if not os.path.exists(EXE) or not os.path.exists(stamp) or open(stamp).read() != h.hexdigest():
-        subprocess.check_call(["g++", "-O1", "-std=c++17", src, "-o", EXE, "-L" + os.path.join(ROOT, "snark_amd"),
+        subprocess.check_call(["g++", "-O2", "-pthread", "-std=c++17", src, "-o", EXE, "-L" + os.path.join(ROOT, "snark_amd"),
                                "-lark355", "-Wl,-rpath," + os.path.join(ROOT, "snark_amd")])
         open(stamp, "w").write(h.hexdigest())
     return EXE
