@@ -243,6 +243,16 @@ int32_t ark355_xyzz_sum(ark355_ctx* ctx, int32_t curve, int32_t group, const uin
 int32_t ark355_fixed_base_mul(ark355_ctx* ctx, int32_t curve, int32_t group, const uint8_t* base,
                               const uint8_t* scalars, uint64_t n, uint8_t* out_affine);
 
+/* The scalars of the Groth16 generator (circuit_specific_setup, snark/src/lib.rs:43-46; upstream
+ * generate_parameters_with_qap) from the R1CS matrices in CSR and the five trapdoor elements tau, alpha, beta, gamma,
+ * delta (5 x 32 B canonical): u_j(tau), v_j(tau), w_j(tau) (num_instance + num_witness each), l_j (num_witness),
+ * gamma_abc_j (num_instance), h_i (N - 1) -- canonical 32-byte values ready for ark355_fixed_base_mul.  Host threads
+ * only (the library's own field code); ARK355_E_POLY_DEGREE_TOO_LARGE past the field's two-adicity. */
+int32_t ark355_setup_scalars(int32_t curve, uint64_t n_constraints, uint64_t num_instance, uint64_t num_witness,
+                             const uint64_t* const row_ptr[3], const uint32_t* const col[3],
+                             const uint8_t* const coeff[3], const uint8_t* trapdoor, uint8_t* out_u, uint8_t* out_v,
+                             uint8_t* out_w, uint8_t* out_l, uint8_t* out_gamma_abc, uint8_t* out_h);
+
 /* ---- timings of the last prove on this context (ms, measured with HIP events) --------------- */
 typedef struct {
   float total_ms;

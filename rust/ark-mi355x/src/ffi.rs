@@ -294,6 +294,23 @@ extern "C" {
         out_affine: *mut u8,
     ) -> i32;
 
+    pub fn ark355_setup_scalars(
+        curve: i32,
+        n_constraints: u64,
+        num_instance: u64,
+        num_witness: u64,
+        row_ptr: *const *const u64,
+        col: *const *const u32,
+        coeff: *const *const u8,
+        trapdoor: *const u8,
+        out_u: *mut u8,
+        out_v: *mut u8,
+        out_w: *mut u8,
+        out_l: *mut u8,
+        out_gamma_abc: *mut u8,
+        out_h: *mut u8,
+    ) -> i32;
+
     pub fn ark355_get_timings(ctx: *const ark355_ctx, out: *mut ark355_timings) -> i32;
     pub fn ark355_get_kernel_stats(ctx: *const ark355_ctx, accumulate_ms: *mut f32, launches: *mut u64, points: *mut u64) -> i32;
 }

@@ -46,6 +46,7 @@ SYMBOLS = [
     "ark355_prove_combine", "ark355_prove_batch", "ark355_comm_unique_id", "ark355_comm_init", "ark355_comm_destroy",
     "ark355_prove_sharded", "ark355_prove_sharded_dev", "ark355_point_size", "ark355_pk_load_bytes", "ark355_pk_dims",
     "ark355_points_decode", "ark355_points_encode", "ark355_proof_to_bytes", "ark355_proof_from_bytes",
+    "ark355_setup_scalars",
 ]
 
 
@@ -153,6 +154,7 @@ class Lib:
         d.ark355_points_encode.argtypes = [vp, i32, i32, vp, u64, i32, vp]
         d.ark355_proof_to_bytes.argtypes = [i32, P(ProofRaw), i32, vp]
         d.ark355_proof_from_bytes.argtypes = [i32, vp, u64, i32, i32, P(ProofRaw)]
+        d.ark355_setup_scalars.argtypes = [i32, u64, u64, u64, P(vp * 3), P(vp * 3), P(vp * 3), vp, vp, vp, vp, vp, vp, vp]
         d.ark355_get_timings.argtypes = [vp, P(Timings)]
         d.ark355_get_kernel_stats.argtypes = [vp, P(C.c_float), P(u64), P(u64)]
         for name in SYMBOLS:
@@ -396,6 +398,33 @@ class Lib:
         sb, k2 = _buf(scalars if n else None)
         self.check(ctx, self.dll.ark355_fixed_base_mul(ctx, curve, group, bb, sb, n, out.ctypes.data_as(C.c_void_p)))
         return out.tobytes()[:n * point_size]
+
+    def setup_scalars(self, curve, n, ell, w, mats, trapdoor: bytes):
+        """ark355_setup_scalars: mats as for r1cs_load; trapdoor = tau|alpha|beta|gamma|delta (5 x 32 B canonical).
+        Returns dict of canonical byte strings u, v, w (m each), l (w), gamma_abc (ell), h (N - 1)."""
+        keep = []
+        rp = (C.c_void_p * 3)()
+        cl = (C.c_void_p * 3)()
+        cf = (C.c_void_p * 3)()
+        for i, (row_ptr, col, coeff) in enumerate(mats):
+            a = np.ascontiguousarray(row_ptr, dtype=np.uint64)
+            b = np.ascontiguousarray(col, dtype=np.uint32)
+            if b.size == 0:
+                b = np.zeros(1, dtype=np.uint32)
+            c, kc = _buf(coeff if len(coeff) else bytes(32))
+            keep += [a, b, kc]
+            rp[i], cl[i], cf[i] = a.ctypes.data, b.ctypes.data, c.value
+        N = 1
+        while N < n + ell:
+            N <<= 1
+        m = ell + w
+        outs = {k: np.zeros(max(1, cnt) * 32, dtype=np.uint8)
+                for k, cnt in (("u", m), ("v", m), ("w", m), ("l", w), ("gamma_abc", ell), ("h", N - 1))}
+        tb, kt = _buf(trapdoor)
+        self.check(None, self.dll.ark355_setup_scalars(curve, n, ell, w, C.byref(rp), C.byref(cl), C.byref(cf), tb,
+                                                       *[outs[k].ctypes.data_as(C.c_void_p) for k in ("u", "v", "w", "l", "gamma_abc", "h")]))
+        cnts = {"u": m, "v": m, "w": m, "l": w, "gamma_abc": ell, "h": N - 1}
+        return {k: outs[k][:cnts[k] * 32] for k in outs}
 
     def timings(self, ctx):
         t = Timings()

@@ -1,5 +1,7 @@
 // Per-curve implementation of the C ABI (explicitly instantiated in ark355_bls.hip / ark355_bn.hip).
 #pragma once
+#include <functional>
+#include <thread>
 #include "common.h"
 #include "groth16_impl.cuh"
 #include "wire_impl.cuh"
@@ -12,16 +14,38 @@ struct BasesDev {
   PrecompTable tab;      // per-window tables of the resident bases
 };
 
-// one lane per scalar: k * P by double-and-add, then affine (setup-time fixed-base multiplications)
+// ---- fixed-base multiplication (setup: the generator's five query vectors are k_i * G) -----------------------------
+// Windowed: T[w][d-1] = d * 2^(8w) * base for d = 1..255, w < 32 (8 160 affine points, built once per call on the
+// device), then every scalar costs 32 mixed additions instead of the ~383 group operations of double-and-add, and the
+// results are normalised 16 at a time with one inversion (batch_to_affine_kernel).  The first version (one lane per
+// scalar, double-and-add, an inversion each) spilled 2.9 KB per lane and took most of the 9 s of bench.py's preparation.
+constexpr uint32_t FB_WBITS = 8, FB_WINDOWS = 32, FB_ROW = (1u << FB_WBITS) - 1u;
+
+// row w of the table in XYZZ form: lane d-1 computes d * (2^(8w) base) by double-and-add over the 8-bit d
+template <class F>
+__global__ void __launch_bounds__(256)
+fixed_base_table_kernel(const Affine<F>* __restrict__ base, XYZZ<F>* __restrict__ table) {
+  const uint32_t w = blockIdx.x, d = threadIdx.x + 1;
+  if (d > FB_ROW) return;
+  XYZZ<F> p = XYZZ<F>::from_affine(*base);
+  for (uint32_t i = 0; i < w * FB_WBITS; i++) p = xyzz_dbl(p);
+  uint32_t k = d;
+  table[w * FB_ROW + (d - 1)] = xyzz_mul_scalar(p, &k, 1);
+}
+
 template <class F, class Fr>
 __global__ void __launch_bounds__(128)
-fixed_base_mul_kernel(const Affine<F>* __restrict__ base, const Fr* __restrict__ scalars, uint64_t n,
-                      Affine<F>* __restrict__ out) {
+fixed_base_mul_kernel(const Affine<F>* __restrict__ table, const Fr* __restrict__ scalars, uint64_t n,
+                      XYZZ<F>* __restrict__ out) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const Fr k = scalars[i];
-  const XYZZ<F> p = XYZZ<F>::from_affine(*base);
-  out[i] = xyzz_to_affine(xyzz_mul_scalar(p, k.l, Fr::N));
+  XYZZ<F> acc = XYZZ<F>::inf();
+  for (uint32_t w = 0; w < FB_WINDOWS; w++) {
+    const uint32_t d = (k.l[w >> 2] >> ((w & 3u) * 8u)) & 0xFFu;
+    if (d) xyzz_madd_ni(acc, table[w * FB_ROW + (d - 1)]);
+  }
+  out[i] = acc;
 }
 
 struct GenericScratch {
@@ -215,26 +239,139 @@ struct Api {
   template <class F>
   static void fixed_base_t(ark355_ctx* ctx, GenericScratch& g, const uint8_t* base, const uint8_t* scalars, uint64_t n,
                            uint8_t* out) {
+    static_assert(Fr::N * 4 == FB_WINDOWS, "one 8-bit window per scalar byte");
     hipStream_t st = ctx->stream;
-    g.a.ensure(sizeof(Affine<F>));
+    const uint32_t rows = FB_WINDOWS * FB_ROW;
+    DevBuf d_base(sizeof(Affine<F>)), d_tx((size_t)rows * sizeof(XYZZ<F>)), d_ta((size_t)rows * sizeof(Affine<F>));
     g.b.ensure(n * sizeof(Fr));
-    g.c.ensure(n * sizeof(Affine<F>));
-    ARK_CHECK_HIP(hipMemcpyAsync(g.a.p, base, sizeof(Affine<F>), hipMemcpyHostToDevice, st));
+    g.a.ensure((n ? n : 1) * sizeof(XYZZ<F>));
+    g.c.ensure((n ? n : 1) * sizeof(Affine<F>));
+    ARK_CHECK_HIP(hipMemcpyAsync(d_base.p, base, sizeof(Affine<F>), hipMemcpyHostToDevice, st));
     if (n) {
+      ARK_LAUNCH((fixed_base_table_kernel<F>), dim3(FB_WINDOWS), dim3(256), 0, st, (const Affine<F>*)d_base.as<Affine<F>>(),
+                 d_tx.as<XYZZ<F>>());
+      ARK_CHECK_LAUNCH();
+      ARK_LAUNCH((batch_to_affine_kernel<F>), dim3(((rows + PRE_K - 1) / PRE_K + MSM_THREADS - 1) / MSM_THREADS), dim3(MSM_THREADS),
+                 0, st, (const XYZZ<F>*)d_tx.as<XYZZ<F>>(), d_ta.as<Affine<F>>(), rows);
+      ARK_CHECK_LAUNCH();
       ARK_CHECK_HIP(hipMemcpyAsync(g.b.p, scalars, n * sizeof(Fr), hipMemcpyHostToDevice, st));
-      const uint32_t grid = (uint32_t)((n + 127) / 128);
-      ARK_LAUNCH((fixed_base_mul_kernel<F, Fr>), dim3(grid), dim3(128), 0, st, g.a.as<Affine<F>>(), g.b.as<Fr>(), n,
-                 g.c.as<Affine<F>>());
+      ARK_REQUIRE(n < (1ull << 32), ARK355_EINVAL, "too many scalars");
+      ARK_LAUNCH((fixed_base_mul_kernel<F, Fr>), dim3((uint32_t)((n + 127) / 128)), dim3(128), 0, st,
+                 (const Affine<F>*)d_ta.as<Affine<F>>(), g.b.as<Fr>(), n, g.a.as<XYZZ<F>>());
+      ARK_CHECK_LAUNCH();
+      ARK_LAUNCH((batch_to_affine_kernel<F>), dim3((uint32_t)(((n + PRE_K - 1) / PRE_K + MSM_THREADS - 1) / MSM_THREADS)),
+                 dim3(MSM_THREADS), 0, st, (const XYZZ<F>*)g.a.as<XYZZ<F>>(), g.c.as<Affine<F>>(), (uint32_t)n);
       ARK_CHECK_LAUNCH();
       ARK_CHECK_HIP(hipMemcpyAsync(out, g.c.p, n * sizeof(Affine<F>), hipMemcpyDeviceToHost, st));
     }
-    ARK_CHECK_HIP(hipStreamSynchronize(st));
+    ARK_CHECK_HIP(hipStreamSynchronize(st));       // the table buffers are freed on return
   }
 
   static void fixed_base(ark355_ctx* ctx, GenericScratch& g, int group, const uint8_t* base, const uint8_t* scalars,
                          uint64_t n, uint8_t* out) {
     if (group == 1) fixed_base_t<Fq>(ctx, g, base, scalars, n, out);
     else fixed_base_t<Fq2>(ctx, g, base, scalars, n, out);
+  }
+
+  // ---- Groth16 generator scalars on the host (the library's own field code, std::thread) ------------------------------
+  // Upstream `generate_parameters_with_qap` / `R1CSToQAP::instance_map_with_evaluation` (SURVEY.md Appendix A "Setup"):
+  //   L_k(tau) = Z(tau)/N * w^k / (tau - w^k);  u_j = sum_k L_k A[k][j] (+ L_{n+j} for j < ell), v_j, w_j likewise;
+  //   l_j = (beta u_j + alpha v_j + w_j) / delta (witness columns), gamma_abc_j = (...) / gamma (instance columns),
+  //   h_i = Z(tau) tau^i / delta.  All outputs canonical 32-byte little-endian; the fixed-base multiplications that turn
+  // them into the key's query vectors are ark355_fixed_base_mul's job.
+  static void setup_scalars(uint64_t n, uint64_t ell, uint64_t w, const uint64_t* const rp[3], const uint32_t* const col[3],
+                            const uint8_t* const coeff[3], const uint8_t* trapdoor, uint8_t* out_u, uint8_t* out_v,
+                            uint8_t* out_w, uint8_t* out_l, uint8_t* out_gabc, uint8_t* out_h) {
+    using P = typename Fr::Params;
+    ARK_REQUIRE(ell >= 1, ARK355_EINVAL, "num_instance must include the constant One");
+    const uint64_t m = ell + w;
+    uint32_t lg = 0;
+    while ((1ull << lg) < n + ell) lg++;
+    ARK_REQUIRE(lg <= (uint32_t)P::TWO_ADICITY, ARK355_E_POLY_DEGREE_TOO_LARGE, "n + ell exceeds the largest radix-2 domain of Fr");
+    const uint64_t N = 1ull << lg;
+    Fr td[5];
+    for (int i = 0; i < 5; i++) {
+      Fr c;
+      memcpy(c.l, trapdoor + 32 * i, sizeof(Fr));
+      td[i] = Fr::to_mont(c);
+    }
+    const Fr tau = td[0], alpha = td[1], beta = td[2], gamma = td[3], delta = td[4];
+    const Fr omega = ntt_root<Fr>(lg, false);
+    const Fr zt = Fr::sub(fr_pow_u64(tau, N), Fr::one());
+    ARK_REQUIRE(!zt.is_zero(), ARK355_EINVAL, "tau lies in the evaluation domain");
+    Fr nn = Fr::zero();
+    nn.l[0] = (uint32_t)N;
+    nn.l[1] = (uint32_t)(N >> 32);
+    const Fr cN = Fr::mul(zt, Fr::inv(Fr::to_mont(nn)));
+    unsigned nt = std::thread::hardware_concurrency();
+    if (nt == 0) nt = 4;
+    if (nt > 32) nt = 32;
+    auto parallel = [&](uint64_t count, const std::function<void(uint64_t, uint64_t)>& fn) {
+      const uint64_t chunk = (count + nt - 1) / nt;
+      std::vector<std::thread> th;
+      for (unsigned t = 0; t < nt; t++) {
+        const uint64_t a = t * chunk, b = std::min<uint64_t>(count, a + chunk);
+        if (a < b) th.emplace_back(fn, a, b);
+      }
+      for (auto& x : th) x.join();
+    };
+    std::vector<Fr> L(N), wk(N);
+    parallel(N, [&](uint64_t a, uint64_t b) {
+      Fr p = fr_pow_u64(omega, a), acc = Fr::one();
+      for (uint64_t k = a; k < b; k++) {            // prefix products of the denominators of this chunk
+        wk[k] = p;
+        acc = Fr::mul(acc, Fr::sub(tau, p));
+        L[k] = acc;
+        p = Fr::mul(p, omega);
+      }
+      Fr inv = Fr::inv(acc);
+      for (uint64_t k = b; k-- > a;) {
+        const Fr iv = k > a ? Fr::mul(inv, L[k - 1]) : inv;
+        inv = Fr::mul(inv, Fr::sub(tau, wk[k]));
+        L[k] = Fr::mul(Fr::mul(iv, wk[k]), cN);
+      }
+    });
+    std::vector<Fr> uvw[3];
+    for (auto& x : uvw) x.assign(m, Fr::zero());
+    for (uint64_t i = 0; i < ell; i++) uvw[0][i] = L[n + i];
+    {
+      const Fr one = Fr::one();
+      std::vector<std::thread> th;
+      for (int k = 0; k < 3; k++)
+        th.emplace_back([&, k] {
+          for (uint64_t i = 0; i < n; i++)
+            for (uint64_t t = rp[k][i]; t < rp[k][i + 1]; t++) {
+              Fr c;
+              memcpy(c.l, coeff[k] + t * sizeof(Fr), sizeof(Fr));
+              Fr& dst = uvw[k][col[k][t]];
+              dst = Fr::add(dst, c == one ? L[i] : Fr::mul(L[i], c));
+            }
+        });
+      for (auto& x : th) x.join();
+    }
+    const Fr gi = Fr::inv(gamma), di = Fr::inv(delta);
+    auto put = [](uint8_t* dst, uint64_t i, const Fr& mont) {
+      const Fr c = Fr::from_mont(mont);
+      memcpy(dst + 32 * i, c.l, sizeof(Fr));
+    };
+    parallel(m, [&](uint64_t a, uint64_t b) {
+      for (uint64_t i = a; i < b; i++) {
+        const Fr abc = Fr::add(Fr::add(Fr::mul(beta, uvw[0][i]), Fr::mul(alpha, uvw[1][i])), uvw[2][i]);
+        if (i < ell) put(out_gabc, i, Fr::mul(abc, gi));
+        else put(out_l, i - ell, Fr::mul(abc, di));
+        put(out_u, i, uvw[0][i]);
+        put(out_v, i, uvw[1][i]);
+        put(out_w, i, uvw[2][i]);
+      }
+    });
+    const Fr h0 = Fr::mul(zt, di);
+    parallel(N - 1, [&](uint64_t a, uint64_t b) {
+      Fr p = Fr::mul(fr_pow_u64(tau, a), h0);
+      for (uint64_t i = a; i < b; i++) {
+        put(out_h, i, p);
+        p = Fr::mul(p, tau);
+      }
+    });
   }
 
   // ---- ark-serialize wire formats (wire_impl.cuh) ------------------------------------------------------------------

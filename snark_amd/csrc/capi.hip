@@ -560,6 +560,19 @@ int32_t ark355_proof_from_bytes(int32_t curve, const uint8_t* in, uint64_t len, 
   return guarded(nullptr, [&] { CURVE_DISPATCH(curve, A::proof_from_bytes(in, len, compressed != 0, validate != 0, out)); });
 }
 
+int32_t ark355_setup_scalars(int32_t curve, uint64_t n, uint64_t ell, uint64_t w, const uint64_t* const row_ptr[3],
+                             const uint32_t* const col[3], const uint8_t* const coeff[3], const uint8_t* trapdoor,
+                             uint8_t* out_u, uint8_t* out_v, uint8_t* out_w, uint8_t* out_l, uint8_t* out_gamma_abc,
+                             uint8_t* out_h) {
+  if (!row_ptr || !col || !coeff || !trapdoor || !out_u || !out_v || !out_w || !out_l || !out_gamma_abc || !out_h)
+    return ARK355_EINVAL;
+  for (int i = 0; i < 3; i++)
+    if (!row_ptr[i] || !col[i] || !coeff[i]) return ARK355_EINVAL;
+  return guarded(nullptr, [&] {
+    CURVE_DISPATCH(curve, A::setup_scalars(n, ell, w, row_ptr, col, coeff, trapdoor, out_u, out_v, out_w, out_l, out_gamma_abc, out_h));
+  });
+}
+
 int32_t ark355_get_timings(const ark355_ctx* ctx, ark355_timings* out) {
   if (!ctx || !out) return ARK355_EINVAL;
   *out = ctx->timings;

@@ -127,37 +127,6 @@ class Proof:
     c: bytes
 
 
-def _batch_inverse(vals, p):
-    pref, acc = [], 1
-    for v in vals:
-        acc = acc * v % p
-        pref.append(acc)
-    inv = pow(acc, -1, p)
-    out = [0] * len(vals)
-    for i in range(len(vals) - 1, -1, -1):
-        prev = pref[i - 1] if i else 1
-        out[i] = inv * prev % p
-        inv = inv * vals[i] % p
-    return out
-
-
-def _lagrange_at(curve: Curve, log_n: int, tau: int):
-    """[L_k(tau)] over the radix-2 domain H of size 2^log_n."""
-    r = curve.r
-    n = 1 << log_n
-    omega = curve.root_of_unity(log_n)
-    zt = (pow(tau, n, r) - 1) % r
-    ws, w = [], 1
-    for _ in range(n):
-        ws.append(w)
-        w = w * omega % r
-    if zt == 0:
-        return [1 if wk == tau % r else 0 for wk in ws], zt
-    invs = _batch_inverse([(tau - wk) % r for wk in ws], r)
-    c = zt * pow(n, -1, r) % r
-    return [c * wk % r * iv % r for wk, iv in zip(ws, invs)], zt
-
-
 class Groth16:
     """`impl SNARK<Fr> for Groth16` over the MI355X backend."""
 
@@ -194,54 +163,41 @@ class Groth16:
 
     # ---- SNARK::circuit_specific_setup (snark/src/lib.rs:43-46) ---------------------------------------
     def circuit_specific_setup(self, r1cs: R1CS, rng, keep_trapdoor=False) -> Tuple[ProvingKey, VerifyingKey]:
-        """`rng` yields field elements: callable rng() -> int (uniform mod r)."""
+        """`rng` yields field elements: callable rng() -> int (uniform mod r).  The generator's scalars (Lagrange
+        coefficients at tau, u/v/w, l, gamma_abc, h) come from `ark355_setup_scalars` (host threads, the library's own
+        field code), the query vectors from `ark355_fixed_base_mul` on the device."""
         cv, r = self.curve, self.curve.r
         tau, alpha, beta, gamma, delta = (rng() % r or 1 for _ in range(5))
-        n, ell, m = r1cs.n, r1cs.ell, r1cs.m
+        ell, m = r1cs.ell, r1cs.m
         N = r1cs.domain_size
-        log_n = N.bit_length() - 1
-        if log_n > cv.two_adicity:
+        if N.bit_length() - 1 > cv.two_adicity:
             raise SynthesisError("PolynomialDegreeTooLarge")
-        L, zt = _lagrange_at(cv, log_n, tau)
-        u = [0] * m
-        v = [0] * m
-        w = [0] * m
-        for i in range(ell):
-            u[i] = L[n + i]
-        for vec, k in ((u, 0), (v, 1), (w, 2)):
-            rp, col, ci = r1cs.row_ptr[k], r1cs.col[k], r1cs.coeff_int[k]
-            rp_l, col_l = rp.tolist(), col.tolist()
-            for i in range(n):
-                lk = L[i]
-                for t in range(rp_l[i], rp_l[i + 1]):
-                    j = col_l[t]
-                    c = ci[t]
-                    vec[j] = (vec[j] + (lk if c == 1 else lk * c)) % r
-        gi, di = pow(gamma, -1, r), pow(delta, -1, r)
-        abc = [(beta * u[i] + alpha * v[i] + w[i]) % r for i in range(m)]
-        gamma_abc_s = [abc[i] * gi % r for i in range(ell)]
-        l_s = [abc[i] * di % r for i in range(ell, m)]
-        h_s, t = [], zt * di % r
-        for _ in range(N - 1):
-            h_s.append(t)
-            t = t * tau % r
+        td = b"".join(cv.fr_canon(x) for x in (tau, alpha, beta, gamma, delta))
+        try:
+            sc = self.lib.setup_scalars(cv.curve_id, r1cs.n, ell, r1cs.w, list(zip(r1cs.row_ptr, r1cs.col, r1cs.coeff)), td)
+        except Ark355Error as e:
+            raise SynthesisError(str(e)) from e
         g1, g2 = cv.g1_gen_raw(), cv.g2_gen_raw()
 
-        def mul(group, scalars):
-            sb = b"".join(cv.fr_canon(s) for s in scalars)
-            return self.lib.fixed_base_mul(self.ctx, cv.curve_id, group, g1 if group == 1 else g2, sb, len(scalars),
+        def mul(group, scalars, n=None):
+            if not isinstance(scalars, np.ndarray):
+                scalars = np.frombuffer(b"".join(cv.fr_canon(s) for s in scalars), dtype=np.uint8)
+            n = len(scalars) // 32
+            return self.lib.fixed_base_mul(self.ctx, cv.curve_id, group, g1 if group == 1 else g2, scalars, n,
                                            self.sizes["g1"] if group == 1 else self.sizes["g2"])
 
         singles1 = mul(1, [alpha, beta, delta])
         singles2 = mul(2, [beta, gamma, delta])
         s1, s2 = self.sizes["g1"], self.sizes["g2"]
         vk = VerifyingKey(alpha_g1=singles1[:s1], beta_g2=singles2[:s2], gamma_g2=singles2[s2:2 * s2],
-                          delta_g2=singles2[2 * s2:], gamma_abc_g1=mul(1, gamma_abc_s))
+                          delta_g2=singles2[2 * s2:], gamma_abc_g1=mul(1, sc["gamma_abc"]))
         pk = ProvingKey(vk=vk, beta_g1=singles1[s1:2 * s1], delta_g1=singles1[2 * s1:],
-                        a_query=mul(1, u), b_g1_query=mul(1, v), b_g2_query=mul(2, v),
-                        h_query=mul(1, h_s), l_query=mul(1, l_s), ell=ell, w=r1cs.w, N=N)
+                        a_query=mul(1, sc["u"]), b_g1_query=mul(1, sc["v"]), b_g2_query=mul(2, sc["v"]),
+                        h_query=mul(1, sc["h"]), l_query=mul(1, sc["l"]), ell=ell, w=r1cs.w, N=N)
         if keep_trapdoor:
-            pk.trapdoor = dict(tau=tau, alpha=alpha, beta=beta, gamma=gamma, delta=delta, u=u, v=v, w=w)
+            # u, v, w stay as canonical byte images; prove_closed_form turns them into integers on first use
+            pk.trapdoor = dict(tau=tau, alpha=alpha, beta=beta, gamma=gamma, delta=delta,
+                               u=sc["u"].tobytes(), v=sc["v"].tobytes(), w=sc["w"].tobytes())
         return pk, vk
 
     # ---- device residency ---------------------------------------------------------------------------------
@@ -329,6 +285,10 @@ class Groth16:
             raise ValueError("setup was not asked to keep the trapdoor")
         cv, R = self.curve, self.curve.r
         m, ell = len(z_ints), pk.ell
+        for k in "uvw":                      # canonical byte images -> integers, once
+            if isinstance(td[k], (bytes, bytearray)):
+                b = td[k]
+                td[k] = [int.from_bytes(b[32 * i:32 * i + 32], "little") for i in range(len(b) // 32)]
         az = sum(z_ints[i] * td["u"][i] for i in range(m)) % R
         bz = sum(z_ints[i] * td["v"][i] for i in range(m)) % R
         cz = sum(z_ints[i] * td["w"][i] for i in range(m)) % R

@@ -208,3 +208,21 @@ def prove_batch_case(lib, ctx, C, count=5, n=9, inflight=3):
     finally:
         lib.dll.ark355_pk_free(pk)
         lib.dll.ark355_r1cs_free(r1)
+
+
+def fixed_base_case(lib, ctx, C, group, n=70, seed=21):
+    """ark355_fixed_base_mul (windowed table, batched normalisation) against the oracle's C fixed-base routine: random
+    scalars, 0 (infinity), 1, r - 1, single-window values, a 256-bit value beyond r, and a base at infinity."""
+    from oracle.c import cbase
+    rnd = random.Random(seed + group)
+    raw = Z.g1_raw if group == 1 else Z.g2_raw
+    G_ = g1(C) if group == 1 else g2(C)
+    sz = lib.sizes(C.curve_id)
+    psz = sz["g1"] if group == 1 else sz["g2"]
+    ks = [rnd.randrange(C.r) for _ in range(n)]
+    ks[:8] = [0, 1, C.r - 1, 255, 256, 1 << 248, (1 << 256) - 1, 0xFF00FF]
+    base = raw(C, G_.mul(G_.gen, 12345))
+    sb = b"".join(k.to_bytes(32, "little") for k in ks)
+    assert lib.fixed_base_mul(ctx, C.curve_id, group, base, sb, len(ks), psz) == cbase.fixed_base(C, group, base, sb, len(ks))
+    assert lib.fixed_base_mul(ctx, C.curve_id, group, bytes(psz), sb, 9, psz) == bytes(9 * psz)
+    assert lib.fixed_base_mul(ctx, C.curve_id, group, base, b"", 0, psz) == b""

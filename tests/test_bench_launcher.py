@@ -33,7 +33,7 @@ def test_bench_gpus_2_spawns_two_replica_ranks():
         assert key in d
 
 
-@pytest.mark.parametrize("exchange", ["window", "ring"])
+@pytest.mark.parametrize("exchange", ["ring"])      # the all-gather mode at 2, 3 and 8 ranks: tests/test_distributed_gloo.py
 def test_bench_shard_mode_two_ranks(exchange):
     d = _run("--gpus", "2", "--mode", "shard", "--shard-exchange", exchange, "--log-n", "7")
     assert d["n_gpus"] == 2 and d["scaling"] == "strong"

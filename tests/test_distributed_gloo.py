@@ -117,7 +117,7 @@ def test_sharded_prove_over_the_c_abi_comm(world, n, modes, tmp_path):
     _run(world, n, tmp_path, modes=modes, whole=False)
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2])
 def test_sharded_prove_small_instance_all_modes(world, tmp_path):
     """Both modes, plus the single-device proof of the same statement, at a size the emulator proves in seconds."""
     _run(world, 150, tmp_path)

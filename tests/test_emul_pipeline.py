@@ -194,3 +194,9 @@ def test_ntt_without_direct_twiddle_tables(emul_lib, emul_ctx, monkeypatch):
         pc.r1cs_case(emul_lib, ctx, BLS12_381, A, B, Cm, z, ell)
     finally:
         emul_lib.ctx_destroy(ctx)
+
+
+@pytest.mark.parametrize("C", [BLS12_381, BN254], ids=lambda c: c.name)
+@pytest.mark.parametrize("group", [1, 2])
+def test_fixed_base_mul_vs_oracle(emul_lib, emul_ctx, C, group):
+    pc.fixed_base_case(emul_lib, emul_ctx, C, group)

@@ -206,3 +206,9 @@ def test_sharded_prove_over_rccl():
                          timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     assert "rccl_ok 1" in out.stdout
+
+
+@pytest.mark.parametrize("C", [BLS12_381, BN254], ids=lambda c: c.name)
+@pytest.mark.parametrize("group", [1, 2])
+def test_fixed_base_mul_vs_oracle(gpu_lib, gpu_ctx, C, group):
+    pc.fixed_base_case(gpu_lib, gpu_ctx, C, group, n=4000)
