@@ -215,9 +215,11 @@ class Lib:
             a = np.ascontiguousarray(row_ptr, dtype=np.uint64)
             b = np.ascontiguousarray(col, dtype=np.uint32)
             c, kc = _buf(coeff if len(coeff) else b"\0")
+            if b.size == 0:
+                b = np.zeros(1, np.uint32)          # a valid pointer for an empty matrix (never read: nnz == 0)
             keep += [a, b, kc]
             rp[i] = a.ctypes.data
-            cl[i] = b.ctypes.data if b.size else np.zeros(1, np.uint32).ctypes.data
+            cl[i] = b.ctypes.data
             cf[i] = c.value
         h = C.c_void_p()
         self.check(ctx, self.dll.ark355_r1cs_load(ctx, curve, n, ell, w, C.byref(rp), C.byref(cl), C.byref(cf),

@@ -33,6 +33,18 @@ fixed_base_table_kernel(const Affine<F>* __restrict__ base, XYZZ<F>* __restrict_
   table[w * FB_ROW + (d - 1)] = xyzz_mul_scalar(p, &k, 1);
 }
 
+// a handful of scalars (the alpha/beta/gamma/delta points of a key, closed-form checks): one lane each, double-and-add --
+// building the 8 160-point table first would cost more than it saves
+template <class F, class Fr>
+__global__ void __launch_bounds__(128)
+fixed_base_small_kernel(const Affine<F>* __restrict__ base, const Fr* __restrict__ scalars, uint64_t n,
+                        XYZZ<F>* __restrict__ out) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const Fr k = scalars[i];
+  out[i] = xyzz_mul_scalar(XYZZ<F>::from_affine(*base), k.l, Fr::N);
+}
+
 template <class F, class Fr>
 __global__ void __launch_bounds__(128)
 fixed_base_mul_kernel(const Affine<F>* __restrict__ table, const Fr* __restrict__ scalars, uint64_t n,
@@ -248,17 +260,23 @@ struct Api {
     g.c.ensure((n ? n : 1) * sizeof(Affine<F>));
     ARK_CHECK_HIP(hipMemcpyAsync(d_base.p, base, sizeof(Affine<F>), hipMemcpyHostToDevice, st));
     if (n) {
-      ARK_LAUNCH((fixed_base_table_kernel<F>), dim3(FB_WINDOWS), dim3(256), 0, st, (const Affine<F>*)d_base.as<Affine<F>>(),
-                 d_tx.as<XYZZ<F>>());
-      ARK_CHECK_LAUNCH();
-      ARK_LAUNCH((batch_to_affine_kernel<F>), dim3(((rows + PRE_K - 1) / PRE_K + MSM_THREADS - 1) / MSM_THREADS), dim3(MSM_THREADS),
-                 0, st, (const XYZZ<F>*)d_tx.as<XYZZ<F>>(), d_ta.as<Affine<F>>(), rows);
-      ARK_CHECK_LAUNCH();
-      ARK_CHECK_HIP(hipMemcpyAsync(g.b.p, scalars, n * sizeof(Fr), hipMemcpyHostToDevice, st));
       ARK_REQUIRE(n < (1ull << 32), ARK355_EINVAL, "too many scalars");
-      ARK_LAUNCH((fixed_base_mul_kernel<F, Fr>), dim3((uint32_t)((n + 127) / 128)), dim3(128), 0, st,
-                 (const Affine<F>*)d_ta.as<Affine<F>>(), g.b.as<Fr>(), n, g.a.as<XYZZ<F>>());
-      ARK_CHECK_LAUNCH();
+      ARK_CHECK_HIP(hipMemcpyAsync(g.b.p, scalars, n * sizeof(Fr), hipMemcpyHostToDevice, st));
+      if (n < 512) {
+        ARK_LAUNCH((fixed_base_small_kernel<F, Fr>), dim3((uint32_t)((n + 127) / 128)), dim3(128), 0, st,
+                   (const Affine<F>*)d_base.as<Affine<F>>(), g.b.as<Fr>(), n, g.a.as<XYZZ<F>>());
+        ARK_CHECK_LAUNCH();
+      } else {
+        ARK_LAUNCH((fixed_base_table_kernel<F>), dim3(FB_WINDOWS), dim3(256), 0, st, (const Affine<F>*)d_base.as<Affine<F>>(),
+                   d_tx.as<XYZZ<F>>());
+        ARK_CHECK_LAUNCH();
+        ARK_LAUNCH((batch_to_affine_kernel<F>), dim3(((rows + PRE_K - 1) / PRE_K + MSM_THREADS - 1) / MSM_THREADS),
+                   dim3(MSM_THREADS), 0, st, (const XYZZ<F>*)d_tx.as<XYZZ<F>>(), d_ta.as<Affine<F>>(), rows);
+        ARK_CHECK_LAUNCH();
+        ARK_LAUNCH((fixed_base_mul_kernel<F, Fr>), dim3((uint32_t)((n + 127) / 128)), dim3(128), 0, st,
+                   (const Affine<F>*)d_ta.as<Affine<F>>(), g.b.as<Fr>(), n, g.a.as<XYZZ<F>>());
+        ARK_CHECK_LAUNCH();
+      }
       ARK_LAUNCH((batch_to_affine_kernel<F>), dim3((uint32_t)(((n + PRE_K - 1) / PRE_K + MSM_THREADS - 1) / MSM_THREADS)),
                  dim3(MSM_THREADS), 0, st, (const XYZZ<F>*)g.a.as<XYZZ<F>>(), g.c.as<Affine<F>>(), (uint32_t)n);
       ARK_CHECK_LAUNCH();

@@ -64,8 +64,7 @@ struct MsmPlan {
 // workgroups = exactly two rounds, but 13 windows (c = 20) / 64 = 832 workgroups still take two rounds -- the second
 // 62 % full -- and the saved additions buy nothing (measured in round 1: -19 % entries, -5 % time).  The length is
 // therefore chosen so that the segments fill a whole number of rounds: nearest round count at ~64 entries per lane,
-// then ceil(entries / (slots x rounds)).  Small MSMs keep 32 so that they stay wide.  pair_lanes: the G2 kernels use two
-// lanes per segment.  ARK355_MSM_SEG=<len> overrides (A/B, tests).
+// then ceil(entries / (slots x rounds)).  pair_lanes: the G2 kernels use two lanes per segment.  ARK355_MSM_SEG=<len> overrides (A/B, tests).
 static inline uint32_t msm_seg_len(uint64_t entries, bool pair_lanes) {
   if (const char* e = getenv("ARK355_MSM_SEG")) {
     const int v = atoi(e);
@@ -82,11 +81,12 @@ static inline uint32_t msm_seg_len(uint64_t entries, bool pair_lanes) {
   }();
 #endif
   const uint64_t slots = cus * 2 * MSM_THREADS / (pair_lanes ? 2 : 1);
-  if (entries <= slots * 48) return 32;
   uint64_t rounds = (entries + slots * 32) / (slots * 64);
   if (rounds < 1) rounds = 1;
+  // one round: every lane takes entries / slots (a 2^18-term MSM at c = 13 has 5.2 M entries = 40 per lane; with a fixed
+  // 32 it ran as 1.25 rounds, i.e. two); never below 16, so that small MSMs do not drown in partial runs
   uint64_t len = (entries + slots * rounds - 1) / (slots * rounds);
-  if (len < 32) len = 32;
+  if (len < 16) len = 16;
   if (len > 160) len = 160;
   return (uint32_t)len;
 }
@@ -680,7 +680,10 @@ msm_accumulate_g2l_kernel(const Affine<Fp2<P>>* __restrict__ bases, const uint32
 #endif
 constexpr uint32_t MSM_HEAVY_SPAN = ARK_MSM_HEAVY_SPAN;
 #ifndef ARK_MSM_HEAVY_GRID
-#define ARK_MSM_HEAVY_GRID 1024u
+// Workgroups of the heavy-bucket merge (each loops over the heavy list).  128 is plenty -- heavy buckets are few by
+// definition -- and 1024 mostly-empty workgroups queued behind the accumulation kernels of the other proofs in flight
+// held the reduction stream for ~0.6 ms per MSM (round-2 timeline).
+#define ARK_MSM_HEAVY_GRID 128u
 #endif
 template <class F>
 __global__ void __launch_bounds__(MSM_THREADS)
@@ -1133,14 +1136,18 @@ static void msm_sort(ark355_ctx* ctx, MsmSort& s, const void* d_scalars, uint64_
 struct MsmBuckets {
   DevBuf buckets, head, tail, head_key, tail_key, partials, heavy_count, heavy_list, lvl_t, lvl_w;
   uint32_t seg_len = 32, segs = 0;      // of the last accumulation over this bucket set (G1 and G2 differ)
+  bool prepared = false;                // msm_prepare_phase ran for the coming accumulation
 };
 
 // Phase 1 of the bucket method over an existing sort: bucket accumulation (the chip-filling kernel).
+// Size and clear the bucket set of one MSM over an existing sort.  The prover issues this on its (high-priority) sort
+// stream right behind the sort, so that the accumulation stream carries nothing but accumulation kernels: three small
+// fill kernels in front of every accumulation launch sat behind the other proofs' workgroups and opened a gap between
+// consecutive accumulations (31 fills per proof, 2.5 ms of stream time with four proofs in flight).
 template <class F>
-static void msm_accumulate_phase(ark355_ctx* ctx, const MsmSort& s, MsmBuckets& b, const Affine<F>* d_bases,
-                                 hipStream_t stream, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr,
-                                 bool bases28 = false) {
+static void msm_prepare_phase(const MsmSort& s, MsmBuckets& b, hipStream_t stream) {
   const MsmPlan& p = s.plan;
+  b.prepared = true;
   if (p.n == 0) return;
   const uint64_t entries = (uint64_t)p.windows * p.n;
   b.seg_len = msm_seg_len(entries, is_fp2<F>::value);
@@ -1154,6 +1161,17 @@ static void msm_accumulate_phase(ark355_ctx* ctx, const MsmSort& s, MsmBuckets& 
   ARK_CHECK_HIP(hipMemsetAsync(b.buckets.p, 0, (size_t)p.total_buckets * sizeof(XYZZ<F>), stream));
   ARK_CHECK_HIP(hipMemsetAsync(b.head_key.p, 0xFF, (size_t)segs * 4, stream));
   ARK_CHECK_HIP(hipMemsetAsync(b.tail_key.p, 0xFF, (size_t)segs * 4, stream));
+}
+
+template <class F>
+static void msm_accumulate_phase(ark355_ctx* ctx, const MsmSort& s, MsmBuckets& b, const Affine<F>* d_bases,
+                                 hipStream_t stream, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr,
+                                 bool bases28 = false) {
+  const MsmPlan& p = s.plan;
+  if (!b.prepared) msm_prepare_phase<F>(s, b, stream);      // stand-alone MSMs: same stream
+  b.prepared = false;
+  if (p.n == 0) return;
+  const uint32_t segs = b.segs;
   const uint32_t grid_s = (segs + MSM_THREADS - 1) / MSM_THREADS;
   if (ev0) ARK_CHECK_HIP(hipEventRecord(ev0, stream));
   // G2 (Fq2): inlining 30 Fq multiplications costs registers (256 VGPR + 256 AGPR, 1 wave/SIMD), the
@@ -1254,7 +1272,9 @@ static void msm_reduce_phase(ark355_ctx* ctx, const MsmSort& s, MsmBuckets& b, X
 #ifndef ARK_MSM_TWO_LEVEL_MIN
 #define ARK_MSM_TWO_LEVEL_MIN (1u << 17)        // bucket count from which the two-level reduction is used (tests: small)
 #endif
-  if (p.key_windows == 1 && p.total_buckets >= ARK_MSM_TWO_LEVEL_MIN) {
+  uint32_t two_level_min = ARK_MSM_TWO_LEVEL_MIN;
+  if (const char* e = getenv("ARK355_MSM_TWO_LEVEL_MIN")) two_level_min = (uint32_t)strtoul(e, nullptr, 10);   // A/B knob
+  if (p.key_windows == 1 && p.total_buckets >= two_level_min) {
     const uint32_t items = (p.total_buckets + MSM_RED_L1 - 1) / MSM_RED_L1;
     b.lvl_t.ensure((size_t)items * sizeof(XYZZ<F>));
     b.lvl_w.ensure((size_t)items * sizeof(XYZZ<F>));
