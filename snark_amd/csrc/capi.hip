@@ -126,7 +126,7 @@ void ark355_ctx_destroy(ark355_ctx* ctx) {
     }
   }
   delete ex;       // outside the lock: it destroys the batch worker contexts, which come back through here
-  for (auto& kv : ctx->ntt_tables) delete kv.second;
+  ctx->ntt_tables.clear();          // shared tables live on while another context of the device holds them
   (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }

@@ -7,6 +7,7 @@
 #include <cstring>
 #include <initializer_list>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -108,7 +109,7 @@ struct ark355_ctx {
   uint64_t acc_launches = 0;
   uint64_t acc_points = 0;
   // NTT twiddle tables keyed by (curve << 8 | log_n)
-  std::map<uint32_t, ark355::NttTables*> ntt_tables;
+  std::map<uint32_t, std::shared_ptr<ark355::NttTables>> ntt_tables;   // shared with the other contexts of the device
   // grow-only scratch buffers reused across calls (sized for 288 GB HBM: never shrunk)
   ark355::DevBuf scratch[12];
 };

@@ -48,6 +48,7 @@ struct NttTables {
   DevBuf n_inv;                        // 1/N
   DevBuf tw_r[2][10];                  // [inverse][r]: w_R^e, e < R/2   (in-tile butterflies)
   std::map<uint32_t, DevBuf> direct;   // (inverse << 16 | s_log << 8 | r) -> w^(s p k), index (p << r) | k
+  std::mutex mu;                       // the lazily built members (tw_r, direct, seam): contexts of one device share a set
 };
 
 template <class Fr>
@@ -436,19 +437,34 @@ static NttTables* build_ntt_tables(uint32_t log_n) {
   return t;
 }
 
+// Tables are read-only once built and identical for every context of a device: the proofs in flight (one context
+// each) share one set -- 200 MiB at N = 2^21 -- through a per-process registry of weak references; a context keeps the
+// sets it used alive.
 template <class Curve>
 static NttTables* get_ntt_tables(ark355_ctx* ctx, uint32_t log_n) {
   const uint32_t key = ((uint32_t)Curve::ID << 8) | log_n;
   auto it = ctx->ntt_tables.find(key);
-  if (it != ctx->ntt_tables.end()) return it->second;
-  NttTables* t = build_ntt_tables<typename Curve::Fr>(log_n);
+  if (it != ctx->ntt_tables.end()) return it->second.get();
+  static std::mutex reg_mu;
+  static std::map<uint64_t, std::weak_ptr<NttTables>> registry;
+  const uint64_t gkey = ((uint64_t)(uint32_t)ctx->device << 32) | key;
+  std::shared_ptr<NttTables> t;
+  {
+    std::lock_guard<std::mutex> lk(reg_mu);
+    t = registry[gkey].lock();
+    if (!t) {
+      t.reset(build_ntt_tables<typename Curve::Fr>(log_n));
+      registry[gkey] = t;
+    }
+  }
   ctx->ntt_tables[key] = t;
-  return t;
+  return t.get();
 }
 
 // w_R^e, e < R/2, R = 2^r (at least one entry so that the pointer is valid for r = 1: w^0)
 template <class Fr>
 static const Fr* ntt_tw_table(NttTables* t, uint32_t r, bool inverse) {
+  std::lock_guard<std::mutex> lk(t->mu);
   DevBuf& b = t->tw_r[inverse ? 1 : 0][r];
   if (!b.p) {
     const Fr wr = fr_pow2k(ntt_root<Fr>(t->log_n, inverse), t->log_n - r);
@@ -461,6 +477,7 @@ static const Fr* ntt_tw_table(NttTables* t, uint32_t r, bool inverse) {
 // g^j / N for j < N
 template <class Fr>
 static const Fr* ntt_seam_table(NttTables* t) {
+  std::lock_guard<std::mutex> lk(t->mu);
   if (!t->seam.p) {
     using P = typename Fr::Params;
     Fr n_inv;
@@ -477,6 +494,7 @@ static const Fr* ntt_direct_table(NttTables* t, uint32_t s_log, uint32_t r, bool
   uint32_t max_log = NTT_DIRECT_MAX_LOG;
   if (const char* e = getenv("ARK355_NTT_DIRECT_MAX")) max_log = (uint32_t)atoi(e);      // tests: force the fallback
   if (ent_log > max_log || ent_log == r) return nullptr;                  // too large / last pass (p == 0 only)
+  std::lock_guard<std::mutex> lk(t->mu);
   const uint32_t key = ((inverse ? 1u : 0u) << 16) | (s_log << 8) | r;
   auto it = t->direct.find(key);
   if (it == t->direct.end()) {
