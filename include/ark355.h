@@ -243,6 +243,25 @@ int32_t ark355_xyzz_sum(ark355_ctx* ctx, int32_t curve, int32_t group, const uin
 int32_t ark355_fixed_base_mul(ark355_ctx* ctx, int32_t curve, int32_t group, const uint8_t* base,
                               const uint8_t* scalars, uint64_t n, uint8_t* out_affine);
 
+/* ---- batch verification (SNARK::verify / verify_with_processed_vk, snark/src/lib.rs:59-80) ------
+ * Checks `count` proofs of ONE verifying key at once with the random-linear-combination test
+ *   prod_j e(rho_j A_j, B_j) = e((sum rho_j) alpha, beta) e(sum_i (sum_j rho_j x_ji) gamma_abc_i, gamma) e(sum rho_j C_j, delta):
+ * count + 3 Miller loops and ONE final exponentiation instead of 4 count pairings.  The two multi-scalar sums run on
+ * the device; the Miller loops and the final exponentiation on host threads.  public_inputs: count x (num_instance - 1)
+ * Fr (Montgomery; the leading One is implicit, as in SNARK::verify); rho: count x 32 B canonical, non-zero, drawn by
+ * the caller from its rng (soundness error ~ 1/|rho|); NULL is allowed for count == 1 (plain verification).
+ * *ok = 1 iff every proof verifies (with overwhelming probability over rho). */
+typedef struct {
+  uint64_t num_instance;        /* ell = gamma_abc_g1 length */
+  const uint8_t* alpha_g1;
+  const uint8_t* beta_g2;
+  const uint8_t* gamma_g2;
+  const uint8_t* delta_g2;
+  const uint8_t* gamma_abc_g1;  /* ell G1 */
+} ark355_vk_desc;
+int32_t ark355_verify_batch(ark355_ctx* ctx, int32_t curve, const ark355_vk_desc* vk, const ark355_proof_raw* proofs,
+                            const uint8_t* public_inputs, const uint8_t* rho, uint64_t count, int32_t* ok);
+
 /* The scalars of the Groth16 generator (circuit_specific_setup, snark/src/lib.rs:43-46; upstream
  * generate_parameters_with_qap) from the R1CS matrices in CSR and the five trapdoor elements tau, alpha, beta, gamma,
  * delta (5 x 32 B canonical): u_j(tau), v_j(tau), w_j(tau) (num_instance + num_witness each), l_j (num_witness),

@@ -60,6 +60,16 @@ pub struct ark355_pk_desc {
 }
 
 #[repr(C)]
+pub struct ark355_vk_desc {
+    pub num_instance: u64,
+    pub alpha_g1: *const u8,
+    pub beta_g2: *const u8,
+    pub gamma_g2: *const u8,
+    pub delta_g2: *const u8,
+    pub gamma_abc_g1: *const u8,
+}
+
+#[repr(C)]
 #[derive(Clone, Copy)]
 pub struct ark355_proof_raw {
     pub a: [u8; 96],
@@ -292,6 +302,17 @@ extern "C" {
         scalars: *const u8,
         n: u64,
         out_affine: *mut u8,
+    ) -> i32;
+
+    pub fn ark355_verify_batch(
+        ctx: *mut ark355_ctx,
+        curve: i32,
+        vk: *const ark355_vk_desc,
+        proofs: *const ark355_proof_raw,
+        public_inputs: *const u8,
+        rho: *const u8,
+        count: u64,
+        ok: *mut i32,
     ) -> i32;
 
     pub fn ark355_setup_scalars(

@@ -46,7 +46,7 @@ SYMBOLS = [
     "ark355_prove_combine", "ark355_prove_batch", "ark355_comm_unique_id", "ark355_comm_init", "ark355_comm_destroy",
     "ark355_prove_sharded", "ark355_prove_sharded_dev", "ark355_point_size", "ark355_pk_load_bytes", "ark355_pk_dims",
     "ark355_points_decode", "ark355_points_encode", "ark355_proof_to_bytes", "ark355_proof_from_bytes",
-    "ark355_setup_scalars",
+    "ark355_setup_scalars", "ark355_verify_batch",
 ]
 
 
@@ -64,6 +64,11 @@ class PkDesc(C.Structure):
         ("alpha_g1", C.c_void_p), ("beta_g1", C.c_void_p), ("delta_g1", C.c_void_p),
         ("beta_g2", C.c_void_p), ("delta_g2", C.c_void_p),
     ]
+
+
+class VkDesc(C.Structure):
+    _fields_ = [("num_instance", C.c_uint64), ("alpha_g1", C.c_void_p), ("beta_g2", C.c_void_p), ("gamma_g2", C.c_void_p),
+                ("delta_g2", C.c_void_p), ("gamma_abc_g1", C.c_void_p)]
 
 
 class ProofRaw(C.Structure):
@@ -155,6 +160,7 @@ class Lib:
         d.ark355_proof_to_bytes.argtypes = [i32, P(ProofRaw), i32, vp]
         d.ark355_proof_from_bytes.argtypes = [i32, vp, u64, i32, i32, P(ProofRaw)]
         d.ark355_setup_scalars.argtypes = [i32, u64, u64, u64, P(vp * 3), P(vp * 3), P(vp * 3), vp, vp, vp, vp, vp, vp, vp]
+        d.ark355_verify_batch.argtypes = [vp, i32, P(VkDesc), vp, vp, vp, u64, P(i32)]
         d.ark355_get_timings.argtypes = [vp, P(Timings)]
         d.ark355_get_kernel_stats.argtypes = [vp, P(C.c_float), P(u64), P(u64)]
         for name in SYMBOLS:
@@ -427,6 +433,29 @@ class Lib:
                                                        *[outs[k].ctypes.data_as(C.c_void_p) for k in ("u", "v", "w", "l", "gamma_abc", "h")]))
         cnts = {"u": m, "v": m, "w": m, "l": w, "gamma_abc": ell, "h": N - 1}
         return {k: outs[k][:cnts[k] * 32] for k in outs}
+
+    def verify_batch(self, ctx, curve, vk_parts, proofs, public_inputs: bytes, rho=None) -> bool:
+        """ark355_verify_batch.  vk_parts: (alpha_g1, beta_g2, gamma_g2, delta_g2, gamma_abc_g1) raw images; proofs: list of
+        (a, b, c) raw images; public_inputs: count x (ell - 1) Montgomery Fr; rho: list of canonical 32-byte values or None."""
+        alpha, beta2, gamma2, delta2, gabc = vk_parts
+        keep = []
+        d = VkDesc()
+        for name, val in (("alpha_g1", alpha), ("beta_g2", beta2), ("gamma_g2", gamma2), ("delta_g2", delta2), ("gamma_abc_g1", gabc)):
+            p, k = _buf(val)
+            keep.append(k)
+            setattr(d, name, p.value)
+        g1 = len(alpha)
+        d.num_instance = len(gabc) // g1
+        arr = (ProofRaw * len(proofs))()
+        for i, (a, b, c) in enumerate(proofs):
+            C.memmove(arr[i].a, a, len(a))
+            C.memmove(arr[i].b, b, len(b))
+            C.memmove(arr[i].c, c, len(c))
+        ib, k1 = _buf(public_inputs if len(public_inputs) else None)
+        rb, k2 = _buf(b"".join(rho) if rho else None)
+        ok = C.c_int32(0)
+        self.check(ctx, self.dll.ark355_verify_batch(ctx, curve, C.byref(d), arr, ib, rb, len(proofs), C.byref(ok)))
+        return bool(ok.value)
 
     def timings(self, ctx):
         t = Timings()

@@ -5,6 +5,7 @@
 #include "common.h"
 #include "groth16_impl.cuh"
 #include "wire_impl.cuh"
+#include "pairing_host.hpp"
 
 namespace ark355 {
 
@@ -390,6 +391,89 @@ struct Api {
         p = Fr::mul(p, tau);
       }
     });
+  }
+
+  // ---- batch verification (pairing_host.hpp) --------------------------------------------------------------------------
+  // sum_j rho_j [ e(A_j, B_j) = e(alpha, beta) e(acc_j, gamma) e(C_j, delta) ]  <=>
+  //   prod_j e(rho_j A_j, B_j) * e(-(sum rho_j) alpha, beta) * e(-sum_i (sum_j rho_j x_ji) gamma_abc_i, gamma)
+  //                            * e(-sum_j rho_j C_j, delta) = 1
+  // (k + 3 Miller loops and one final exponentiation for k proofs).  The two multi-scalar sums run on the device.
+  static bool verify_batch(ark355_ctx* ctx, GenericScratch& g, const ark355_vk_desc* vk, const ark355_proof_raw* proofs,
+                           const uint8_t* inputs, const uint8_t* rho, uint64_t count) {
+    using PH = PairingHost<Curve>;
+    const uint64_t ell = vk->num_instance;
+    ARK_REQUIRE(ell >= 1 && count >= 1, ARK355_EINVAL, "empty batch or key");
+    ARK_REQUIRE(rho || count == 1, ARK355_EINVAL, "a batch needs one random coefficient per proof");
+    auto g1_of = [](const uint8_t* p) {
+      Affine<Fq> a;
+      memcpy(&a, p, sizeof(a));
+      return a;
+    };
+    auto g2_of = [](const uint8_t* p) {
+      Affine<Fq2> a;
+      memcpy(&a, p, sizeof(a));
+      return a;
+    };
+    std::vector<Fr> r(count), coef(ell, Fr::zero());
+    for (uint64_t j = 0; j < count; j++) {
+      if (rho) {
+        Fr c;
+        memcpy(c.l, rho + 32 * j, sizeof(Fr));
+        r[j] = Fr::to_mont(c);
+        ARK_REQUIRE(!r[j].is_zero(), ARK355_EINVAL, "zero random coefficient");
+      } else {
+        r[j] = Fr::one();
+      }
+      coef[0] = Fr::add(coef[0], r[j]);
+      for (uint64_t i = 1; i < ell; i++) {
+        Fr x;
+        memcpy(x.l, inputs + ((size_t)j * (ell - 1) + (i - 1)) * sizeof(Fr), sizeof(Fr));
+        coef[i] = Fr::add(coef[i], Fr::mul(r[j], x));
+      }
+    }
+    // device MSMs over canonical scalars
+    std::vector<uint8_t> sc(std::max<uint64_t>(ell, count) * sizeof(Fr)), cpts(count * sizeof(Affine<Fq>));
+    Affine<Fq> acc, csum;
+    for (uint64_t i = 0; i < ell; i++) {
+      const Fr c = Fr::from_mont(coef[i]);
+      memcpy(sc.data() + i * sizeof(Fr), c.l, sizeof(Fr));
+    }
+    msm_host(ctx, g, 1, vk->gamma_abc_g1, sc.data(), ell, reinterpret_cast<uint8_t*>(&acc));
+    for (uint64_t j = 0; j < count; j++) {
+      const Fr c = Fr::from_mont(r[j]);
+      memcpy(sc.data() + j * sizeof(Fr), c.l, sizeof(Fr));
+      memcpy(cpts.data() + j * sizeof(Affine<Fq>), proofs[j].c, sizeof(Affine<Fq>));
+    }
+    msm_host(ctx, g, 1, cpts.data(), sc.data(), count, reinterpret_cast<uint8_t*>(&csum));
+    std::vector<Affine<Fq>> Ps(count + 3);
+    std::vector<Affine<Fq2>> Qs(count + 3);
+    unsigned nt = std::thread::hardware_concurrency();
+    if (nt == 0) nt = 4;
+    if (nt > 16) nt = 16;
+    {
+      // rho_j A_j on host threads (one 255-bit scalar multiplication each)
+      std::vector<std::thread> th;
+      const unsigned k = (unsigned)std::min<uint64_t>(nt, count);
+      for (unsigned t = 0; t < k; t++)
+        th.emplace_back([&, t] {
+          for (uint64_t j = t; j < count; j += k) {
+            const Affine<Fq> a = g1_of(proofs[j].a);
+            const Fr c = Fr::from_mont(r[j]);
+            Ps[j] = rho ? xyzz_to_affine(xyzz_mul_scalar(XYZZ<Fq>::from_affine(a), c.l, Fr::N)) : a;
+            Qs[j] = g2_of(proofs[j].b);
+          }
+        });
+      for (auto& x : th) x.join();
+    }
+    const Fr s0 = Fr::from_mont(coef[0]);
+    const Affine<Fq> alpha = g1_of(vk->alpha_g1);
+    Ps[count] = Affine<Fq>::neg(xyzz_to_affine(xyzz_mul_scalar(XYZZ<Fq>::from_affine(alpha), s0.l, Fr::N)));
+    Qs[count] = g2_of(vk->beta_g2);
+    Ps[count + 1] = acc.is_inf() ? acc : Affine<Fq>::neg(acc);
+    Qs[count + 1] = g2_of(vk->gamma_g2);
+    Ps[count + 2] = csum.is_inf() ? csum : Affine<Fq>::neg(csum);
+    Qs[count + 2] = g2_of(vk->delta_g2);
+    return PH::product_is_one(Ps, Qs, nt);
   }
 
   // ---- ark-serialize wire formats (wire_impl.cuh) ------------------------------------------------------------------

@@ -560,6 +560,20 @@ int32_t ark355_proof_from_bytes(int32_t curve, const uint8_t* in, uint64_t len, 
   return guarded(nullptr, [&] { CURVE_DISPATCH(curve, A::proof_from_bytes(in, len, compressed != 0, validate != 0, out)); });
 }
 
+int32_t ark355_verify_batch(ark355_ctx* ctx, int32_t curve, const ark355_vk_desc* vk, const ark355_proof_raw* proofs,
+                            const uint8_t* public_inputs, const uint8_t* rho, uint64_t count, int32_t* ok) {
+  if (!ctx || !vk || !proofs || !ok || !vk->alpha_g1 || !vk->beta_g2 || !vk->gamma_g2 || !vk->delta_g2 || !vk->gamma_abc_g1 ||
+      (vk->num_instance > 1 && !public_inputs))
+    return ARK355_EINVAL;
+  *ok = 0;
+  return guarded(ctx, [&] {
+    CtxExtra& ex = extra(ctx);
+    bool good = false;
+    CURVE_DISPATCH(curve, good = A::verify_batch(ctx, ex.generic, vk, proofs, public_inputs, rho, count));
+    *ok = good ? 1 : 0;
+  });
+}
+
 int32_t ark355_setup_scalars(int32_t curve, uint64_t n, uint64_t ell, uint64_t w, const uint64_t* const row_ptr[3],
                              const uint32_t* const col[3], const uint8_t* const coeff[3], const uint8_t* trapdoor,
                              uint8_t* out_u, uint8_t* out_v, uint8_t* out_w, uint8_t* out_l, uint8_t* out_gamma_abc,

@@ -226,3 +226,44 @@ def fixed_base_case(lib, ctx, C, group, n=70, seed=21):
     assert lib.fixed_base_mul(ctx, C.curve_id, group, base, sb, len(ks), psz) == cbase.fixed_base(C, group, base, sb, len(ks))
     assert lib.fixed_base_mul(ctx, C.curve_id, group, bytes(psz), sb, 9, psz) == bytes(9 * psz)
     assert lib.fixed_base_mul(ctx, C.curve_id, group, base, b"", 0, psz) == b""
+
+
+def verify_batch_case(lib, ctx, C, count=2, n=9, seed=31):
+    """ark355_verify_batch (random linear combination: count + 3 Miller loops, one final exponentiation; multi-scalar
+    sums on the device) against the oracle's pairing check: valid batches accept, a tampered proof, a wrong public input
+    or a proof bound to another statement make the batch fail; single-proof verification (rho = NULL) agrees with
+    oracle.groth16.verify."""
+    rnd = random.Random(seed)
+    td = G.Trapdoor(tau=rnd.randrange(2, C.r), alpha=3, beta=5, gamma=7, delta=11)
+    A, B, Cm, z0, ell = S.mulchain_direct(C.r, n, seed=seed)
+    pk = G.setup(C, A, B, Cm, ell, len(z0), td)
+    vk = (Z.g1_raw(C, pk.vk.alpha_g1), Z.g2_raw(C, pk.vk.beta_g2), Z.g2_raw(C, pk.vk.gamma_g2), Z.g2_raw(C, pk.vk.delta_g2),
+          g1_vec_raw(C, pk.vk.gamma_abc_g1))
+    proofs, inputs, oproofs, zs = [], [], [], []
+    for j in range(count):
+        _, _, _, z, _ = S.mulchain_direct(C.r, n, seed=seed + 1 + j)        # same circuit, different statement
+        p = G.prove_closed_form(C, pk, z, ell, rnd.randrange(C.r), rnd.randrange(C.r))
+        if j == 0:
+            assert G.verify(C, pk.vk, z[1:ell], p)          # the oracle's own pairing check (slow: once)
+        oproofs.append(p)
+        zs.append(z)
+        proofs.append((Z.g1_raw(C, p.a), Z.g2_raw(C, p.b), Z.g1_raw(C, p.c)))
+        inputs.append(z_bytes(C, z[1:ell]))
+    rho = [Z.fr_canon(C, rnd.randrange(1, 1 << 128)) for _ in range(count)]
+    assert lib.verify_batch(ctx, C.curve_id, vk, proofs, b"".join(inputs), rho)
+    for j in range(count):
+        assert lib.verify_batch(ctx, C.curve_id, vk, [proofs[j]], inputs[j])          # plain verification
+    # a proof bound to another statement
+    assert not lib.verify_batch(ctx, C.curve_id, vk, [proofs[0]], inputs[1])
+    assert not G.verify(C, pk.vk, zs[1][1:ell], oproofs[0])
+    # tampered C in the middle of a batch
+    bad = list(proofs)
+    bad[1] = (proofs[1][0], proofs[1][1], proofs[0][2])
+    assert not lib.verify_batch(ctx, C.curve_id, vk, bad, b"".join(inputs), rho)
+    # wrong public input
+    wrong = list(inputs)
+    wrong[-1] = z_bytes(C, [(zs[-1][1] + 1) % C.r])
+    assert not lib.verify_batch(ctx, C.curve_id, vk, proofs, b"".join(wrong), rho)
+    # A at infinity is not a valid proof
+    inf = [(bytes(len(proofs[0][0])), proofs[0][1], proofs[0][2])]
+    assert not lib.verify_batch(ctx, C.curve_id, vk, inf, inputs[0])

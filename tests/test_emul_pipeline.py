@@ -200,3 +200,8 @@ def test_ntt_without_direct_twiddle_tables(emul_lib, emul_ctx, monkeypatch):
 @pytest.mark.parametrize("group", [1, 2])
 def test_fixed_base_mul_vs_oracle(emul_lib, emul_ctx, C, group):
     pc.fixed_base_case(emul_lib, emul_ctx, C, group)
+
+
+@pytest.mark.parametrize("C", [BLS12_381, BN254], ids=lambda c: c.name)
+def test_batch_verification_vs_oracle_pairing(emul_lib, emul_ctx, C):
+    pc.verify_batch_case(emul_lib, emul_ctx, C)

@@ -212,3 +212,8 @@ def test_sharded_prove_over_rccl():
 @pytest.mark.parametrize("group", [1, 2])
 def test_fixed_base_mul_vs_oracle(gpu_lib, gpu_ctx, C, group):
     pc.fixed_base_case(gpu_lib, gpu_ctx, C, group, n=4000)
+
+
+@pytest.mark.parametrize("C", [BLS12_381, BN254], ids=lambda c: c.name)
+def test_batch_verification_vs_oracle_pairing(gpu_lib, gpu_ctx, C):
+    pc.verify_batch_case(gpu_lib, gpu_ctx, C, count=6)
