@@ -128,6 +128,69 @@ where
         }
     }
 
+    /// Batch verification (`ark355_verify_batch`): every proof of ONE verifying key checked with a random linear
+    /// combination -- `proofs.len() + 3` Miller loops and one final exponentiation.  `public_inputs[j]` excludes the
+    /// leading One, as in `SNARK::verify`.
+    pub fn verify_batch<R: RngCore + CryptoRng>(
+        vk: &VerifyingKey<E>,
+        public_inputs: &[Vec<E::ScalarField>],
+        proofs: &[Proof<E>],
+        rng: &mut R,
+    ) -> Result<bool, Mi355xError> {
+        let ell = vk.gamma_abc_g1.len();
+        if proofs.is_empty() {
+            return Ok(true);
+        }
+        if public_inputs.len() != proofs.len() || public_inputs.iter().any(|x| x.len() + 1 != ell) {
+            return Ok(false);
+        }
+        let one = |p: &Affine<P1>| marshal::flatten_points(core::slice::from_ref(p));
+        let one2 = |p: &Affine<P2>| marshal::flatten_points(core::slice::from_ref(p));
+        let (alpha, beta, gamma, delta) = (one(&vk.alpha_g1), one2(&vk.beta_g2), one2(&vk.gamma_g2), one2(&vk.delta_g2));
+        let gabc = marshal::flatten_points(&vk.gamma_abc_g1);
+        let desc = ffi::ark355_vk_desc {
+            num_instance: ell as u64,
+            alpha_g1: alpha.as_ptr(),
+            beta_g2: beta.as_ptr(),
+            gamma_g2: gamma.as_ptr(),
+            delta_g2: delta.as_ptr(),
+            gamma_abc_g1: gabc.as_ptr(),
+        };
+        let mut raw = Vec::with_capacity(proofs.len());
+        for p in proofs {
+            let mut r = ffi::ark355_proof_raw { a: [0; 96], b: [0; 192], c: [0; 96] };
+            let (a, b, c) = (one(&p.a), one2(&p.b), one(&p.c));
+            r.a[..a.len()].copy_from_slice(&a);
+            r.b[..b.len()].copy_from_slice(&b);
+            r.c[..c.len()].copy_from_slice(&c);
+            raw.push(r);
+        }
+        let xs: Vec<E::ScalarField> = public_inputs.iter().flatten().copied().collect();
+        let mut rho = Vec::with_capacity(32 * proofs.len());
+        for _ in proofs {
+            let mut k = [0u8; 32];
+            rng.fill_bytes(&mut k[..16]); // 128-bit coefficients
+            k[0] |= 1; // non-zero
+            rho.extend_from_slice(&k);
+        }
+        let mut ok = 0i32;
+        cache::with_ctx(|ctx| {
+            cache::check(ctx, unsafe {
+                ffi::ark355_verify_batch(
+                    ctx,
+                    E::CURVE_ID,
+                    &desc,
+                    raw.as_ptr(),
+                    marshal::scalars_image(&xs).as_ptr(),
+                    if proofs.len() > 1 { rho.as_ptr() } else { core::ptr::null() },
+                    proofs.len() as u64,
+                    &mut ok,
+                )
+            })
+        })?;
+        Ok(ok == 1)
+    }
+
     /// Assignments already synthesised (each `instance || witness`): up to `inflight` proofs share the GPU.
     pub fn prove_assignments<R: RngCore + CryptoRng>(
         res: &cache::Resident,

@@ -7,8 +7,9 @@ Mirrors ``ark_snark::SNARK`` (/root/reference/snark/src/lib.rs:22-81) for one im
   (u_i(tau), v_i(tau), w_i(tau), ...; SURVEY.md Appendix A "Setup"), the device performs the
   fixed-base multiplications (``ark355_fixed_base_mul``);
 * ``prove``                   (lib.rs:50-54)           -> ``ark355_prove`` (the hot path);
-* ``verify`` / ``process_vk`` (lib.rs:59-80)           -> not part of the accelerated path; the
-  arkworks host keeps its own CPU verifier (the proofs are byte-compatible).  Raises here.
+* ``verify`` / ``process_vk`` (lib.rs:59-80)           -> ``ark355_verify_batch`` (random linear combination on
+  the device MSM, Miller loops and the final exponentiation on host threads); proofs stay byte-compatible
+  with the arkworks CPU verifier.
 
 Inputs come from the unchanged ``ark-relations`` constraint system on the host:
 ``R1CS.from_rows`` takes exactly what ``ConstraintSystem::to_matrices()["R1CS"]`` returns
@@ -305,9 +306,36 @@ class Groth16:
         s1 = self.sizes["g1"]
         return Proof(g1[:s1], g2, g1[s1:])
 
-    # ---- not on the accelerated path ---------------------------------------------------------------------------------
-    def verify(self, *a, **k):
-        raise NotImplementedError("SNARK::verify stays on the arkworks host (CPU); proofs are byte-compatible")
+    # ---- SNARK::verify (snark/src/lib.rs:59-80) -----------------------------------------------------------------------
+    def verify(self, vk: VerifyingKey, public_inputs: Sequence[int], proof: Proof) -> bool:
+        """`public_inputs` excludes the leading One, as in `SNARK::verify`.  One proof = a batch of one."""
+        return self.verify_batch(vk, [public_inputs], [proof])
 
-    process_vk = verify
+    def process_vk(self, vk: VerifyingKey) -> VerifyingKey:
+        """Nothing is precomputed on the host side of this backend: the processed key is the key (lib.rs:70-73)."""
+        return vk
+
     verify_with_processed_vk = verify
+
+    def verify_batch(self, vk: VerifyingKey, public_inputs, proofs, rng=None) -> bool:
+        """`ark355_verify_batch`: all proofs of ONE verifying key checked with a random linear combination (count + 3
+        Miller loops, one final exponentiation).  `rng` yields the 128-bit coefficients; required for more than one proof."""
+        cv = self.curve
+        count = len(proofs)
+        if count == 0:
+            return True
+        ell = len(vk.gamma_abc_g1) // self.sizes["g1"]
+        if any(len(x) + 1 != ell for x in public_inputs) or len(public_inputs) != count:
+            return False                          # upstream: MalformedVerifyingKey / wrong input length -> not accepted
+        rho = None
+        if count > 1:
+            if rng is None:
+                raise ValueError("batch verification needs an rng for the random coefficients")
+            rho = [cv.fr_canon((rng() % ((1 << 128) - 1)) + 1) for _ in range(count)]
+        xs = b"".join(cv.fr_mont(v) for row in public_inputs for v in row)
+        try:
+            return self.lib.verify_batch(self.ctx, cv.curve_id,
+                                         (vk.alpha_g1, vk.beta_g2, vk.gamma_g2, vk.delta_g2, vk.gamma_abc_g1),
+                                         [(p.a, p.b, p.c) for p in proofs], xs, rho)
+        except Ark355Error as e:
+            raise SynthesisError(str(e)) from e

@@ -3,8 +3,9 @@
 //
 //   SNARK::circuit_specific_setup(circuit, rng) -> (ProvingKey, VerifyingKey)     lib.rs:43-46, :87-92
 //   SNARK::prove(&pk, circuit, rng) -> Proof                                       lib.rs:50-54
-//   SNARK::verify / process_vk / verify_with_processed_vk                          lib.rs:59-80: NOT on the
-//       accelerated path -- the arkworks host keeps its CPU verifier (proofs are byte-compatible).
+//   SNARK::verify / verify_with_processed_vk (+ verify_batch)                      lib.rs:59-80: ark355_verify_batch
+//       (random linear combination on the device MSM, Miller loops + final exponentiation on host threads);
+//       proofs stay byte-compatible with the arkworks CPU verifier.
 //
 // `prove` follows the un-vendored ark-groth16 `create_random_proof_with_reduction`: new constraint system,
 // OptimizationGoal::Constraints, generate_constraints, finalize, matrices + assignment, then r and s drawn
@@ -526,9 +527,45 @@ class Groth16 {
     pk.resident = res;
   }
 
-  // SNARK::verify family: outside the accelerated path
-  bool verify(const VerifyingKey&, const std::vector<Fr>&, const Proof&) const {
-    throw std::logic_error("SNARK::verify stays on the arkworks host (CPU); proofs are byte-compatible");
+  // ---- SNARK::verify (lib.rs:59-80) and batch verification over the C ABI (ark355_verify_batch) ------------------------
+  bool verify(const VerifyingKey& vk, const std::vector<Fr>& public_inputs, const Proof& proof) const {
+    return verify_batch(vk, {public_inputs}, {proof}, Rng());
+  }
+  // every proof of ONE verifying key with a random linear combination; rng yields the coefficients (count > 1)
+  bool verify_batch(const VerifyingKey& vk, const std::vector<std::vector<Fr>>& public_inputs,
+                    const std::vector<Proof>& proofs, const Rng& rng) const {
+    const size_t count = proofs.size(), ell = vk.gamma_abc_g1.size() / G1;
+    if (count == 0) return true;
+    if (public_inputs.size() != count) return false;
+    for (const auto& x : public_inputs)
+      if (x.size() + 1 != ell) return false;
+    ark355_vk_desc d;
+    d.num_instance = ell;
+    d.alpha_g1 = vk.alpha_g1.data();
+    d.beta_g2 = vk.beta_g2.data();
+    d.gamma_g2 = vk.gamma_g2.data();
+    d.delta_g2 = vk.delta_g2.data();
+    d.gamma_abc_g1 = vk.gamma_abc_g1.data();
+    std::vector<ark355_proof_raw> raw(count);
+    std::vector<Fr> xs;
+    std::vector<uint8_t> rho(32 * count, 0);
+    for (size_t j = 0; j < count; j++) {
+      memset(&raw[j], 0, sizeof(raw[j]));
+      memcpy(raw[j].a, proofs[j].a.data(), G1);
+      memcpy(raw[j].b, proofs[j].b.data(), G2);
+      memcpy(raw[j].c, proofs[j].c.data(), G1);
+      xs.insert(xs.end(), public_inputs[j].begin(), public_inputs[j].end());
+      if (count > 1) {
+        uint8_t k[32];
+        rng().to_canonical_bytes(k);
+        memcpy(&rho[32 * j], k, 16);             // 128-bit coefficients
+        rho[32 * j] |= 1;
+      }
+    }
+    int32_t ok = 0;
+    be_->check(ark355_verify_batch(be_->ctx(), C::ID, &d, raw.data(), reinterpret_cast<const uint8_t*>(xs.data()),
+                                   count > 1 ? rho.data() : nullptr, count, &ok));
+    return ok == 1;
   }
 
   static std::vector<uint8_t> g1_generator() {

@@ -426,6 +426,27 @@ static int run_prove(const std::string& circuit, size_t n) {
     return 3;
   }
   printf("batch_ok 1\n");
+  // SNARK::verify through the same ABI: the proofs of this run verify, a proof against the wrong input does not
+  {
+    typename G::CSRef cs = G::CSRef::new_ref();
+    circ->generate_constraints(cs);
+    cs.finalize();
+    const auto& inner = cs.borrow();
+    std::vector<F> x(inner.instance_assignment.begin() + 1, inner.instance_assignment.end());
+    std::vector<F> wrong = x;
+    if (!wrong.empty()) wrong[0] = wrong[0] + F::one();
+    uint64_t seq4[] = {0x5151, 0x6262, 0x7373};
+    size_t p4 = 0;
+    typename G::Rng rng4 = [&]() { return F::from_u64(seq4[p4++ % 3]); };
+    const bool v1 = groth.verify(keys.second, x, proof);
+    const bool v2 = groth.verify_batch(keys.second, {x, x, x}, {proof, proof2, batch[1]}, rng4);
+    const bool v3 = wrong.empty() ? false : groth.verify(keys.second, wrong, proof);
+    if (!v1 || !v2 || v3) {
+      fprintf(stderr, "verify: single %d batch %d wrong-input %d\n", (int)v1, (int)v2, (int)v3);
+      return 4;
+    }
+    printf("verify_ok 1\n");
+  }
   return 0;
 }
 

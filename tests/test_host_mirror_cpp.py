@@ -68,6 +68,7 @@ def test_cpp_snark_trait_prove_matches_oracle(exe, curve_name, circuit, n):
     r = subprocess.run([exe, "--prove", curve_name, circuit, str(n)], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     assert "batch_ok 1" in r.stdout          # Groth16::prove_batch (ark355_prove_batch) agreed with single proofs
+    assert "verify_ok 1" in r.stdout         # Groth16::verify / verify_batch (ark355_verify_batch) on those proofs
     got = _parse(r.stdout)
     if circuit == "example":            # relations/examples/satisfiable.rs, BASELINE configs[0]
         from oracle import r1cs as R
