@@ -99,7 +99,9 @@ void ark355_r1cs_free(ark355_r1cs* r1cs);
 /* domain size N the library will use for this instance */
 uint64_t ark355_r1cs_domain_size(const ark355_r1cs* r1cs);
 
-/* ---- proof (SNARK::Proof, snark/src/lib.rs:32): affine A (G1), B (G2), C (G1), Montgomery raw */
+/* ---- proof (SNARK::Proof, snark/src/lib.rs:32): affine A (G1), B (G2), C (G1), Montgomery raw.
+ *      The arrays are sized for BLS12-381 (96 / 192 B); BN254 points (64 / 128 B) occupy the leading bytes of each
+ *      array and the rest is zero -- ark355_sizes() gives the sizes in use. */
 typedef struct {
   uint8_t a[96];
   uint8_t b[192];
