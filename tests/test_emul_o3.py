@@ -10,10 +10,10 @@ from oracle.fields import BLS12_381, BN254
 
 @pytest.mark.parametrize("C", [BLS12_381, BN254], ids=lambda c: c.name)
 def test_instances_vs_o3_on_the_emulator(emul_lib, emul_ctx, C):
-    O.check_instance(emul_lib, emul_ctx, C, S.mulchain_csr(C.r, 70), [(5, 7)], batch=2 if C is BLS12_381 else 0, inflight=1)
+    O.check_instance(emul_lib, emul_ctx, C, S.mulchain_csr(C.r, 40), [(5, 7)], batch=2 if C is BLS12_381 else 0, inflight=1)
     if C is BLS12_381:
         O.check_instance(emul_lib, emul_ctx, C, S.dummy_csr(C.r, 64), [(0, 1)])
-    O.check_instance(emul_lib, emul_ctx, C, S.bench_lc_csr(C.r, 40), [(C.r - 1, C.r - 1)])
+    O.check_instance(emul_lib, emul_ctx, C, S.bench_lc_csr(C.r, 24), [(C.r - 1, C.r - 1)])
 
 
 @pytest.mark.parametrize("group", [1, 2])
