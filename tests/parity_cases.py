@@ -255,7 +255,7 @@ def verify_batch_case(lib, ctx, C, count=2, n=9, seed=31, oracle_pairing=True, l
         assert lib.verify_batch(ctx, C.curve_id, vk, [proofs[j]], inputs[j])          # plain verification
     # a proof bound to another statement
     assert not lib.verify_batch(ctx, C.curve_id, vk, [proofs[0]], inputs[1])
-    if oracle_pairing:
+    if oracle_pairing and not light:
         assert not G.verify(C, pk.vk, zs[1][1:ell], oproofs[0])
     # tampered C in the middle of a batch
     bad = list(proofs)
