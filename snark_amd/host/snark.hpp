@@ -107,7 +107,11 @@ class Backend {
     int rc = ark355_ctx_create(device, &ctx_);
     if (rc != ARK355_OK) throw BackendError(rc, "ark355_ctx_create failed (no GPU? the backend has no CPU fallback)");
   }
-  ~Backend() { ark355_ctx_destroy(ctx_); }
+  ~Backend() {
+    for (ark355_ctx* c : workers_) ark355_ctx_destroy(c);
+    for (auto& b : pinned_) ark355_host_free(b.first);
+    ark355_ctx_destroy(ctx_);
+  }
   Backend(const Backend&) = delete;
   ark355_ctx* ctx() const { return ctx_; }
   int device() const { return device_; }
@@ -119,9 +123,44 @@ class Backend {
     throw BackendError(rc, ark355_last_error(ctx_));
   }
 
+  // Worker context k (k = 0, 1, ...) of the pipelined prover: same device, own streams and scratch.  Created on first
+  // use and kept for the backend's lifetime -- a context's scratch (bucket sets, NTT ping-pong buffers, events) is
+  // gigabytes of hipMalloc, far too slow to repeat per call.  nullptr when the device refuses another context.
+  ark355_ctx* worker(size_t k) const {
+    std::lock_guard<std::mutex> lk(mu_);
+    while (workers_.size() <= k) {
+      ark355_ctx* c = nullptr;
+      if (ark355_ctx_create(device_, &c) != ARK355_OK) return nullptr;
+      workers_.push_back(c);
+    }
+    return workers_[k];
+  }
+  // Page-locked host buffers (ark355_host_alloc), recycled across calls: pinning 32 MB costs milliseconds.
+  std::pair<void*, size_t> take_pinned(size_t bytes) const {
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      for (size_t k = 0; k < pinned_.size(); k++)
+        if (pinned_[k].second >= bytes) {
+          auto b = pinned_[k];
+          pinned_.erase(pinned_.begin() + k);
+          return b;
+        }
+    }
+    void* raw = nullptr;
+    if (ark355_host_alloc(bytes, &raw) != ARK355_OK) throw std::bad_alloc();
+    return {raw, bytes};
+  }
+  void give_pinned(std::pair<void*, size_t> b) const {
+    std::lock_guard<std::mutex> lk(mu_);
+    pinned_.push_back(b);
+  }
+
  private:
   ark355_ctx* ctx_ = nullptr;
   int device_ = 0;
+  mutable std::mutex mu_;
+  mutable std::vector<ark355_ctx*> workers_;
+  mutable std::vector<std::pair<void*, size_t>> pinned_;
 };
 
 template <class C>
@@ -330,6 +369,35 @@ class Groth16 {
     return out;
   }
 
+  // Proofs for assignments that are already synthesised (z_i = instance || witness, Montgomery images, z_len
+  // elements each; page-locked buffers copy at PCIe rate): ark355_prove_batch over the resident key.
+  std::vector<Proof> prove_assignments(ProvingKey& pk, const std::vector<const Fr*>& z, uint64_t z_len,
+                                       const std::vector<std::pair<Fr, Fr>>& randomisers, uint32_t inflight = 3,
+                                       double* device_seconds = nullptr) const {
+    if (!(pk.resident && pk.resident->r1cs)) throw std::logic_error("prove_assignments needs a resident key (prove once first)");
+    if (randomisers.size() < z.size()) throw std::logic_error("one (r, s) pair per proof");
+    if (z.empty()) return {};
+    std::vector<uint8_t> rc(32 * z.size(), 0), sc(32 * z.size(), 0);
+    std::vector<const uint8_t*> zp;
+    for (size_t i = 0; i < z.size(); i++) {
+      randomisers[i].first.to_canonical_bytes(&rc[32 * i]);
+      randomisers[i].second.to_canonical_bytes(&sc[32 * i]);
+      zp.push_back(reinterpret_cast<const uint8_t*>(z[i]));
+    }
+    std::vector<ark355_proof_raw> raw(z.size());
+    const auto t_dev = std::chrono::steady_clock::now();
+    be_->check(ark355_prove_batch(be_->ctx(), pk.resident->pk, pk.resident->r1cs, zp.data(), z_len, rc.data(), sc.data(),
+                                  z.size(), inflight, raw.data()));
+    if (device_seconds) *device_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_dev).count();
+    std::vector<Proof> out(z.size());
+    for (size_t i = 0; i < z.size(); i++) {
+      out[i].a.assign(raw[i].a, raw[i].a + G1);
+      out[i].b.assign(raw[i].b, raw[i].b + G2);
+      out[i].c.assign(raw[i].c, raw[i].c + G1);
+    }
+    return out;
+  }
+
   // End-to-end SNARK::prove for MANY instances of one circuit, synthesis included and overlapped with the GPU:
   // the reference's parallel unit is one OS thread per proof because ConstraintSystemRef is Rc<RefCell<..>>
   // (relations/src/gr1cs/constraint_system_ref.rs:33), so `synth_threads` host threads each run
@@ -359,39 +427,21 @@ class Groth16 {
     }
     if (synth_threads < 1) synth_threads = 1;
     if (inflight < 1) inflight = 1;
-    // assignments travel in page-locked buffers (ark355_host_alloc): the H2D copy inside ark355_prove then runs at
-    // PCIe rate instead of being staged through the runtime's bounce buffers
+    // assignments travel in page-locked buffers (ark355_host_alloc, recycled by the backend): the H2D copy inside
+    // ark355_prove then runs at PCIe rate instead of being staged through the runtime's bounce buffers
     struct Pinned {
       Fr* p = nullptr;
-      size_t n = 0;
+      size_t n = 0, cap = 0;        // elements in use / bytes owned
     };
     struct Item {
       size_t index;
       Pinned z;
     };
-    std::vector<Pinned> pool;
-    std::mutex pool_mu;
     auto take_buf = [&](size_t n) {
-      {
-        std::lock_guard<std::mutex> lk(pool_mu);
-        for (size_t k = 0; k < pool.size(); k++)
-          if (pool[k].n >= n) {
-            Pinned b = pool[k];
-            pool.erase(pool.begin() + k);
-            return b;
-          }
-      }
-      Pinned b;
-      void* raw = nullptr;
-      if (ark355_host_alloc(n * sizeof(Fr), &raw) != ARK355_OK) throw std::bad_alloc();
-      b.p = static_cast<Fr*>(raw);
-      b.n = n;
-      return b;
+      auto b = be_->take_pinned(n * sizeof(Fr));
+      return Pinned{static_cast<Fr*>(b.first), n, b.second};
     };
-    auto give_buf = [&](Pinned b) {
-      std::lock_guard<std::mutex> lk(pool_mu);
-      pool.push_back(b);
-    };
+    auto give_buf = [&](Pinned b) { be_->give_pinned({b.p, b.cap}); };
     std::deque<Item> queue;
     std::mutex mu;
     std::condition_variable cv_not_empty, cv_not_full;
@@ -474,11 +524,11 @@ class Groth16 {
         fail(std::current_exception());
       }
     };
-    // prover contexts: the backend's own plus inflight - 1 more on the same device
+    // prover contexts: the backend's own plus inflight - 1 of its persistent workers
     std::vector<ark355_ctx*> extra_ctx;
     for (uint32_t k = 1; k < inflight; k++) {
-      ark355_ctx* c = nullptr;
-      if (ark355_ctx_create(be_->device(), &c) != ARK355_OK) break;
+      ark355_ctx* c = be_->worker(k - 1);
+      if (!c) break;
       extra_ctx.push_back(c);
     }
     const auto t_start = now();
@@ -488,9 +538,7 @@ class Groth16 {
     consumer(be_->ctx());
     for (auto& t : th) t.join();
     const double wall = std::chrono::duration<double>(now() - t_start).count();
-    for (ark355_ctx* c : extra_ctx) ark355_ctx_destroy(c);
-    for (auto& it : queue) pool.push_back(it.z);
-    for (auto& b : pool) ark355_host_free(b.p);
+    for (auto& it : queue) give_buf(it.z);
     if (first_error) std::rethrow_exception(first_error);
     if (stats) {
       stats->wall_s = wall;
