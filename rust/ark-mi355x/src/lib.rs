@@ -8,6 +8,7 @@ mod cache;
 mod error;
 pub mod ffi;
 mod marshal;
+mod pool;
 
 use core::marker::PhantomData;
 
@@ -21,9 +22,10 @@ use ark_relations::gr1cs::{
 use ark_snark::{CircuitSpecificSetupSNARK, SNARK};
 use ark_std::rand::{CryptoRng, RngCore};
 
-pub use cache::{evict, set_device};
+pub use cache::{evict, lookup, set_device, Resident};
 pub use error::Mi355xError;
 pub use marshal::{layout_self_test, Mi355xCurve};
+pub use pool::{PinnedAssignment, ProverPool, Ticket};
 
 /// Drop-in sibling of `ark_groth16::Groth16<E>`.
 pub struct Mi355xGroth16<E>(PhantomData<E>);
