@@ -64,6 +64,7 @@ fixed_base_mul_kernel(const Affine<F>* __restrict__ table, const Fr* __restrict_
 struct GenericScratch {
   MsmSort sort;
   MsmBuckets bk;
+  BaScratch ba;
   DevBuf a, b, c;
 };
 
@@ -164,8 +165,13 @@ struct Api {
     ARK_CHECK_HIP(hipEventCreate(&e1));
     try {
       msm_sort<Fr>(ctx, g.sort, d_scalars, n, mont, st, tab);
-      msm_buckets<F>(ctx, g.sort, g.bk, d_bases, d_res, 0, st, n ? e0 : nullptr, n ? e1 : nullptr,
-                     tab != nullptr && tab->limb28);
+      if (tab != nullptr && tab->batch_affine) {
+        const MsmSort& tail = msm_ba_accumulate_phase<F>(ctx, g.sort, g.bk, g.ba, d_bases, st, n ? e0 : nullptr, n ? e1 : nullptr);
+        msm_reduce_phase<F>(ctx, tail, g.bk, d_res, 0, st);
+      } else {
+        msm_buckets<F>(ctx, g.sort, g.bk, d_bases, d_res, 0, st, n ? e0 : nullptr, n ? e1 : nullptr,
+                       tab != nullptr && tab->limb28);
+      }
       if (want_affine) {
         ARK_LAUNCH((xyzz_to_affine_kernel<F>), dim3(1), dim3(64), 0, st, (const XYZZ<F>*)d_res, d_aff, 1u);
         ARK_CHECK_LAUNCH();

@@ -52,6 +52,7 @@ struct ProverScratch {
   // a proof are in flight together on separate streams (sized for 288 GB of HBM, not for reuse)
   MsmSort sortZ, sortH;
   MsmBuckets bkA, bkB1, bkB2, bkL, bkH;
+  BaScratch baA, baB1, baB2, baL, baH;      // batch-affine tree levels (msm_ba_impl.cuh), used when a table asks for them
   hipStream_t sW = nullptr, sS = nullptr, sA = nullptr, sR = nullptr;
   // events of one proof, created once per context (prove_run used to create and destroy 23 of them per proof)
   static constexpr int N_EVENTS = 32;
@@ -327,15 +328,16 @@ static void prove_run(ark355_ctx* ctx, ProverScratch& sc, const PkDev& pk, const
     ARK_CHECK_HIP(hipStreamWaitEvent(sS, ev[E_Z], 0));
     msm_sort<Fr>(ctx, sc.sortZ, (const uint8_t*)sc.zx.p + pk.z_lo * sizeof(Fr), pk.z_cnt, 1, sS, &pk.a_ext);
     // bucket sets are sized and cleared here, behind the sort they belong to (msm_prepare_phase)
-    msm_prepare_phase<Fq2>(sc.sortZ, sc.bkB2, sS);
-    msm_prepare_phase<Fq>(sc.sortZ, sc.bkA, sS);
-    msm_prepare_phase<Fq>(sc.sortZ, sc.bkB1, sS);
-    msm_prepare_phase<Fq>(sc.sortZ, sc.bkL, sS);
+    // (a batch-affine MSM sizes its bucket set later, for the nodes its tree levels leave over)
+    if (!pk.b2_ext.batch_affine) msm_prepare_phase<Fq2>(sc.sortZ, sc.bkB2, sS);
+    if (!pk.a_ext.batch_affine) msm_prepare_phase<Fq>(sc.sortZ, sc.bkA, sS);
+    if (!pk.b1_ext.batch_affine) msm_prepare_phase<Fq>(sc.sortZ, sc.bkB1, sS);
+    if (!pk.l_ext.batch_affine) msm_prepare_phase<Fq>(sc.sortZ, sc.bkL, sS);
     ARK_CHECK_HIP(hipEventRecord(ev[E_SORT0], sS));
     ARK_CHECK_HIP(hipEventRecord(ev[E_SORT1], sS));     // (L' shares the sort of zx)
     ARK_CHECK_HIP(hipStreamWaitEvent(sS, ev[E_H], 0));
     msm_sort<Fr>(ctx, sc.sortH, (const uint8_t*)d_h + pk.h_lo * sizeof(Fr), pk.h_cnt, 1, sS, &pk.h_query);
-    msm_prepare_phase<Fq>(sc.sortH, sc.bkH, sS);
+    if (!pk.h_query.batch_affine) msm_prepare_phase<Fq>(sc.sortH, sc.bkH, sS);
     ARK_CHECK_HIP(hipEventRecord(ev[E_SORT2], sS));
 
     // accumulations (A, B1, B2 share the sort of zx) and, per MSM, its reduction on sR
@@ -346,20 +348,29 @@ static void prove_run(ark355_ctx* ctx, ProverScratch& sc, const PkDev& pk, const
       bool g2;
       const PrecompTable* tab;
       int res;
+      BaScratch* ba;
     } jobs[5] = {
         // G2 first: its bucket reduction is the longest latency-bound tail (~4-6 ms on a few workgroups) and
         // hides under the four G1 accumulations that follow
-        {E_SORT0, &sc.sortZ, &sc.bkB2, true, &pk.b2_ext, 0},
-        {E_SORT0, &sc.sortZ, &sc.bkA, false, &pk.a_ext, 0},
-        {E_SORT0, &sc.sortZ, &sc.bkB1, false, &pk.b1_ext, 1},
-        {E_SORT0, &sc.sortZ, &sc.bkL, false, &pk.l_ext, 2},
-        {E_SORT2, &sc.sortH, &sc.bkH, false, &pk.h_query, 3},
+        {E_SORT0, &sc.sortZ, &sc.bkB2, true, &pk.b2_ext, 0, &sc.baB2},
+        {E_SORT0, &sc.sortZ, &sc.bkA, false, &pk.a_ext, 0, &sc.baA},
+        {E_SORT0, &sc.sortZ, &sc.bkB1, false, &pk.b1_ext, 1, &sc.baB1},
+        {E_SORT0, &sc.sortZ, &sc.bkL, false, &pk.l_ext, 2, &sc.baL},
+        {E_SORT2, &sc.sortH, &sc.bkH, false, &pk.h_query, 3, &sc.baH},
     };
     uint64_t pts = 0;
     for (int j = 0; j < 5; j++) {
       const Job& jb = jobs[j];
       ARK_CHECK_HIP(hipStreamWaitEvent(sA, ev[jb.sort_ev], 0));
-      if (jb.g2) {
+      const MsmSort* red_sort = jb.sort;          // what the reduction reads offsets / counts from
+      if (jb.tab->batch_affine) {
+        if (jb.g2)
+          red_sort = &msm_ba_accumulate_phase<Fq2>(ctx, *jb.sort, *jb.bk, *jb.ba, jb.tab->table.template as<Affine<Fq2>>(), sA,
+                                                   acc0[j], acc1[j]);
+        else
+          red_sort = &msm_ba_accumulate_phase<Fq>(ctx, *jb.sort, *jb.bk, *jb.ba, jb.tab->table.template as<Affine<Fq>>(), sA,
+                                                  acc0[j], acc1[j]);
+      } else if (jb.g2) {
         msm_accumulate_phase<Fq2>(ctx, *jb.sort, *jb.bk, jb.tab->table.template as<Affine<Fq2>>(), sA, acc0[j], acc1[j],
                                   jb.tab->limb28);
       } else {
@@ -371,17 +382,17 @@ static void prove_run(ark355_ctx* ctx, ProverScratch& sc, const PkDev& pk, const
       if (cm && shard_mode == ARK355_SHARD_BUCKET_RING) {
         // bucket-level exchange: the ranks run their MSMs in the same order, so the ring steps pair up
         if (jb.g2)
-          msm_reduce_phase<Fq2>(ctx, *jb.sort, *jb.bk, g2res, 0, sR, [&](XYZZ<Fq2>* bk, uint32_t nb, hipStream_t st) {
+          msm_reduce_phase<Fq2>(ctx, *red_sort, *jb.bk, g2res, 0, sR, [&](XYZZ<Fq2>* bk, uint32_t nb, hipStream_t st) {
             ring_reduce_scatter_buckets<Fq2>(*cm, bk, nb, st);
           });
         else
-          msm_reduce_phase<Fq>(ctx, *jb.sort, *jb.bk, g1res + jb.res, 0, sR, [&](XYZZ<Fq>* bk, uint32_t nb, hipStream_t st) {
+          msm_reduce_phase<Fq>(ctx, *red_sort, *jb.bk, g1res + jb.res, 0, sR, [&](XYZZ<Fq>* bk, uint32_t nb, hipStream_t st) {
             ring_reduce_scatter_buckets<Fq>(*cm, bk, nb, st);
           });
       } else if (jb.g2) {
-        msm_reduce_phase<Fq2>(ctx, *jb.sort, *jb.bk, g2res, 0, sR);
+        msm_reduce_phase<Fq2>(ctx, *red_sort, *jb.bk, g2res, 0, sR);
       } else {
-        msm_reduce_phase<Fq>(ctx, *jb.sort, *jb.bk, g1res + jb.res, 0, sR);
+        msm_reduce_phase<Fq>(ctx, *red_sort, *jb.bk, g1res + jb.res, 0, sR);
       }
       pts += (uint64_t)jb.sort->plan.windows * jb.sort->plan.n;
     }

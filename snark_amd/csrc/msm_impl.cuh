@@ -983,6 +983,7 @@ struct PrecompTable {
   DevBuf table;          // windows * n rows: Affine<F>, or Affine28 rows when limb28 is set
   uint64_t n = 0;
   bool limb28 = false;   // rows are stored in the radix-2^28 form of field28.cuh (msm28_impl.cuh)
+  bool batch_affine = false;   // canonical affine rows, accumulated by msm_ba_impl.cuh (ARK355_G1/G2_BATCH_AFFINE=1)
 };
 
 #ifndef ARK_LIMB28_DEFAULT
@@ -990,6 +991,12 @@ struct PrecompTable {
 #endif
 // ARK355_LIMB28=0|1 / ARK355_G2_LIMB28=0|1 (both default 1): window tables and bucket accumulation of G1 / G2 in the
 // radix-2^28 form (msm28_impl.cuh); 0 keeps the 32-bit kernels (A/B switches, exercised by the tests).
+// ARK355_G2_BATCH_AFFINE=1 / ARK355_G1_BATCH_AFFINE=1: the window table of that group stays in the canonical affine
+// form and its bucket accumulation runs as batch-affine tree levels (msm_ba_impl.cuh).  Read when a table is built.
+static inline bool msm_use_batch_affine(bool g2) {
+  const char* e = getenv(g2 ? "ARK355_G2_BATCH_AFFINE" : "ARK355_G1_BATCH_AFFINE");
+  return e && e[0] == '1';
+}
 static inline bool msm_use_limb28(bool g2) {       // read when a table is built (not cached: tests flip it)
   const char* e = getenv(g2 ? "ARK355_G2_LIMB28" : "ARK355_LIMB28");
   return e ? (e[0] == '1') : (ARK_LIMB28_DEFAULT != 0);
@@ -1020,6 +1027,10 @@ static void precomp_build(PrecompTable& t, const void* d_bases, uint64_t n, hipS
     ARK_CHECK_LAUNCH();
   }
   ARK_CHECK_HIP(hipStreamSynchronize(stream));     // tmp is freed on return
+  if (msm_use_batch_affine(is_fp2<F>::value)) {
+    t.batch_affine = true;
+    return;
+  }
   if (msm_use_limb28(is_fp2<F>::value)) {
     // re-encode the finished table for the 28-bit accumulation kernels; the 32-bit rows are dropped
     const uint64_t rows = (uint64_t)p.windows * n;
@@ -1314,3 +1325,4 @@ static void msm_buckets(ark355_ctx* ctx, const MsmSort& s, MsmBuckets& b, const 
 }
 
 }  // namespace ark355
+#include "msm_ba_impl.cuh"

@@ -206,3 +206,32 @@ def test_fixed_base_mul_vs_oracle(emul_lib, emul_ctx, C, group):
 def test_batch_verification_vs_oracle_pairing(emul_lib, emul_ctx, C):
     # the oracle's (slow, pure-Python) pairing is consulted for BLS12-381 here and for both curves in the GPU tier
     pc.verify_batch_case(emul_lib, emul_ctx, C, oracle_pairing=C is BLS12_381, light=True)
+
+
+@pytest.mark.parametrize("group", [2, 1])
+@pytest.mark.parametrize("levels", ["5", "1", "9"])
+def test_batch_affine_accumulation_edge_cases(emul_lib, emul_ctx, monkeypatch, group, levels):
+    """ARK355_G2_BATCH_AFFINE / ARK355_G1_BATCH_AFFINE (msm_ba_impl.cuh): the first tree levels of every bucket as affine
+    additions with shared inversions.  P + P, P + (-P), infinity and runs of equal points inside buckets, for 1, 5 and 9
+    tree levels (9 leaves a single node per bucket), against the oracle's naive MSM."""
+    import numpy as np
+    monkeypatch.setenv("ARK355_G2_BATCH_AFFINE" if group == 2 else "ARK355_G1_BATCH_AFFINE", "1")
+    monkeypatch.setenv("ARK355_BA_LEVELS", levels)
+
+    def to_dev(b):
+        a = np.frombuffer(b, dtype=np.uint8).copy()
+        return a.ctypes.data, a
+    pc.resident_msm_edge_case(emul_lib, emul_ctx, BLS12_381, group, 24, to_dev)
+    if levels == "5":
+        pc.resident_msm_edge_case(emul_lib, emul_ctx, BN254, group, 40, to_dev, seed=5)
+
+
+@pytest.mark.parametrize("C", [BLS12_381, BN254], ids=lambda c: c.name)
+def test_prove_with_batch_affine_accumulation(emul_lib, emul_ctx, monkeypatch, C):
+    """Whole proofs with the G2 MSM (and, second pass, all five MSMs) on the batch-affine path: same bytes as the oracle."""
+    A, B, Cm, z, ell = S.mulchain_direct(C.r, 13)
+    monkeypatch.setenv("ARK355_G2_BATCH_AFFINE", "1")
+    pc.prove_case(emul_lib, emul_ctx, C, A, B, Cm, z, ell, rs=((0x1234567890abcdef, 0xfedcba0987654321aabbccdd),))
+    if C is BLS12_381:
+        monkeypatch.setenv("ARK355_G1_BATCH_AFFINE", "1")
+        pc.prove_case(emul_lib, emul_ctx, C, A, B, Cm, z, ell, rs=((7, 9),))
