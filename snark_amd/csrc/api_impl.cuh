@@ -159,7 +159,6 @@ struct Api {
     hipStream_t st = ctx->stream;
     g.c.ensure(sizeof(XYZZ<F>) + sizeof(Affine<F>));
     XYZZ<F>* d_res = g.c.as<XYZZ<F>>();
-    Affine<F>* d_aff = reinterpret_cast<Affine<F>*>(d_res + 1);
     hipEvent_t e0, e1;
     ARK_CHECK_HIP(hipEventCreate(&e0));
     ARK_CHECK_HIP(hipEventCreate(&e1));
@@ -172,14 +171,15 @@ struct Api {
         msm_buckets<F>(ctx, g.sort, g.bk, d_bases, d_res, 0, st, n ? e0 : nullptr, n ? e1 : nullptr,
                        tab != nullptr && tab->limb28);
       }
-      if (want_affine) {
-        ARK_LAUNCH((xyzz_to_affine_kernel<F>), dim3(1), dim3(64), 0, st, (const XYZZ<F>*)d_res, d_aff, 1u);
-        ARK_CHECK_LAUNCH();
-        ARK_CHECK_HIP(hipMemcpyAsync(out, d_aff, sizeof(Affine<F>), hipMemcpyDeviceToHost, st));
-      } else {
-        ARK_CHECK_HIP(hipMemcpyAsync(out, d_res, sizeof(XYZZ<F>), hipMemcpyDeviceToHost, st));
-      }
+      // the one inversion of the normalisation runs in the library's host-compiled field code (tens of microseconds);
+      // a single device lane took ~1 ms for it, a third of a stand-alone 2^16-term MSM
+      XYZZ<F> h_res;
+      ARK_CHECK_HIP(hipMemcpyAsync(want_affine ? (void*)&h_res : (void*)out, d_res, sizeof(XYZZ<F>), hipMemcpyDeviceToHost, st));
       ARK_CHECK_HIP(hipStreamSynchronize(st));
+      if (want_affine) {
+        const Affine<F> a = xyzz_to_affine(h_res);
+        memcpy(out, &a, sizeof(a));
+      }
       float ms = 0;
       if (n) (void)hipEventElapsedTime(&ms, e0, e1);
       ctx->acc_ms = ms;
@@ -239,14 +239,14 @@ struct Api {
     g.a.ensure(count * sizeof(XYZZ<F>) + sizeof(XYZZ<F>) + sizeof(Affine<F>));
     XYZZ<F>* d_in = g.a.as<XYZZ<F>>();
     XYZZ<F>* d_sum = d_in + count;
-    Affine<F>* d_aff = reinterpret_cast<Affine<F>*>(d_sum + 1);
     if (count) ARK_CHECK_HIP(hipMemcpyAsync(d_in, partials, count * sizeof(XYZZ<F>), hipMemcpyHostToDevice, st));
     ARK_LAUNCH((xyzz_sum_kernel<F>), dim3(1), dim3(64), 0, st, (const XYZZ<F>*)d_in, (uint32_t)count, d_sum);
     ARK_CHECK_LAUNCH();
-    ARK_LAUNCH((xyzz_to_affine_kernel<F>), dim3(1), dim3(64), 0, st, (const XYZZ<F>*)d_sum, d_aff, 1u);
-    ARK_CHECK_LAUNCH();
-    ARK_CHECK_HIP(hipMemcpyAsync(out, d_aff, sizeof(Affine<F>), hipMemcpyDeviceToHost, st));
+    XYZZ<F> h_sum;
+    ARK_CHECK_HIP(hipMemcpyAsync(&h_sum, d_sum, sizeof(XYZZ<F>), hipMemcpyDeviceToHost, st));
     ARK_CHECK_HIP(hipStreamSynchronize(st));
+    const Affine<F> a = xyzz_to_affine(h_sum);      // host-side normalisation (see msm_generic)
+    memcpy(out, &a, sizeof(a));
   }
 
   static void xyzz_sum(ark355_ctx* ctx, GenericScratch& g, int group, const uint8_t* partials, uint64_t count,

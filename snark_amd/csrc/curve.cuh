@@ -159,13 +159,22 @@ template <class F>
 ARK_HD_NOINLINE void xyzz_madd_ni(XYZZ<F>& acc, const Affine<F>& p) {
   xyzz_madd_t<true>(acc, p);
 }
+// One out-of-line body per field with the multiplications INLINED: the latency-bound tails (merge, bucket reduction,
+// combination: a few dozen dependent group operations on a handful of waves) spend their time in exactly these two
+// functions, and a call per field multiplication (operands and result through scratch memory) doubled it.
+#ifndef ARK_COLD_GROUP_OPS_INLINE_MUL
+#define ARK_COLD_GROUP_OPS_INLINE_MUL 1
+#endif
+// Fq only: the Fq2 addition with inlined multiplications wants 456 registers, which drags every kernel that calls it down to
+// one wave per SIMD -- and then the CUs a tail kernel sits on cannot host a wave of another proof's accumulation kernel.
+// (A register cap cannot be put on a device function: amdgpu_num_vgpr applies to kernels only.)
 template <class F>
 ARK_HD_NOINLINE XYZZ<F> xyzz_add(const XYZZ<F>& a, const XYZZ<F>& b) {
-  return xyzz_add_t<true>(a, b);
+  return xyzz_add_t<!(ARK_COLD_GROUP_OPS_INLINE_MUL && F::COLD_INLINE_MUL)>(a, b);
 }
 template <class F>
 ARK_HD_NOINLINE XYZZ<F> xyzz_dbl(const XYZZ<F>& p) {
-  return xyzz_dbl_t<true>(p);
+  return xyzz_dbl_t<!(ARK_COLD_GROUP_OPS_INLINE_MUL && F::COLD_INLINE_MUL)>(p);
 }
 
 // canonical affine image (one field inversion)

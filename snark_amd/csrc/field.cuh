@@ -438,6 +438,7 @@ struct Fp {
 #endif
   // a*b - c*d with ONE Montgomery reduction (the Y3 of the mixed addition)
   static constexpr bool FUSED_MUL_SUB = true;
+  static constexpr bool COLD_INLINE_MUL = true;      // curve.cuh: out-of-line group operations inline their multiplications
   ARK_HD static Fp mul_sub(const Fp& a, const Fp& b, const Fp& c, const Fp& d) { return mul2sum(a, b, neg(c), d); }
 
   ARK_HD static Fp sqr(const Fp& a) { return mul(a, a); }
@@ -508,6 +509,7 @@ struct Fp2 {
     return Fp2{t, Base::add(m, m)};
   }
   static constexpr bool FUSED_MUL_SUB = false;
+  static constexpr bool COLD_INLINE_MUL = false;     // curve.cuh: out-of-line group operations keep calling mul_ni
   ARK_HD static Fp2 mul_sub(const Fp2& a, const Fp2& b, const Fp2& c, const Fp2& d) { return sub(mul(a, b), mul(c, d)); }
   ARK_HD_NOINLINE static Fp2 mul_ni(const Fp2& a, const Fp2& b) {
     Base v0 = Base::mul_ni(a.c0, b.c0);

@@ -672,6 +672,12 @@ msm_accumulate_g2l_kernel(const Affine<Fp2<P>>* __restrict__ bases, const uint32
   flush(cur_key, end);
 }
 
+// The latency-bound tail kernels (merge, bucket reduction) keep to 256 registers per lane: two waves per SIMD, so that a
+// wave of theirs and a wave of an accumulation kernel of another proof in flight can share a SIMD.  (Left to itself the
+// Fq2 group addition takes 456 registers -- one wave per SIMD -- and the CUs a tail kernel sits on stop accumulating.)
+#ifndef MSM_TAIL_WAVES
+#define MSM_TAIL_WAVES 2
+#endif
 // buckets whose entries straddle segment boundaries: add their partial runs.  Buckets spread over more than
 // MSM_HEAVY_SPAN segments (skewed scalars: boolean witnesses, the all-equal DummyCircuit, a short top window) are
 // only recorded here and summed by a whole workgroup each in msm_merge_heavy_kernel.
@@ -686,7 +692,7 @@ constexpr uint32_t MSM_HEAVY_SPAN = ARK_MSM_HEAVY_SPAN;
 #define ARK_MSM_HEAVY_GRID 128u
 #endif
 template <class F>
-__global__ void __launch_bounds__(MSM_THREADS)
+__global__ void __launch_bounds__(MSM_THREADS, MSM_TAIL_WAVES)
 msm_merge_kernel(uint32_t total_buckets, const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ counts,
                  XYZZ<F>* __restrict__ buckets, const XYZZ<F>* __restrict__ head, const uint32_t* __restrict__ head_key,
                  const XYZZ<F>* __restrict__ tail, const uint32_t* __restrict__ tail_key,
@@ -733,7 +739,7 @@ ARK_D XYZZ<F> wave_reduce_sum(XYZZ<F> v) {
 
 // one workgroup per heavy bucket: lanes stride over the bucket's segments, wave butterfly, 4 waves through LDS
 template <class F>
-__global__ void __launch_bounds__(MSM_THREADS)
+__global__ void __launch_bounds__(MSM_THREADS, MSM_TAIL_WAVES)
 msm_merge_heavy_kernel(const uint32_t* __restrict__ heavy_count, const uint32_t* __restrict__ heavy_list,
                        const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ counts,
                        XYZZ<F>* __restrict__ buckets, const XYZZ<F>* __restrict__ head,
@@ -775,7 +781,7 @@ msm_merge_heavy_kernel(const uint32_t* __restrict__ heavy_count, const uint32_t*
 // ---- K5: bucket reduction: per window sum_{b} (b+1) * bucket[b] -----------------------------------------------
 // grid.x = blocks per window, grid.y = windows.  Output: partials[window * gridDim.x + blockIdx.x].
 template <class F>
-__global__ void __launch_bounds__(MSM_THREADS)
+__global__ void __launch_bounds__(MSM_THREADS, MSM_TAIL_WAVES)
 msm_reduce_kernel(const XYZZ<F>* __restrict__ buckets, uint32_t buckets_per_window, XYZZ<F>* __restrict__ partials) {
   __shared__ uint32_t wave_out[(MSM_THREADS / 64) * (sizeof(XYZZ<F>) / 4)];
   const uint32_t w = blockIdx.y;
@@ -828,7 +834,7 @@ msm_reduce_kernel(const XYZZ<F>* __restrict__ buckets, uint32_t buckets_per_wind
 constexpr uint32_t MSM_RED_L1 = 16;       // buckets per level-1 lane (power of two: K T is log2 K doublings)
 constexpr uint32_t MSM_RED_L1_LOG = 4;
 template <class F>
-__global__ void __launch_bounds__(MSM_THREADS)
+__global__ void __launch_bounds__(MSM_THREADS, MSM_TAIL_WAVES)
 msm_reduce_l1_kernel(const XYZZ<F>* __restrict__ buckets, uint32_t nbuckets, XYZZ<F>* __restrict__ T,
                      XYZZ<F>* __restrict__ W) {
   const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
@@ -846,7 +852,7 @@ msm_reduce_l1_kernel(const XYZZ<F>* __restrict__ buckets, uint32_t nbuckets, XYZ
 
 // Output: partials[blockIdx.x] = sum over this workgroup's lanes of  sum_j W_j + K * sum_j j T_j
 template <class F>
-__global__ void __launch_bounds__(MSM_THREADS)
+__global__ void __launch_bounds__(MSM_THREADS, MSM_TAIL_WAVES)
 msm_reduce_l2_kernel(const XYZZ<F>* __restrict__ T, const XYZZ<F>* __restrict__ W, uint32_t items,
                      XYZZ<F>* __restrict__ partials) {
   __shared__ uint32_t wave_out[(MSM_THREADS / 64) * (sizeof(XYZZ<F>) / 4)];
