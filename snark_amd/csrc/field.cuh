@@ -623,6 +623,7 @@ struct Fp2L {
   }
   ARK_D static Fp2L mul_ni(const Fp2L& a, const Fp2L& b) { return mul(a, b); }
   ARK_D static Fp2L sqr_ni(const Fp2L& a) { return mul(a, a); }
+  static constexpr bool COLD_INLINE_MUL = true;     // curve.cuh: a lane's half of an Fq2 operation has Fq-like registers
 };
 
 #endif  // ARK_PLAIN_HOST

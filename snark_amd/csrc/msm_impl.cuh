@@ -824,6 +824,125 @@ msm_reduce_kernel(const XYZZ<F>* __restrict__ buckets, uint32_t buckets_per_wind
   }
 }
 
+// ---- the same tails for G2 with LANE PAIRS (field.cuh Fp2L) ------------------------------------------------------------
+// Over Fq2 the out-of-line group addition with inlined multiplications needs 456 registers, so the kernels above call a
+// function per field multiplication when F = Fq2 -- 3.9 ms of bucket reduction and 1.2 ms of merge per 2^20-term MSM on a
+// few dozen workgroups.  Here every bucket / chunk belongs to TWO lanes, each holding one component of every coordinate:
+// G1-like registers per lane, multiplications inlined, and each Fq2 product is shared by the pair.  Control flow is
+// uniform inside a pair (keys, counts and the pair-wide predicates of Fp2L).
+#ifndef ARK_PLAIN_HOST
+template <class P>
+ARK_D XYZZ<Fp2L<P>> pair_load(const XYZZ<Fp2<P>>* p) {
+  const Fp<P>* q = reinterpret_cast<const Fp<P>*>(p);
+  const uint32_t par = threadIdx.x & 1u;
+  return XYZZ<Fp2L<P>>{Fp2L<P>{q[0 + par]}, Fp2L<P>{q[2 + par]}, Fp2L<P>{q[4 + par]}, Fp2L<P>{q[6 + par]}};
+}
+template <class P>
+ARK_D void pair_store(XYZZ<Fp2<P>>* p, const XYZZ<Fp2L<P>>& v) {
+  Fp<P>* q = reinterpret_cast<Fp<P>*>(p);
+  const uint32_t par = threadIdx.x & 1u;
+  q[0 + par] = v.x.c;
+  q[2 + par] = v.y.c;
+  q[4 + par] = v.zz.c;
+  q[6 + par] = v.zzz.c;
+}
+// butterfly over the 32 pairs of a wave (the masks keep the lane parity)
+template <class P>
+ARK_D XYZZ<Fp2L<P>> wave_reduce_sum_pairs(XYZZ<Fp2L<P>> v) {
+  for (int mask = 32; mask >= 2; mask >>= 1) {
+    XYZZ<Fp2L<P>> o = xyzz_shfl_xor(v, mask);
+    v = xyzz_add(v, o);
+  }
+  return v;
+}
+
+template <class P>
+__global__ void __launch_bounds__(MSM_THREADS, MSM_TAIL_WAVES)
+msm_merge_pair_kernel(uint32_t total_buckets, const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ counts,
+                      XYZZ<Fp2<P>>* __restrict__ buckets, const XYZZ<Fp2<P>>* __restrict__ head,
+                      const uint32_t* __restrict__ head_key, const XYZZ<Fp2<P>>* __restrict__ tail,
+                      const uint32_t* __restrict__ tail_key, uint32_t* __restrict__ heavy_count,
+                      uint32_t* __restrict__ heavy_list, uint32_t seg_len) {
+  using L = Fp2L<P>;
+  const uint32_t key = (blockIdx.x * blockDim.x + threadIdx.x) >> 1;
+  if (key >= total_buckets) return;
+  const uint32_t cnt = counts[key];
+  if (cnt == 0) return;
+  const uint32_t o = offsets[key];
+  const uint32_t t0 = o / seg_len, t1 = (o + cnt - 1) / seg_len;
+  if (t0 == t1) return;   // the single run was complete and already written
+  if (t1 - t0 > MSM_HEAVY_SPAN) {
+    if ((threadIdx.x & 1u) == 0) heavy_list[atomicAdd(heavy_count, 1u)] = key;
+    return;
+  }
+  XYZZ<L> sum = XYZZ<L>::inf();
+  for (uint32_t t = t0; t <= t1; t++) {
+    if (head_key[t] == key) sum = xyzz_add(sum, pair_load<P>(&head[t]));
+    if (tail_key[t] == key) sum = xyzz_add(sum, pair_load<P>(&tail[t]));
+  }
+  pair_store<P>(&buckets[key], sum);
+}
+
+// grid.x = blocks per window (MSM_THREADS / 2 chunks each), grid.y = windows
+template <class P>
+__global__ void __launch_bounds__(MSM_THREADS, MSM_TAIL_WAVES)
+msm_reduce_pair_kernel(const XYZZ<Fp2<P>>* __restrict__ buckets, uint32_t buckets_per_window,
+                       XYZZ<Fp2<P>>* __restrict__ partials) {
+  using L = Fp2L<P>;
+  constexpr int WORDS = sizeof(XYZZ<Fp2<P>>) / 4, HALF = sizeof(Fp<P>) / 4;
+  __shared__ uint32_t wave_out[(MSM_THREADS / 64) * WORDS];
+  const uint32_t w = blockIdx.y;
+  const uint32_t chunk = (blockIdx.x * blockDim.x + threadIdx.x) >> 1;
+  const uint32_t first = chunk * MSM_RED_K;
+  XYZZ<L> contrib = XYZZ<L>::inf();
+  if (first < buckets_per_window) {
+    const uint32_t last = (first + MSM_RED_K < buckets_per_window) ? first + MSM_RED_K : buckets_per_window;
+    const XYZZ<Fp2<P>>* wb = buckets + (uint64_t)w * buckets_per_window;
+    XYZZ<L> running = XYZZ<L>::inf();
+    XYZZ<L> acc = XYZZ<L>::inf();
+    for (uint32_t b = last; b-- > first;) {
+      running = xyzz_add(running, pair_load<P>(&wb[b]));
+      acc = xyzz_add(acc, running);
+    }
+    if (first != 0 && !running.is_inf()) {
+      uint32_t k = first;
+      acc = xyzz_add(acc, xyzz_mul_scalar(running, &k, 1));
+    }
+    contrib = acc;
+  }
+  contrib = wave_reduce_sum_pairs<P>(contrib);
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane < 2) {          // the first pair of the wave: component `lane` of each coordinate
+    const Fp<P>* src[4] = {&contrib.x.c, &contrib.y.c, &contrib.zz.c, &contrib.zzz.c};
+    for (int k = 0; k < 4; k++)
+      for (int i = 0; i < HALF; i++) wave_out[wave * WORDS + (2 * k + lane) * HALF + i] = src[k]->l[i];
+  }
+  __syncthreads();
+  if (threadIdx.x < 2) {
+    XYZZ<L> sum = XYZZ<L>::inf();
+    for (uint32_t v = 0; v < blockDim.x / 64; v++)
+      sum = xyzz_add(sum, pair_load<P>(reinterpret_cast<const XYZZ<Fp2<P>>*>(&wave_out[v * WORDS])));
+    pair_store<P>(&partials[w * gridDim.x + blockIdx.x], sum);
+  }
+}
+
+// one wave = 32 pairs; window tables only (ONE bucket set: the pairs share its partials)
+template <class P>
+__global__ void __launch_bounds__(64)
+msm_combine_pair_kernel(const XYZZ<Fp2<P>>* __restrict__ partials, uint32_t count, XYZZ<Fp2<P>>* __restrict__ out,
+                        int accumulate) {
+  using L = Fp2L<P>;
+  const uint32_t pr = threadIdx.x >> 1;
+  XYZZ<L> v = XYZZ<L>::inf();
+  for (uint32_t i = pr; i < count; i += 32) v = xyzz_add(v, pair_load<P>(&partials[i]));
+  v = wave_reduce_sum_pairs<P>(v);
+  if (threadIdx.x < 2) {
+    if (accumulate) v = xyzz_add(v, pair_load<P>(out));
+    pair_store<P>(out, v);
+  }
+}
+#endif  // ARK_PLAIN_HOST
+
 // ---- two-level bucket reduction for large bucket sets (window sizes c >= 18 over window tables) ---------------------
 // sum_b (b+1) B_b with b = K j + i:  sum_j [ W_j + K j T_j ],  T_j = sum_i B_{Kj+i},  W_j = sum_i (i+1) B_{Kj+i}.
 // Level 1 gives every lane K consecutive buckets (two additions per bucket, no scalar multiplication at all); level 2
@@ -1246,6 +1365,12 @@ static void msm_accumulate_phase(ark355_ctx* ctx, const MsmSort& s, MsmBuckets& 
   if (ev1) ARK_CHECK_HIP(hipEventRecord(ev1, stream));
 }
 
+// ARK355_G2_PAIR_TAILS=0: keep the one-lane-per-bucket tail kernels for G2 (A/B; default: the lane-pair kernels)
+static inline bool msm_g2_pair_tails() {
+  const char* e = getenv("ARK355_G2_PAIR_TAILS");
+  return !(e && e[0] == '0');
+}
+
 // Phase 2: straddling-run merge, weighted bucket reduction, window combination; writes/accumulates the XYZZ
 // result into d_out.  Only a handful of workgroups and latency-bound, so the prover runs it on its own stream
 // underneath the next MSM's accumulation.
@@ -1273,10 +1398,25 @@ static void msm_reduce_phase(ark355_ctx* ctx, const MsmSort& s, MsmBuckets& b, X
     b.heavy_count.ensure(16);
     b.heavy_list.ensure((size_t)max_heavy * 4);
     ARK_CHECK_HIP(hipMemsetAsync(b.heavy_count.p, 0, 4, stream));
-    ARK_LAUNCH((msm_merge_kernel<F>), dim3(grid_b), dim3(MSM_THREADS), 0, stream, p.total_buckets,
-               s.offsets.as<uint32_t>(), s.counts.as<uint32_t>(), b.buckets.as<XYZZ<F>>(), b.head.as<XYZZ<F>>(),
-               b.head_key.as<uint32_t>(), b.tail.as<XYZZ<F>>(), b.tail_key.as<uint32_t>(),
-               b.heavy_count.as<uint32_t>(), b.heavy_list.as<uint32_t>(), b.seg_len);
+    if constexpr (is_fp2<F>::value) {
+      if (msm_g2_pair_tails()) {
+        using P = typename F::Base::Params;
+        ARK_LAUNCH((msm_merge_pair_kernel<P>), dim3(2 * grid_b), dim3(MSM_THREADS), 0, stream, p.total_buckets,
+                   s.offsets.as<uint32_t>(), s.counts.as<uint32_t>(), b.buckets.as<XYZZ<F>>(), b.head.as<XYZZ<F>>(),
+                   b.head_key.as<uint32_t>(), b.tail.as<XYZZ<F>>(), b.tail_key.as<uint32_t>(),
+                   b.heavy_count.as<uint32_t>(), b.heavy_list.as<uint32_t>(), b.seg_len);
+      } else {
+        ARK_LAUNCH((msm_merge_kernel<F>), dim3(grid_b), dim3(MSM_THREADS), 0, stream, p.total_buckets,
+                   s.offsets.as<uint32_t>(), s.counts.as<uint32_t>(), b.buckets.as<XYZZ<F>>(), b.head.as<XYZZ<F>>(),
+                   b.head_key.as<uint32_t>(), b.tail.as<XYZZ<F>>(), b.tail_key.as<uint32_t>(),
+                   b.heavy_count.as<uint32_t>(), b.heavy_list.as<uint32_t>(), b.seg_len);
+      }
+    } else {
+      ARK_LAUNCH((msm_merge_kernel<F>), dim3(grid_b), dim3(MSM_THREADS), 0, stream, p.total_buckets,
+                 s.offsets.as<uint32_t>(), s.counts.as<uint32_t>(), b.buckets.as<XYZZ<F>>(), b.head.as<XYZZ<F>>(),
+                 b.head_key.as<uint32_t>(), b.tail.as<XYZZ<F>>(), b.tail_key.as<uint32_t>(),
+                 b.heavy_count.as<uint32_t>(), b.heavy_list.as<uint32_t>(), b.seg_len);
+    }
     ARK_CHECK_LAUNCH();
     const uint32_t grid_h = max_heavy < ARK_MSM_HEAVY_GRID ? max_heavy : ARK_MSM_HEAVY_GRID;
     ARK_LAUNCH((msm_merge_heavy_kernel<F>), dim3(grid_h), dim3(MSM_THREADS), 0, stream, b.heavy_count.as<uint32_t>(),
@@ -1310,6 +1450,26 @@ static void msm_reduce_phase(ark355_ctx* ctx, const MsmSort& s, MsmBuckets& b, X
     return;
   }
   const uint32_t chunks = (p.buckets_per_window + MSM_RED_K - 1) / MSM_RED_K;
+  if constexpr (is_fp2<F>::value) {
+    if (msm_g2_pair_tails()) {
+      using P = typename F::Base::Params;
+      const uint32_t blocks_pw = (chunks + MSM_THREADS / 2 - 1) / (MSM_THREADS / 2);       // a lane pair per chunk
+      b.partials.ensure((size_t)blocks_pw * p.key_windows * sizeof(XYZZ<F>));
+      ARK_LAUNCH((msm_reduce_pair_kernel<P>), dim3(blocks_pw, p.key_windows), dim3(MSM_THREADS), 0, stream,
+                 (const XYZZ<F>*)b.buckets.as<XYZZ<F>>(), p.buckets_per_window, b.partials.as<XYZZ<F>>());
+      ARK_CHECK_LAUNCH();
+      if (p.key_windows == 1) {
+        ARK_LAUNCH((msm_combine_pair_kernel<P>), dim3(1), dim3(64), 0, stream, (const XYZZ<F>*)b.partials.as<XYZZ<F>>(),
+                   blocks_pw, d_out, accumulate);
+      } else {
+        ARK_REQUIRE(p.key_windows <= 64, ARK355_EINVAL, "window count exceeds one wave");
+        ARK_LAUNCH((msm_combine_kernel<F>), dim3(1), dim3(64), 0, stream, b.partials.as<XYZZ<F>>(), blocks_pw,
+                   p.key_windows, p.c, d_out, accumulate);
+      }
+      ARK_CHECK_LAUNCH();
+      return;
+    }
+  }
   const uint32_t blocks_per_window = (chunks + MSM_THREADS - 1) / MSM_THREADS;
   b.partials.ensure((size_t)blocks_per_window * p.key_windows * sizeof(XYZZ<F>));
   ARK_LAUNCH((msm_reduce_kernel<F>), dim3(blocks_per_window, p.key_windows), dim3(MSM_THREADS), 0, stream,
