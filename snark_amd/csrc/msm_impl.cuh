@@ -883,6 +883,45 @@ msm_merge_pair_kernel(uint32_t total_buckets, const uint32_t* __restrict__ offse
   pair_store<P>(&buckets[key], sum);
 }
 
+// one workgroup per heavy bucket: the 128 pairs stride over the bucket's segments, pair butterfly, 4 waves through LDS
+template <class P>
+__global__ void __launch_bounds__(MSM_THREADS, MSM_TAIL_WAVES)
+msm_merge_heavy_pair_kernel(const uint32_t* __restrict__ heavy_count, const uint32_t* __restrict__ heavy_list,
+                            const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ counts,
+                            XYZZ<Fp2<P>>* __restrict__ buckets, const XYZZ<Fp2<P>>* __restrict__ head,
+                            const uint32_t* __restrict__ head_key, const XYZZ<Fp2<P>>* __restrict__ tail,
+                            const uint32_t* __restrict__ tail_key, uint32_t seg_len) {
+  using L = Fp2L<P>;
+  constexpr int WORDS = sizeof(XYZZ<Fp2<P>>) / 4, HALF = sizeof(Fp<P>) / 4;
+  __shared__ uint32_t wave_out[(MSM_THREADS / 64) * WORDS];
+  const uint32_t nheavy = *heavy_count;
+  for (uint32_t h = blockIdx.x; h < nheavy; h += gridDim.x) {
+    const uint32_t key = heavy_list[h];
+    const uint32_t o = offsets[key], cnt = counts[key];
+    const uint32_t t0 = o / seg_len, t1 = (o + cnt - 1) / seg_len;
+    XYZZ<L> sum = XYZZ<L>::inf();
+    for (uint32_t t = t0 + (threadIdx.x >> 1); t <= t1; t += blockDim.x / 2) {
+      if (head_key[t] == key) sum = xyzz_add(sum, pair_load<P>(&head[t]));
+      if (tail_key[t] == key) sum = xyzz_add(sum, pair_load<P>(&tail[t]));
+    }
+    sum = wave_reduce_sum_pairs<P>(sum);
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane < 2) {
+      const Fp<P>* src[4] = {&sum.x.c, &sum.y.c, &sum.zz.c, &sum.zzz.c};
+      for (int k = 0; k < 4; k++)
+        for (int i = 0; i < HALF; i++) wave_out[wave * WORDS + (2 * k + lane) * HALF + i] = src[k]->l[i];
+    }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+      XYZZ<L> tot = XYZZ<L>::inf();
+      for (uint32_t v = 0; v < blockDim.x / 64; v++)
+        tot = xyzz_add(tot, pair_load<P>(reinterpret_cast<const XYZZ<Fp2<P>>*>(&wave_out[v * WORDS])));
+      pair_store<P>(&buckets[key], tot);
+    }
+    __syncthreads();
+  }
+}
+
 // grid.x = blocks per window (MSM_THREADS / 2 chunks each), grid.y = windows
 template <class P>
 __global__ void __launch_bounds__(MSM_THREADS, MSM_TAIL_WAVES)
@@ -1419,9 +1458,20 @@ static void msm_reduce_phase(ark355_ctx* ctx, const MsmSort& s, MsmBuckets& b, X
     }
     ARK_CHECK_LAUNCH();
     const uint32_t grid_h = max_heavy < ARK_MSM_HEAVY_GRID ? max_heavy : ARK_MSM_HEAVY_GRID;
-    ARK_LAUNCH((msm_merge_heavy_kernel<F>), dim3(grid_h), dim3(MSM_THREADS), 0, stream, b.heavy_count.as<uint32_t>(),
-               b.heavy_list.as<uint32_t>(), s.offsets.as<uint32_t>(), s.counts.as<uint32_t>(), b.buckets.as<XYZZ<F>>(),
-               b.head.as<XYZZ<F>>(), b.head_key.as<uint32_t>(), b.tail.as<XYZZ<F>>(), b.tail_key.as<uint32_t>(), b.seg_len);
+    bool heavy_done = false;
+    if constexpr (is_fp2<F>::value) {
+      if (msm_g2_pair_tails()) {
+        using P = typename F::Base::Params;
+        ARK_LAUNCH((msm_merge_heavy_pair_kernel<P>), dim3(grid_h), dim3(MSM_THREADS), 0, stream, b.heavy_count.as<uint32_t>(),
+                   b.heavy_list.as<uint32_t>(), s.offsets.as<uint32_t>(), s.counts.as<uint32_t>(), b.buckets.as<XYZZ<F>>(),
+                   b.head.as<XYZZ<F>>(), b.head_key.as<uint32_t>(), b.tail.as<XYZZ<F>>(), b.tail_key.as<uint32_t>(), b.seg_len);
+        heavy_done = true;
+      }
+    }
+    if (!heavy_done)
+      ARK_LAUNCH((msm_merge_heavy_kernel<F>), dim3(grid_h), dim3(MSM_THREADS), 0, stream, b.heavy_count.as<uint32_t>(),
+                 b.heavy_list.as<uint32_t>(), s.offsets.as<uint32_t>(), s.counts.as<uint32_t>(), b.buckets.as<XYZZ<F>>(),
+                 b.head.as<XYZZ<F>>(), b.head_key.as<uint32_t>(), b.tail.as<XYZZ<F>>(), b.tail_key.as<uint32_t>(), b.seg_len);
     ARK_CHECK_LAUNCH();
   }
   if constexpr (HOOK) after_merge(b.buckets.as<XYZZ<F>>(), p.total_buckets, stream);
