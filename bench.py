@@ -256,12 +256,14 @@ def main():
     if world > 1:
         dist.barrier()
     dev_sync()
+    cpu0 = time.process_time()
     t0 = time.perf_counter()
     results = run(args.steps, rec)
     dev_sync()
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
+    host_cpu_s = time.process_time() - cpu0          # CPU time of all threads of this rank over the timed region
     if trace is not None and rank == 0:
         tl = sorted(trace)[-args.steps:]
         sys.stderr.write("[bench] timed region: t0 -> first call %.2f ms; calls (start, duration ms): %s; last return -> end %.2f ms\n" % (
@@ -354,6 +356,8 @@ def main():
                                          "launches share the chip, so the single-stream run (--inflight 1) is the "
                                          "clean reading"}},
             "parity": parity,
+            # host CPU seconds burnt per second of the timed region by this rank (launch threads, waits, the O(1) proof tail)
+            "host_cpu_cores": host_cpu_s / dt if dt > 0 else None,
             "phases_ms": tim,
             "prove_alg_bytes": prove_alg_bytes,
             "prove_hbm_frac": prove_alg_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS,

@@ -26,6 +26,7 @@
 #include "msm_impl.cuh"
 #include "witness_impl.cuh"
 #include "comm_impl.cuh"
+#include <thread>
 
 namespace ark355 {
 
@@ -47,6 +48,29 @@ static inline void shard_range(uint64_t total, uint32_t idx, uint32_t cnt, uint6
   *n = b - a;
 }
 
+// Wait for the proof's last event WITHOUT burning a core.  On the boxes this was built on, every wait of the HIP runtime
+// spins -- hipStreamSynchronize, hipEventSynchronize on a hipEventBlockingSync event, torch.cuda.synchronize alike
+// (profiles/r02_host_wait.txt: 1.00 cores per waiting thread, 4.8 cores for a bench with four proofs in flight) -- and
+// those are the cores the synthesis threads of an end-to-end prover and the other ranks of a multi-GPU node need.  A proof
+// takes tens of milliseconds, so the proving thread polls the event and sleeps 100 us in between.  ARK355_WAIT_SPIN=1
+// hands the wait back to the runtime.
+static inline void wait_event_polite(hipEvent_t ev) {
+  static const bool spin = [] {
+    const char* e = getenv("ARK355_WAIT_SPIN");
+    return e && e[0] == '1';
+  }();
+  if (spin) {
+    ARK_CHECK_HIP(hipEventSynchronize(ev));
+    return;
+  }
+  for (;;) {
+    const hipError_t e = hipEventQuery(ev);
+    if (e == hipSuccess) return;
+    if (e != hipErrorNotReady) ARK_CHECK_HIP(e);
+    std::this_thread::sleep_for(std::chrono::microseconds(100));
+  }
+}
+
 struct ProverScratch {
   // one sort per distinct scalar vector (zx for A/B1/B2/L', h for H) and one bucket set per MSM: the five MSMs of
   // a proof are in flight together on separate streams (sized for 288 GB of HBM, not for reuse)
@@ -60,10 +84,11 @@ struct ProverScratch {
   bool have_events = false;
   void ensure_events() {
     if (have_events) return;
-    for (auto& e : events) ARK_CHECK_HIP(hipEventCreate(&e));
+    for (auto& e : events) ARK_CHECK_HIP(hipEventCreateWithFlags(&e, hipEventBlockingSync));
     have_events = true;
   }
   ~ProverScratch() {
+    release_pinned();
     for (hipStream_t st : {sW, sS, sA, sR})
       if (st) (void)hipStreamDestroy(st);
     for (auto& e : events)
@@ -74,6 +99,37 @@ struct ProverScratch {
   DevBuf results;   // XYZZ results: A, B1, L, H (G1) then B2 (G2)
   DevBuf proof;     // raw affine proof A | B | C
   DevBuf rs;        // canonical r, s (2 x Fr)
+  // Page-locked landing zone of the proof's last copy (five XYZZ sums, or the three affine points).  A D2H copy into
+  // pageable memory is not asynchronous: hipMemcpyAsync then blocks -- spinning -- until everything queued before it on
+  // the stream has run, i.e. for the whole proof (profiles/r02_host_wait.txt: one host core per proof in flight).
+  void* h_pinned = nullptr;
+  size_t h_pinned_bytes = 0;
+  void* pinned(size_t bytes) {
+    if (bytes > h_pinned_bytes) {
+      release_pinned();
+#if defined(ARK_EMUL)
+      h_pinned = malloc(bytes);
+      if (!h_pinned) throw HipError{ARK355_ENOMEM, "host allocation failed"};
+#else
+      if (hipHostMalloc(&h_pinned, bytes, hipHostMallocDefault) != hipSuccess) {
+        h_pinned = nullptr;
+        throw HipError{ARK355_ENOMEM, "hipHostMalloc failed"};
+      }
+#endif
+      h_pinned_bytes = bytes;
+    }
+    return h_pinned;
+  }
+  void release_pinned() {
+    if (!h_pinned) return;
+#if defined(ARK_EMUL)
+    free(h_pinned);
+#else
+    (void)hipHostFree(h_pinned);
+#endif
+    h_pinned = nullptr;
+    h_pinned_bytes = 0;
+  }
 };
 
 // out layout (device): Affine<Fq> A | Affine<Fq2> B | Affine<Fq> C
@@ -405,34 +461,43 @@ static void prove_run(ark355_ctx* ctx, ProverScratch& sc, const PkDev& pk, const
       const size_t psz = 4 * sizeof(XYZZ<Fq>) + sizeof(XYZZ<Fq2>);
       cm->gather.ensure(psz * (size_t)cm->world);
       ARK_CHECK_NCCL(ncclAllGather(g1res, cm->gather.p, psz, ncclUint8, cm->comm, sR));
-      std::vector<uint8_t> all(psz * (size_t)cm->world);
-      ARK_CHECK_HIP(hipMemcpyAsync(all.data(), cm->gather.p, all.size(), hipMemcpyDeviceToHost, sR));
+      const size_t all_bytes = psz * (size_t)cm->world;
+      uint8_t* all = static_cast<uint8_t*>(sc.pinned(all_bytes));
+      ARK_CHECK_HIP(hipMemcpyAsync(all, cm->gather.p, all_bytes, hipMemcpyDeviceToHost, sR));
       ARK_CHECK_HIP(hipEventRecord(ev[E_END], sR));
-      ARK_CHECK_HIP(hipStreamSynchronize(sR));
-      combine_partials_host<Curve>(all.data(), (uint64_t)cm->world, r_canon, s_canon, out);
+      wait_event_polite(ev[E_END]);
+      combine_partials_host<Curve>(all, (uint64_t)cm->world, r_canon, s_canon, out);
     } else if (partials_out) {
       // sharded prove: hand back the five XYZZ partial sums (A, B1, L', H in G1, then B2 in G2)
-      ARK_CHECK_HIP(hipMemcpyAsync(partials_out, g1res, 4 * sizeof(XYZZ<Fq>) + sizeof(XYZZ<Fq2>), hipMemcpyDeviceToHost, sR));
+      const size_t psz = 4 * sizeof(XYZZ<Fq>) + sizeof(XYZZ<Fq2>);
+      void* land = sc.pinned(psz);
+      ARK_CHECK_HIP(hipMemcpyAsync(land, g1res, psz, hipMemcpyDeviceToHost, sR));
       ARK_CHECK_HIP(hipEventRecord(ev[E_END], sR));
-      ARK_CHECK_HIP(hipStreamSynchronize(sR));
+      wait_event_polite(ev[E_END]);
+      memcpy(partials_out, land, psz);
     } else if (dev_fin && dev_fin[0] == '1') {
       ARK_LAUNCH((groth16_finalize_kernel<Curve>), dim3(1), dim3(192), 0, sR, (const XYZZ<Fq>*)g1res,
                  (const XYZZ<Fq2>*)g2res, sc.rs.as<Fr>(), sc.proof.as<unsigned char>());
       ARK_CHECK_LAUNCH();
-      ARK_CHECK_HIP(hipMemcpyAsync(out->a, sc.proof.p, sizeof(Affine<Fq>), hipMemcpyDeviceToHost, sR));
-      ARK_CHECK_HIP(hipMemcpyAsync(out->b, (uint8_t*)sc.proof.p + sizeof(Affine<Fq>), sizeof(Affine<Fq2>), hipMemcpyDeviceToHost, sR));
-      ARK_CHECK_HIP(hipMemcpyAsync(out->c, (uint8_t*)sc.proof.p + sizeof(Affine<Fq>) + sizeof(Affine<Fq2>), sizeof(Affine<Fq>), hipMemcpyDeviceToHost, sR));
+      const size_t fsz = 2 * sizeof(Affine<Fq>) + sizeof(Affine<Fq2>);
+      uint8_t* land = static_cast<uint8_t*>(sc.pinned(fsz));
+      ARK_CHECK_HIP(hipMemcpyAsync(land, sc.proof.p, fsz, hipMemcpyDeviceToHost, sR));
       ARK_CHECK_HIP(hipEventRecord(ev[E_END], sR));
-      ARK_CHECK_HIP(hipStreamSynchronize(sR));
+      wait_event_polite(ev[E_END]);
+      memcpy(out->a, land, sizeof(Affine<Fq>));
+      memcpy(out->b, land + sizeof(Affine<Fq>), sizeof(Affine<Fq2>));
+      memcpy(out->c, land + sizeof(Affine<Fq>) + sizeof(Affine<Fq2>), sizeof(Affine<Fq>));
     } else {
       XYZZ<Fq> h1[4];
       XYZZ<Fq2> h2;
-      ARK_CHECK_HIP(hipMemcpyAsync(h1, g1res, sizeof(h1), hipMemcpyDeviceToHost, sR));
-      ARK_CHECK_HIP(hipMemcpyAsync(&h2, g2res, sizeof(h2), hipMemcpyDeviceToHost, sR));
+      uint8_t* land = static_cast<uint8_t*>(sc.pinned(sizeof(h1) + sizeof(h2)));       // g1res and g2res are adjacent
+      ARK_CHECK_HIP(hipMemcpyAsync(land, g1res, sizeof(h1) + sizeof(h2), hipMemcpyDeviceToHost, sR));
       ARK_CHECK_HIP(hipEventRecord(ev[E_END], sR));
       t_launched = since(t_enter);
-      ARK_CHECK_HIP(hipStreamSynchronize(sR));
+      wait_event_polite(ev[E_END]);
       t_synced = since(t_enter);
+      memcpy(h1, land, sizeof(h1));
+      memcpy(&h2, land + sizeof(h1), sizeof(h2));
       finalize_host<Curve>(h1, h2, rc, scn, out);
       t_tail = since(t_enter);
     }

@@ -240,6 +240,8 @@ static inline hipError_t hipEventCreate(hipEvent_t* e) {
   *e = new EmuEvent();
   return hipSuccess;
 }
+constexpr unsigned hipEventBlockingSync = 1u;
+static inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { return hipEventCreate(e); }
 static inline hipError_t hipEventDestroy(hipEvent_t e) {
   delete e;
   return hipSuccess;
@@ -249,6 +251,10 @@ static inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t = nullptr) {
   return hipSuccess;
 }
 static inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+static inline hipError_t hipEventQuery(hipEvent_t) { return hipSuccess; }
+#ifndef hipErrorNotReady
+#define hipErrorNotReady ((hipError_t)600)
+#endif
 static inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) {
   *ms = std::chrono::duration<float, std::milli>(b->t - a->t).count();
   return hipSuccess;
