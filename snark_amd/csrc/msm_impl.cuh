@@ -679,8 +679,11 @@ msm_accumulate_g2l_kernel(const Affine<Fp2<P>>* __restrict__ bases, const uint32
 #define MSM_TAIL_WAVES 2
 #endif
 // buckets whose entries straddle segment boundaries: add their partial runs.  Buckets spread over more than
-// MSM_HEAVY_SPAN segments (skewed scalars: boolean witnesses, the all-equal DummyCircuit, a short top window) are
-// only recorded here and summed by a whole workgroup each in msm_merge_heavy_kernel.
+// heavy_span segments (skewed scalars: boolean witnesses, the all-equal DummyCircuit, a short top window) are
+// only recorded here and summed by a whole workgroup each in msm_merge_heavy_kernel.  heavy_span is MSM_HEAVY_SPAN, or
+// twice the AVERAGE span when that is larger: in a 2^24-term MSM every bucket of a uniform input spans
+// ~130 segments, and sending all 32 768 of them through the 128 workgroups of the heavy kernel took 46 ms where one lane
+// per bucket takes 4 (profiles/r02_msm_microbench.txt).
 #ifndef ARK_MSM_HEAVY_SPAN
 #define ARK_MSM_HEAVY_SPAN 48   // tests shrink it so that tiny cases take the heavy path
 #endif
@@ -696,7 +699,8 @@ __global__ void __launch_bounds__(MSM_THREADS, MSM_TAIL_WAVES)
 msm_merge_kernel(uint32_t total_buckets, const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ counts,
                  XYZZ<F>* __restrict__ buckets, const XYZZ<F>* __restrict__ head, const uint32_t* __restrict__ head_key,
                  const XYZZ<F>* __restrict__ tail, const uint32_t* __restrict__ tail_key,
-                 uint32_t* __restrict__ heavy_count, uint32_t* __restrict__ heavy_list, uint32_t seg_len) {
+                 uint32_t* __restrict__ heavy_count, uint32_t* __restrict__ heavy_list, uint32_t seg_len,
+                 uint32_t heavy_span) {
   const uint32_t key = blockIdx.x * blockDim.x + threadIdx.x;
   if (key >= total_buckets) return;
   const uint32_t cnt = counts[key];
@@ -704,7 +708,7 @@ msm_merge_kernel(uint32_t total_buckets, const uint32_t* __restrict__ offsets, c
   const uint32_t o = offsets[key];
   const uint32_t t0 = o / seg_len, t1 = (o + cnt - 1) / seg_len;
   if (t0 == t1) return;   // the single run was complete and already written
-  if (t1 - t0 > MSM_HEAVY_SPAN) {
+  if (t1 - t0 > heavy_span) {
     heavy_list[atomicAdd(heavy_count, 1u)] = key;
     return;
   }
@@ -862,7 +866,7 @@ msm_merge_pair_kernel(uint32_t total_buckets, const uint32_t* __restrict__ offse
                       XYZZ<Fp2<P>>* __restrict__ buckets, const XYZZ<Fp2<P>>* __restrict__ head,
                       const uint32_t* __restrict__ head_key, const XYZZ<Fp2<P>>* __restrict__ tail,
                       const uint32_t* __restrict__ tail_key, uint32_t* __restrict__ heavy_count,
-                      uint32_t* __restrict__ heavy_list, uint32_t seg_len) {
+                      uint32_t* __restrict__ heavy_list, uint32_t seg_len, uint32_t heavy_span) {
   using L = Fp2L<P>;
   const uint32_t key = (blockIdx.x * blockDim.x + threadIdx.x) >> 1;
   if (key >= total_buckets) return;
@@ -871,7 +875,7 @@ msm_merge_pair_kernel(uint32_t total_buckets, const uint32_t* __restrict__ offse
   const uint32_t o = offsets[key];
   const uint32_t t0 = o / seg_len, t1 = (o + cnt - 1) / seg_len;
   if (t0 == t1) return;   // the single run was complete and already written
-  if (t1 - t0 > MSM_HEAVY_SPAN) {
+  if (t1 - t0 > heavy_span) {
     if ((threadIdx.x & 1u) == 0) heavy_list[atomicAdd(heavy_count, 1u)] = key;
     return;
   }
@@ -1434,6 +1438,9 @@ static void msm_reduce_phase(ark355_ctx* ctx, const MsmSort& s, MsmBuckets& b, X
     const uint32_t grid_b = (p.total_buckets + MSM_THREADS - 1) / MSM_THREADS;
     // at most entries / (MSM_HEAVY_SPAN * segment length) buckets can be heavy
     const uint32_t max_heavy = segs / MSM_HEAVY_SPAN + 1;
+    // "heavy" is relative: twice the average span of a bucket once that exceeds the fixed threshold
+    const uint32_t avg_span = (uint32_t)(((uint64_t)segs + p.total_buckets - 1) / p.total_buckets);
+    const uint32_t heavy_span = (2 * avg_span > MSM_HEAVY_SPAN) ? 2 * avg_span : MSM_HEAVY_SPAN;
     b.heavy_count.ensure(16);
     b.heavy_list.ensure((size_t)max_heavy * 4);
     ARK_CHECK_HIP(hipMemsetAsync(b.heavy_count.p, 0, 4, stream));
@@ -1443,18 +1450,18 @@ static void msm_reduce_phase(ark355_ctx* ctx, const MsmSort& s, MsmBuckets& b, X
         ARK_LAUNCH((msm_merge_pair_kernel<P>), dim3(2 * grid_b), dim3(MSM_THREADS), 0, stream, p.total_buckets,
                    s.offsets.as<uint32_t>(), s.counts.as<uint32_t>(), b.buckets.as<XYZZ<F>>(), b.head.as<XYZZ<F>>(),
                    b.head_key.as<uint32_t>(), b.tail.as<XYZZ<F>>(), b.tail_key.as<uint32_t>(),
-                   b.heavy_count.as<uint32_t>(), b.heavy_list.as<uint32_t>(), b.seg_len);
+                   b.heavy_count.as<uint32_t>(), b.heavy_list.as<uint32_t>(), b.seg_len, heavy_span);
       } else {
         ARK_LAUNCH((msm_merge_kernel<F>), dim3(grid_b), dim3(MSM_THREADS), 0, stream, p.total_buckets,
                    s.offsets.as<uint32_t>(), s.counts.as<uint32_t>(), b.buckets.as<XYZZ<F>>(), b.head.as<XYZZ<F>>(),
                    b.head_key.as<uint32_t>(), b.tail.as<XYZZ<F>>(), b.tail_key.as<uint32_t>(),
-                   b.heavy_count.as<uint32_t>(), b.heavy_list.as<uint32_t>(), b.seg_len);
+                   b.heavy_count.as<uint32_t>(), b.heavy_list.as<uint32_t>(), b.seg_len, heavy_span);
       }
     } else {
       ARK_LAUNCH((msm_merge_kernel<F>), dim3(grid_b), dim3(MSM_THREADS), 0, stream, p.total_buckets,
                  s.offsets.as<uint32_t>(), s.counts.as<uint32_t>(), b.buckets.as<XYZZ<F>>(), b.head.as<XYZZ<F>>(),
                  b.head_key.as<uint32_t>(), b.tail.as<XYZZ<F>>(), b.tail_key.as<uint32_t>(),
-                 b.heavy_count.as<uint32_t>(), b.heavy_list.as<uint32_t>(), b.seg_len);
+                 b.heavy_count.as<uint32_t>(), b.heavy_list.as<uint32_t>(), b.seg_len, heavy_span);
     }
     ARK_CHECK_LAUNCH();
     const uint32_t grid_h = max_heavy < ARK_MSM_HEAVY_GRID ? max_heavy : ARK_MSM_HEAVY_GRID;
