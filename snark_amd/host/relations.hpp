@@ -152,14 +152,24 @@ class LinearCombination {
     else terms.insert(terms.begin() + i, cv);
     return *this;
   }
-  LinearCombination operator+(const std::pair<F, Variable>& cv) const {
+  LinearCombination operator+(const std::pair<F, Variable>& cv) const& {
     LinearCombination r = *this;
     r += cv;
     return r;
   }
-  LinearCombination operator+(Variable v) const { return *this + std::make_pair(F::one(), v); }
-  LinearCombination operator-(const std::pair<F, Variable>& cv) const { return *this + std::make_pair(-cv.first, cv.second); }
-  LinearCombination operator-(Variable v) const { return *this - std::make_pair(F::one(), v); }
+  // the reference's Add takes self by value (utils/linear_combination.rs:194-202): `lc = lc + x` moves, it never copies
+  // the terms.  Here that is `lc = std::move(lc) + x` (or `lc += x`).
+  LinearCombination operator+(const std::pair<F, Variable>& cv) && {
+    *this += cv;
+    return std::move(*this);
+  }
+  LinearCombination& operator+=(Variable v) { return *this += std::make_pair(F::one(), v); }
+  LinearCombination operator+(Variable v) const& { return *this + std::make_pair(F::one(), v); }
+  LinearCombination operator+(Variable v) && { return std::move(*this) + std::make_pair(F::one(), v); }
+  LinearCombination operator-(const std::pair<F, Variable>& cv) const& { return *this + std::make_pair(-cv.first, cv.second); }
+  LinearCombination operator-(const std::pair<F, Variable>& cv) && { return std::move(*this) + std::make_pair(-cv.first, cv.second); }
+  LinearCombination operator-(Variable v) const& { return *this - std::make_pair(F::one(), v); }
+  LinearCombination operator-(Variable v) && { return std::move(*this) - std::make_pair(F::one(), v); }
   // compactify (:53-82): sort by Variable, merge equal keys
   void compactify() {
     if (terms.size() <= 1) return;
@@ -406,15 +416,16 @@ class ConstraintSystem {
     if (should_construct_matrices() || should_generate_lc_assignments()) return new_lc_add_helper(f());
     return Variable::symbolic_lc(num_linear_combinations++);
   }
-  // :472-499
-  Variable new_lc_add_helper(const LC& l) {
+  // :472-499 (the closure's LC is consumed: its terms move into the map)
+  Variable new_lc_add_helper(LC&& l) {
     if (l.terms.empty() || (l.terms.size() == 1 && l.terms[0].second.is_zero())) return Variable::symbolic_lc(0);
     if (l.terms.size() == 1 && l.terms[0].first == F::one()) return l.terms[0].second;
     size_t index = num_linear_combinations++;
-    lc_map.push_back(l.terms);
+    lc_map.push_back(std::move(l.terms));
+    const auto& stored = lc_map.back();
     if (should_generate_lc_assignments()) {
       F acc = F::zero();
-      for (const auto& cv : l.terms) {
+      for (const auto& cv : stored) {
         F x;
         if (!assigned_value(cv.second, &x)) throw SynthesisError(SynthesisErrorKind::AssignmentMissing);
         acc = acc + cv.first * x;

@@ -215,7 +215,7 @@ struct RefBenchCircuit : ConstraintSynthesizer<F> {
       const size_t ka = 1 + ra.next() % 10, kb = 1 + rb.next() % 10;
       auto pick = [&](SplitMix64& r, size_t k) {
         L lc;
-        for (size_t j = 0; j < k; j++) lc = lc + vars[lower + r.next() % cur];
+        for (size_t j = 0; j < k; j++) lc = std::move(lc) + vars[lower + r.next() % cur];   // Rust: `lc = lc + var` moves
         return lc;
       };
       const Variable ci = vars[lower + rc.next() % cur];
