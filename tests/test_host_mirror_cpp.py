@@ -119,3 +119,20 @@ def test_cpp_end_to_end_pipelined_prove_matches_batch(exe):
     assert "e2e_ok 1" in r.stdout
     kv = dict(line.split("=", 1) for line in r.stdout.strip().splitlines() if "=" in line)
     assert float(kv["e2e_constraints_per_s"]) > 0 and float(kv["device_only_constraints_per_s"]) > 0
+
+
+def test_cpp_pipeline_over_the_emulator(emul_lib):
+    """The C++ host mirror linked against the EMULATOR build of the same library sources (checker only): setup, then
+    Groth16::prove_pipelined (synthesis threads -> the prover), ark355_prove_batch and prove_assignments over page-locked
+    buffers must all give the same proofs; --prove additionally checks the proof against the trapdoor closed form.  Covers
+    the host-side plumbing (Backend worker contexts, buffer recycling, queueing) on a machine without a GPU."""
+    src = os.path.join(CPP_DIR, "test_host_mirror.cpp")
+    emul = os.path.join(ROOT, "tests", "emul")
+    exe_e = os.path.join(CPP_DIR, "test_host_mirror_emul")
+    subprocess.check_call(["g++", "-O2", "-pthread", "-std=c++17", src, "-o", exe_e, "-L" + emul, "-lark355_emul",
+                           "-Wl,-rpath," + emul])
+    r = subprocess.run([exe_e, "--e2e", "bls12_381", "24", "3", "2", "1"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "e2e_ok 1" in r.stdout
+    r = subprocess.run([exe_e, "--prove", "bn254", "mulchain", "20"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
