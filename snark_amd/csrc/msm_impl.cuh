@@ -22,6 +22,10 @@
 //                  reduction with __shfl_xor, one partial per workgroup
 //      combine     lane w sums window w's partials, doubles it c*w times, __shfl_xor tree over windows
 //                  (with window tables there is ONE bucket set and no doubling)
+//   The merge / reduce / combine tails are latency-bound (a few dozen dependent group operations on 32-128 workgroups).
+//   G1: the out-of-line group addition inlines its multiplications (curve.cuh); G2: the *_pair_kernel flavours give every
+//   bucket / chunk to a LANE PAIR (Fp2L: one component of each Fq2 coordinate per lane).
+//   msm_ba_impl.cuh (included at the end) holds the batch-affine alternative to K4, off by default.
 //
 // Algorithmic bytes per term: 32 B scalar + affine base (G1 96 B / G2 192 B BLS12-381).
 #pragma once
