@@ -7,6 +7,7 @@
 //
 //   Variable                      utils/variable.rs:4-18,52-113   (3-bit tag | 61-bit index, same Ord)
 //   LinearCombination<F>          utils/linear_combination.rs:15,53-82,174-212
+//   FieldInterner<F>, LcMap<F>    gr1cs/field_interner.rs:16-72, gr1cs/lc_map.rs:52-135 (interned coefficients, flat LC storage)
 //   ConstraintSystem<F>           gr1cs/constraint_system.rs:44-97,109-139,...
 //   ConstraintSystemRef<F>        gr1cs/constraint_system_ref.rs:26-34 (Rc<RefCell<..>> -> shared_ptr)
 //   ConstraintSynthesizer<F>      gr1cs/mod.rs:54-61
@@ -16,11 +17,14 @@
 #pragma once
 #include <stdint.h>
 #include <algorithm>
+#include <cstring>
 #include <functional>
 #include <map>
 #include <memory>
 #include <stdexcept>
 #include <string>
+#include <type_traits>
+#include <unordered_map>
 #include <utility>
 #include <vector>
 
@@ -206,6 +210,91 @@ namespace gr1cs {
 
 static const char* const R1CS_PREDICATE_LABEL = "R1CS";   // predicate/polynomial_constraint.rs:69
 
+// ---- FieldInterner<F>  (gr1cs/field_interner.rs:16-72) --------------------------------------------------------------
+// Coefficients are stored once and referred to by a 32-bit id; One and -One are interned up front (ids 0 and 1) and One
+// never goes through the map -- almost every coefficient of a real circuit is one of the two.
+template <class F>
+class FieldInterner {
+  static_assert(std::is_trivially_copyable<F>::value && sizeof(F) % 8 == 0, "the interner hashes the limbs of F");
+
+ public:
+  FieldInterner() {
+    intern(F::one());
+    intern(-F::one());
+  }
+  uint32_t get_or_intern(const F& value) {
+    if (value == vec_[0]) return 0;
+    auto it = map_.find(value);
+    return it != map_.end() ? it->second : intern(value);
+  }
+  const F& value(uint32_t id) const { return vec_[id]; }       // ids only ever come from get_or_intern
+  size_t len() const { return vec_.size(); }
+
+ private:
+  struct Hash {
+    size_t operator()(const F& f) const {
+      uint64_t w[sizeof(F) / 8];
+      std::memcpy(w, &f, sizeof(F));
+      uint64_t h = 0x9e3779b97f4a7c15ull;
+      for (uint64_t x : w) {
+        h ^= x;
+        h *= 0xff51afd7ed558ccdull;
+        h ^= h >> 32;
+      }
+      return (size_t)h;
+    }
+  };
+  uint32_t intern(const F& value) {
+    const uint32_t id = (uint32_t)vec_.size();
+    map_.emplace(value, id);
+    vec_.push_back(value);
+    return id;
+  }
+  std::unordered_map<F, uint32_t, Hash> map_;
+  std::vector<F> vec_;
+};
+
+// ---- LcMap<F>  (gr1cs/lc_map.rs:52-135) -----------------------------------------------------------------------------
+// Every linear combination of the constraint system in ONE pair of flat arrays (variables, interned coefficients) with
+// an offsets array: LC i occupies [offsets[i], offsets[i + 1]).  12 bytes per term and no allocation per LC, against a
+// heap vector of 40-byte (F, Variable) pairs each.
+template <class F>
+class LcMap {
+ public:
+  LcMap() : offsets_{0} {}
+  void reserve(size_t lcs, size_t terms) {
+    vars_.reserve(terms);
+    coeffs_.reserve(terms);
+    offsets_.reserve(lcs + 1);
+  }
+  // push (lc_map.rs:92-109): appends one LC
+  template <class It>
+  void push(It first, It last, FieldInterner<F>& interner) {
+    for (; first != last; ++first) {
+      coeffs_.push_back(interner.get_or_intern(first->first));
+      vars_.push_back(first->second);
+    }
+    offsets_.push_back(vars_.size());
+  }
+  size_t num_lcs() const { return offsets_.size() - 1; }
+  size_t total_lc_size() const { return vars_.size(); }
+  // term range of LC i (bounds-checked like the reference's `get`)
+  size_t begin(size_t i) const { return offsets_.at(i); }
+  size_t end(size_t i) const { return offsets_.at(i + 1); }
+  Variable var(size_t k) const { return vars_[k]; }
+  uint32_t coeff(size_t k) const { return coeffs_[k]; }
+  bool any_lc_var() const {                                       // any_lcs_used (constraint_system.rs:762-764)
+    for (const Variable& v : vars_)
+      if (v.is_lc()) return true;
+    return false;
+  }
+
+ private:
+  std::vector<Variable> vars_;
+  std::vector<uint32_t> coeffs_;
+  std::vector<size_t> offsets_;
+};
+
 // gr1cs/mod.rs:74-90
 struct SynthesisMode {
   enum Tag { Setup, Prove } tag = Prove;
@@ -226,7 +315,8 @@ class ConstraintSystem {
   ConstraintSystem() {
     instance_assignment.push_back(F::one());
     lc_assignment.push_back(F::zero());
-    lc_map.emplace_back();                     // the zero LC (:111)
+    lc_map.push(static_cast<const std::pair<F, Variable>*>(nullptr), static_cast<const std::pair<F, Variable>*>(nullptr),
+                field_interner);               // the zero LC (:111)
     r1cs_args.resize(3);                       // R1CS predicate registered by default (:136-137)
   }
 
@@ -274,31 +364,37 @@ class ConstraintSystem {
   // :717-758
   void inline_all_lcs() {
     if (!should_construct_matrices()) return;
-    bool any_used = false;
-    for (const auto& l : lc_map)
-      for (const auto& cv : l)
-        if (cv.second.is_lc()) any_used = true;
-    if (!any_used) return;
-    std::vector<std::vector<std::pair<F, Variable>>> inlined;
-    inlined.reserve(lc_map.size());
-    for (const auto& l : lc_map) {
-      LC out;
-      for (const auto& cv : l) {
+    if (!lc_map.any_lc_var()) return;
+    LcMap<F> inlined;
+    inlined.reserve(lc_map.num_lcs(), lc_map.total_lc_size());
+    LC out;
+    out.terms.reserve(10);
+    const F zero = F::zero();
+    for (size_t i = 0; i < lc_map.num_lcs(); i++) {
+      for (size_t k = lc_map.begin(i); k < lc_map.end(i); k++) {
+        const uint32_t cid = lc_map.coeff(k);
+        const Variable var = lc_map.var(k);
         size_t idx;
-        if (cv.second.get_lc_index(&idx)) {
-          const auto& sub = inlined[idx];
-          if (cv.first == F::one()) {
-            out.terms.insert(out.terms.end(), sub.begin(), sub.end());
+        if (var.get_lc_index(&idx)) {
+          // already transformed: LCs only refer to earlier ones
+          const size_t b = inlined.begin(idx), e = inlined.end(idx);
+          if (cid == 0) {                                        // coefficient One
+            for (size_t j = b; j < e; j++) out.terms.emplace_back(field_interner.value(inlined.coeff(j)), inlined.var(j));
           } else {
-            for (const auto& s : sub)
-              if (!s.second.is_zero() && !(s.first == F::zero())) out.terms.emplace_back(cv.first * s.first, s.second);
+            const F coeff = field_interner.value(cid);
+            for (size_t j = b; j < e; j++) {
+              const F& c2 = field_interner.value(inlined.coeff(j));
+              const Variable v2 = inlined.var(j);
+              if (!v2.is_zero() && !(c2 == zero)) out.terms.emplace_back(coeff * c2, v2);
+            }
           }
         } else {
-          out.terms.push_back(cv);
+          out.terms.emplace_back(field_interner.value(cid), var);
         }
       }
       out.compactify();
-      inlined.push_back(std::move(out.terms));
+      inlined.push(out.terms.begin(), out.terms.end(), field_interner);
+      out.terms.clear();
     }
     lc_map = std::move(inlined);
   }
@@ -308,8 +404,13 @@ class ConstraintSystem {
     LC l;
     if (v.is_zero()) return l;
     size_t idx;
-    if (v.get_lc_index(&idx)) l.terms = lc_map.at(idx);
-    else l.terms.emplace_back(F::one(), v);
+    if (v.get_lc_index(&idx)) {
+      const size_t b = lc_map.begin(idx), e = lc_map.end(idx);
+      l.terms.reserve(e - b);
+      for (size_t k = b; k < e; k++) l.terms.emplace_back(field_interner.value(lc_map.coeff(k)), lc_map.var(k));
+    } else {
+      l.terms.emplace_back(F::one(), v);
+    }
     return l;
   }
   // :792-804
@@ -347,9 +448,9 @@ class ConstraintSystem {
       row.emplace_back(c, idx);
     };
     if (v.get_lc_index(&lc_idx)) {
-      const auto& terms = lc_map.at(lc_idx);
-      row.reserve(terms.size());
-      for (const auto& cv : terms) push(cv.first, cv.second);
+      const size_t b = lc_map.begin(lc_idx), e = lc_map.end(lc_idx);
+      row.reserve(e - b);
+      for (size_t k = b; k < e; k++) push(field_interner.value(lc_map.coeff(k)), lc_map.var(k));
     } else {
       push(F::one(), v);
     }
@@ -416,13 +517,13 @@ class ConstraintSystem {
     if (should_construct_matrices() || should_generate_lc_assignments()) return new_lc_add_helper(f());
     return Variable::symbolic_lc(num_linear_combinations++);
   }
-  // :472-499 (the closure's LC is consumed: its terms move into the map)
+  // :472-499 (the closure's LC is consumed: its terms go into the flat map, coefficients interned)
   Variable new_lc_add_helper(LC&& l) {
     if (l.terms.empty() || (l.terms.size() == 1 && l.terms[0].second.is_zero())) return Variable::symbolic_lc(0);
     if (l.terms.size() == 1 && l.terms[0].first == F::one()) return l.terms[0].second;
     size_t index = num_linear_combinations++;
-    lc_map.push_back(std::move(l.terms));
-    const auto& stored = lc_map.back();
+    lc_map.push(l.terms.begin(), l.terms.end(), field_interner);             // LcMap::push (lc_map.rs:92-109)
+    const auto& stored = l.terms;
     if (should_generate_lc_assignments()) {
       F acc = F::zero();
       for (const auto& cv : stored) {
@@ -435,7 +536,8 @@ class ConstraintSystem {
     return Variable::symbolic_lc(index);
   }
 
-  std::vector<std::vector<std::pair<F, Variable>>> lc_map;
+  LcMap<F> lc_map;
+  FieldInterner<F> field_interner;
   std::vector<std::vector<Variable>> r1cs_args;   // column-wise argument_lcs (predicate/mod.rs:81-94)
 };
 

@@ -244,6 +244,18 @@ static void test_bench_lc_is_satisfied() {
 // in Prove{construct_matrices: true} mode, then finalize -- plus to_matrices, on this machine's host
 template <class F>
 static int run_synth_bench(size_t n) {
+  if (getenv("ARK355_SYNTH_WITNESS_ONLY")) {          // the per-proof path alone, on a fresh heap
+    RefBenchCircuit<F> c0(F::from_u64(0x7654321), n);
+    auto cs0 = ConstraintSystemRef<F>::new_ref();
+    cs0.set_mode(SynthesisMode::prove(false, false));
+    auto ta = std::chrono::steady_clock::now();
+    c0.generate_constraints(cs0);
+    cs0.finalize();
+    std::vector<F> z0 = cs0.borrow().full_assignment();
+    auto tb = std::chrono::steady_clock::now();
+    printf("witness_only_ms=%.3f\nwitness_only_z_len=%zu\n", std::chrono::duration<double, std::milli>(tb - ta).count(), z0.size());
+    return 0;
+  }
   RefBenchCircuit<F> circ(F::from_u64(0x1234567), n);
   auto cs = ConstraintSystemRef<F>::new_ref();
   cs.set_optimization_goal(OptimizationGoal::Constraints);
