@@ -61,6 +61,10 @@ struct MsmPlan {
   // window combination disappear from the per-proof path.
   bool precomp = false;
   uint32_t key_windows = 0;     // bucket sets: 1 with precomp, `windows` without
+  // Scalars above (r - 1) / 2 are replaced by r - k with every digit's sign flipped (k P = (r - k)(-P)): the values
+  // that remain are one bit shorter, which saves a whole window exactly when c divides the scalar width -- c = 17 for
+  // 255-bit scalars: 15 windows instead of 16.  Derived from c alone, so a table and the MSMs over it always agree.
+  bool negate_high = false;
 };
 
 // Entries per accumulation lane ("segment length").  The accumulation kernels keep CUs x 2 workgroups x 256 lanes
@@ -95,6 +99,8 @@ static inline uint32_t msm_seg_len(uint64_t entries, bool pair_lanes) {
   return (uint32_t)len;
 }
 
+struct MsmPlan;
+static inline int msm_digit_flags(const MsmPlan& p);
 inline MsmPlan msm_plan(uint64_t n, uint32_t scalar_bits, bool precomp = false, int force_c = 0) {
   MsmPlan p;
   p.n = n;
@@ -136,11 +142,46 @@ inline MsmPlan msm_plan(uint64_t n, uint32_t scalar_bits, bool precomp = false, 
   p.c = (uint32_t)c;
   // one extra bit so that the top window never produces a carry
   p.windows = (scalar_bits + 1 + p.c - 1) / p.c;
+  if (precomp && (scalar_bits + p.c - 1) / p.c < p.windows) {
+    p.negate_high = true;
+    p.windows = (scalar_bits + p.c - 1) / p.c;
+  }
   p.buckets_per_window = 1u << (p.c - 1);
   p.key_windows = precomp ? 1u : p.windows;
   p.total_buckets = p.key_windows * p.buckets_per_window;
   return p;
 }
+
+static inline int msm_digit_flags(const MsmPlan& p) { return (p.precomp ? 1 : 0) | (p.negate_high ? 2 : 0); }
+
+// `precomp` of the digit kernels is a bit set: bit 0 = window tables (one bucket set, values index table rows),
+// bit 1 = MsmPlan::negate_high
+constexpr int MSM_DIGITS_PRECOMP = 1, MSM_DIGITS_NEGATE_HIGH = 2;
+
+// k (canonical) > (r - 1) / 2: replace it by r - k and report it
+template <class Fr>
+ARK_D bool msm_negate_if_high(Fr& k) {
+  using P = typename Fr::Params;
+  Fr nk;
+  uint32_t borrow = 0;
+#pragma unroll
+  for (int j = 0; j < Fr::N; j++) {
+    const uint64_t t = (uint64_t)P::mod(j) - k.l[j] - borrow;
+    nk.l[j] = (uint32_t)t;
+    borrow = (uint32_t)(t >> 32) & 1u;
+  }
+  bool greater = false, decided = false;          // k > nk ?
+#pragma unroll
+  for (int j = Fr::N - 1; j >= 0; j--) {
+    if (!decided && k.l[j] != nk.l[j]) {
+      greater = k.l[j] > nk.l[j];
+      decided = true;
+    }
+  }
+  if (greater) k = nk;
+  return greater;
+}
+
 
 // Wave-aggregated "fetch-and-add 1" on counter[key]: returns this lane's slot, i.e. what
 // atomicAdd(&counter[key], 1) would have returned, but lanes of a wave that share a key are served by ONE atomic.
@@ -176,13 +217,15 @@ ARK_D uint32_t wave_agg_inc(uint32_t* counter, uint32_t key, bool valid) {
 // ---- K2: signed window digits + histogram ----------------------------------------------------------
 template <class Fr>
 __global__ void __launch_bounds__(MSM_THREADS)
-msm_digits_kernel(const Fr* __restrict__ scalars, uint32_t n, int mont, uint32_t c, uint32_t windows, int precomp,
+msm_digits_kernel(const Fr* __restrict__ scalars, uint32_t n, int mont, uint32_t c, uint32_t windows, int precomp_flags,
                   uint32_t table_stride,
                   uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, uint32_t* __restrict__ counts) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   const bool in_range = i < n;                     // no early return: the wave-level primitives need every lane
   Fr k = in_range ? scalars[i] : Fr::zero();
   if (mont) k = Fr::from_mont(k);
+  const int precomp = precomp_flags & MSM_DIGITS_PRECOMP;
+  const uint32_t flip = ((precomp_flags & MSM_DIGITS_NEGATE_HIGH) && msm_negate_if_high(k)) ? 1u : 0u;
   const uint32_t B = 1u << (c - 1);
   const uint32_t full = 1u << c;
   uint32_t carry = 0;
@@ -210,7 +253,7 @@ msm_digits_kernel(const Fr* __restrict__ scalars, uint32_t n, int mont, uint32_t
     const uint32_t key = valid ? (precomp ? (d - 1) : (w * B + d - 1)) : MSM_INVALID;
     if (in_range) {
       keys[e] = key;
-      vals[e] = valid ? ((precomp ? (w * table_stride + i) : i) | (neg << 31)) : 0u;
+      vals[e] = valid ? ((precomp ? (w * table_stride + i) : i) | ((neg ^ flip) << 31)) : 0u;
     }
     (void)wave_agg_inc(counts, valid ? key : 0u, valid);
   }
@@ -331,9 +374,11 @@ constexpr uint32_t SORT_TILE = MSM_THREADS * SORT_EPT;
 
 // calls fn(w, key, val) for every non-zero signed digit of scalar i
 template <class Fr, class Fn>
-ARK_D void msm_for_each_digit(Fr k, int mont, uint32_t i, uint32_t n, uint32_t c, uint32_t windows, int precomp,
+ARK_D void msm_for_each_digit(Fr k, int mont, uint32_t i, uint32_t n, uint32_t c, uint32_t windows, int precomp_flags,
                               uint32_t table_stride, Fn&& fn) {
   if (mont) k = Fr::from_mont(k);
+  const int precomp = precomp_flags & MSM_DIGITS_PRECOMP;
+  const uint32_t flip = ((precomp_flags & MSM_DIGITS_NEGATE_HIGH) && msm_negate_if_high(k)) ? 1u : 0u;
   const uint32_t B = 1u << (c - 1);
   const uint32_t full = 1u << c;
   uint32_t carry = 0;
@@ -357,7 +402,7 @@ ARK_D void msm_for_each_digit(Fr k, int mont, uint32_t i, uint32_t n, uint32_t c
     }
     if (d != 0) {
       const uint32_t key = precomp ? (d - 1) : (w * B + d - 1);
-      const uint32_t val = (precomp ? (w * table_stride + i) : i) | (neg << 31);
+      const uint32_t val = (precomp ? (w * table_stride + i) : i) | ((neg ^ flip) << 31);
       fn(w, key, val);
     }
   }
@@ -1183,6 +1228,9 @@ static void precomp_build(PrecompTable& t, const void* d_bases, uint64_t n, hipS
                     plan_n ? (int)msm_plan(plan_n, Fr::Params::BITS, /*precomp=*/true).c : 0);
   const MsmPlan& p = t.plan;
   ARK_REQUIRE((uint64_t)p.windows * n < (1ull << 31), ARK355_EINVAL, "window table too large for 31-bit indices");
+  if (getenv("ARK355_TRACE_HOST"))
+    fprintf(stderr, "[ark355] window table: %llu bases, c = %u, %u windows%s\n", (unsigned long long)n, p.c, p.windows,
+            p.negate_high ? ", scalars above (r - 1) / 2 negated" : "");
   t.table.alloc((size_t)p.windows * (n ? n : 1) * sizeof(Affine<F>));
   if (n == 0) return;
   ARK_CHECK_HIP(hipMemcpyAsync(t.table.p, d_bases, n * sizeof(Affine<F>), hipMemcpyDeviceToDevice, stream));
@@ -1270,7 +1318,7 @@ static void msm_sort(ark355_ctx* ctx, MsmSort& s, const void* d_scalars, uint64_
   if (legacy || bins > SORT_MAX_BINS) {
     const uint32_t grid_n = (uint32_t)((n + MSM_THREADS - 1) / MSM_THREADS);
     ARK_LAUNCH((msm_digits_kernel<Fr>), dim3(grid_n), dim3(MSM_THREADS), 0, stream, (const Fr*)d_scalars, (uint32_t)n,
-               mont, p.c, p.windows, p.precomp ? 1 : 0, stride, s.keys.as<uint32_t>(), s.vals.as<uint32_t>(),
+               mont, p.c, p.windows, msm_digit_flags(p), stride, s.keys.as<uint32_t>(), s.vals.as<uint32_t>(),
                s.counts.as<uint32_t>());
     ARK_CHECK_LAUNCH();
     ARK_LAUNCH(scan_exclusive_kernel, dim3(1), dim3(SCAN_THREADS), 0, stream, s.counts.as<uint32_t>(),
@@ -1290,14 +1338,14 @@ static void msm_sort(ark355_ctx* ctx, MsmSort& s, const void* d_scalars, uint64_
   s.hist.ensure(hist_elems * 4);
   s.hist_scanned.ensure(hist_elems * 4);
   ARK_LAUNCH((sort_hi_hist_kernel<Fr>), dim3(grid1), dim3(SORT_HI_THREADS), 0, stream, (const Fr*)d_scalars, (uint32_t)n,
-             mont, p.c, p.windows, p.precomp ? 1 : 0, stride, bins, s.hist.as<uint32_t>());
+             mont, p.c, p.windows, msm_digit_flags(p), stride, bins, s.hist.as<uint32_t>());
   ARK_CHECK_LAUNCH();
   ARK_REQUIRE(hist_elems < (1ull << 31), ARK355_EINVAL, "sort histogram too large");
   ARK_LAUNCH(scan_exclusive_kernel, dim3(1), dim3(SCAN_THREADS), 0, stream, s.hist.as<uint32_t>(),
              s.hist_scanned.as<uint32_t>(), (uint32_t)hist_elems, s.total.as<uint32_t>());
   ARK_CHECK_LAUNCH();
   ARK_LAUNCH((sort_hi_scatter_kernel<Fr>), dim3(grid1), dim3(SORT_HI_THREADS), 0, stream, (const Fr*)d_scalars,
-             (uint32_t)n, mont, p.c, p.windows, p.precomp ? 1 : 0, stride, bins, s.hist_scanned.as<uint32_t>(),
+             (uint32_t)n, mont, p.c, p.windows, msm_digit_flags(p), stride, bins, s.hist_scanned.as<uint32_t>(),
              s.keys.as<uint32_t>(), s.vals.as<uint32_t>());
   ARK_CHECK_LAUNCH();
   // level 2: bucket histogram, bucket offsets, final placement

@@ -270,3 +270,28 @@ def verify_batch_case(lib, ctx, C, count=2, n=9, seed=31, oracle_pairing=True, l
     # A at infinity is not a valid proof
     inf = [(bytes(len(proofs[0][0])), proofs[0][1], proofs[0][2])]
     assert not lib.verify_batch(ctx, C.curve_id, vk, inf, inputs[0])
+
+
+def resident_known_dlog_case(lib, ctx, C, group, n, to_dev, seed=21):
+    """Resident bases s_i * G (made by ark355_fixed_base_mul) + ark355_msm_dev with scalars around the negation
+    threshold of MsmPlan::negate_high -- 0, 1, r - 1, (r - 1) / 2, (r + 1) / 2, 2^(bits - 1) and random ones -- against
+    (sum k_i s_i) * G.  Any size: no naive MSM on the Python side."""
+    rnd = random.Random(seed + n)
+    G_ = g1(C) if group == 1 else g2(C)
+    raw = Z.g1_raw if group == 1 else Z.g2_raw
+    fromraw = Z.g1_from_raw if group == 1 else Z.g2_from_raw
+    sz = lib.sizes(C.curve_id)
+    psz = sz["g1"] if group == 1 else sz["g2"]
+    ss = [rnd.getrandbits(64) + 1 for _ in range(n)]
+    bases = lib.fixed_base_mul(ctx, C.curve_id, group, raw(C, G_.gen), b"".join(Z.fr_canon(C, s) for s in ss), n, psz)
+    half = (C.r - 1) // 2
+    special = [0, 1, C.r - 1, half, half + 1, half - 1, 1 << (C.r.bit_length() - 1), C.r - 2, 2, half + 12345]
+    ks = [special[i] if i < len(special) else rnd.randrange(C.r) for i in range(n)]
+    h = lib.bases_load(ctx, C.curve_id, group, bases, n)
+    try:
+        ptr, keep = to_dev(b"".join(Z.fr_canon(C, k) for k in ks))
+        out = lib.msm_dev(ctx, h, ptr, n, 0, psz)
+        expect = G_.mul(G_.gen, sum(k * s for k, s in zip(ks, ss)) % C.r)
+        assert fromraw(C, out) == expect, (C.name, group, n)
+    finally:
+        lib.dll.ark355_bases_free(h)

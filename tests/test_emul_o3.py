@@ -38,3 +38,25 @@ def test_large_window_two_level_reduction_and_odd_segments(emul_lib, emul_ctx, m
 
     O.check_resident_msm(emul_lib, emul_ctx, BLS12_381, 1, 1024, to_dev, seed=7)
     O.check_resident_msm(emul_lib, emul_ctx, BN254, 2, 1024, to_dev, seed=8)
+
+
+@pytest.mark.parametrize("c", ["5", "15"])
+def test_window_sizes_that_negate_high_scalars(emul_lib, emul_ctx, monkeypatch, c):
+    """MsmPlan::negate_high: when the window size divides the scalar width (5, 15, 17 for BLS12-381's 255 bits), scalars
+    above (r - 1) / 2 are replaced by r - k with flipped digit signs and a whole window disappears (c = 17: 15 instead
+    of 16).  Scalars around the threshold against the known discrete log; the three distributions against oracle/c;
+    a whole proof."""
+    import parity_cases as pc
+    from oracle import synthetic as S
+    monkeypatch.setenv("ARK355_MSM_C", c)
+
+    def to_dev(b):
+        a = np.frombuffer(b, dtype=np.uint8).copy()
+        return a.ctypes.data, a
+
+    pc.resident_known_dlog_case(emul_lib, emul_ctx, BLS12_381, 1, 1024, to_dev)
+    if c == "5":
+        pc.resident_known_dlog_case(emul_lib, emul_ctx, BLS12_381, 2, 1024, to_dev)
+        O.check_resident_msm(emul_lib, emul_ctx, BLS12_381, 1, 1024, to_dev, seed=9)
+        A, B, Cm, z, ell = S.mulchain_direct(BLS12_381.r, 1030)
+        pc.prove_case(emul_lib, emul_ctx, BLS12_381, A, B, Cm, z, ell, rs=((5, 7),))

@@ -247,3 +247,13 @@ def test_prove_with_batch_affine_g2(gpu_lib, gpu_ctx, monkeypatch, C):
     monkeypatch.setenv("ARK355_G2_BATCH_AFFINE", "1")
     A, B, Cm, z, ell = S.mulchain_direct(C.r, 300)
     pc.prove_case(gpu_lib, gpu_ctx, C, A, B, Cm, z, ell, rs=((0x1234567890abcdef, 0xfedcba0987654321aabbccdd), (0, 5)))
+
+
+@pytest.mark.gpu
+def test_prove_with_window_17_negating_high_scalars(gpu_lib, gpu_ctx, monkeypatch):
+    """ARK355_MSM_C=17 on a key of >= 1024 terms: MsmPlan::negate_high (scalars above (r - 1) / 2 become r - k with
+    flipped digit signs), 15 windows, 2^16 buckets -- the proof must still be the oracle's."""
+    monkeypatch.setenv("ARK355_MSM_C", "17")
+    C = BLS12_381
+    A, B, Cm, z, ell = S.mulchain_direct(C.r, 1030)
+    pc.prove_case(gpu_lib, gpu_ctx, C, A, B, Cm, z, ell, rs=((C.r - 3, 12345),))
