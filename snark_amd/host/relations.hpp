@@ -331,22 +331,28 @@ class ConstraintSystem {
   bool is_new() const { return num_instance_variables == 1 && num_witness_variables == 0 && num_r1cs_constraints == 0 && num_linear_combinations == 1; }
 
   // :591-617
-  Variable new_input_variable(const std::function<F()>& f) {
+  // (the value / LC closures are template parameters, as the reference's `FnOnce() -> ..` generics are: no type erasure,
+  // no allocation for a closure that captures more than two pointers)
+  template <class Fn>
+  Variable new_input_variable(Fn&& f) {
     size_t i = num_instance_variables++;
     if (!is_in_setup_mode()) instance_assignment.push_back(f());
     return Variable::instance(i);
   }
-  Variable new_witness_variable(const std::function<F()>& f) {
+  template <class Fn>
+  Variable new_witness_variable(Fn&& f) {
     size_t i = num_witness_variables++;
     if (!is_in_setup_mode()) witness_assignment.push_back(f());
     return Variable::witness(i);
   }
 
   // :523-532
-  Variable new_lc(const std::function<LC()>& f) { return new_lc_helper(f); }
+  template <class Fn>
+  Variable new_lc(Fn&& f) { return new_lc_helper(f); }
 
   // :431-438 -> :323-353
-  void enforce_r1cs_constraint(const std::function<LC()>& a, const std::function<LC()>& b, const std::function<LC()>& c) {
+  template <class FA, class FB, class FC>
+  void enforce_r1cs_constraint(FA&& a, FB&& b, FC&& c) {
     if (should_construct_matrices()) {
       Variable va = new_constraint_lc(a), vb = new_constraint_lc(b), vc = new_constraint_lc(c);
       r1cs_args[0].push_back(va);
@@ -508,12 +514,14 @@ class ConstraintSystem {
 
  private:
   // :455-461
-  Variable new_constraint_lc(const std::function<LC()>& f) {
+  template <class Fn>
+  Variable new_constraint_lc(Fn&& f) {
     if (should_construct_matrices()) return new_lc_helper(f);
     return Variable::symbolic_lc(num_linear_combinations++);
   }
   // :503-519
-  Variable new_lc_helper(const std::function<LC()>& f) {
+  template <class Fn>
+  Variable new_lc_helper(Fn&& f) {
     if (should_construct_matrices() || should_generate_lc_assignments()) return new_lc_add_helper(f());
     return Variable::symbolic_lc(num_linear_combinations++);
   }
@@ -556,11 +564,15 @@ class ConstraintSystemRef {
   }
   void set_mode(SynthesisMode m) const { borrow().set_mode(m); }
   void set_optimization_goal(OptimizationGoal g) const { borrow().set_optimization_goal(g); }
-  Variable new_input_variable(const std::function<F()>& f) const { return borrow().new_input_variable(f); }
-  Variable new_witness_variable(const std::function<F()>& f) const { return borrow().new_witness_variable(f); }
-  Variable new_lc(const std::function<LC()>& f) const { return borrow().new_lc(f); }
+  template <class Fn>
+  Variable new_input_variable(Fn&& f) const { return borrow().new_input_variable(f); }
+  template <class Fn>
+  Variable new_witness_variable(Fn&& f) const { return borrow().new_witness_variable(f); }
+  template <class Fn>
+  Variable new_lc(Fn&& f) const { return borrow().new_lc(f); }
   // constraint_system_ref.rs:235-250: returns Ok(()) without recording when matrices are off (:241-243)
-  void enforce_r1cs_constraint(const std::function<LC()>& a, const std::function<LC()>& b, const std::function<LC()>& c) const {
+  template <class FA, class FB, class FC>
+  void enforce_r1cs_constraint(FA&& a, FB&& b, FC&& c) const {
     auto& cs = borrow();
     if (!cs.should_construct_matrices()) return;
     cs.enforce_r1cs_constraint(a, b, c);
