@@ -27,18 +27,62 @@ def free(lib, pkh, rh):
     lib.dll.ark355_r1cs_free(rh)
 
 
-def check_instance(lib, ctx, C, inst, rs_pairs, batch=0, inflight=4):
+def vk_parts(pk):
+    return (pk["alpha_g1"], pk["beta_g2"], pk["gamma_g2"], pk["delta_g2"], pk["gamma_abc_g1"])
+
+
+def check_equation(lib, ctx, C, inst, pk, proofs, python_pairing=False):
+    """The Groth16 equation on proofs made with the ORACLE's key: ark355_verify_batch (device MSMs + the library's host
+    pairing) and, once per call when asked, the oracle's independent textbook pairing (oracle/pairing.py)."""
     n, ell, w, mats, z = inst
+    inputs = S._mont_bytes(C.r, z[1:ell])
+    rnd = random.Random(len(proofs) * 977 + n)
+    rho = [Z.fr_canon(C, rnd.randrange(1, C.r)) for _ in proofs]
+    assert lib.verify_batch(ctx, C.curve_id, vk_parts(pk), proofs, inputs * len(proofs), rho if len(proofs) > 1 else None)
+    # a proof of the same statement with C replaced by A must fail
+    a, b, c = proofs[0]
+    assert not lib.verify_batch(ctx, C.curve_id, vk_parts(pk), [(a, b, a)], inputs)
+    if python_pairing:
+        vk = G.VerifyingKey(Z.g1_from_raw(C, pk["alpha_g1"]), Z.g2_from_raw(C, pk["beta_g2"]), Z.g2_from_raw(C, pk["gamma_g2"]),
+                            Z.g2_from_raw(C, pk["delta_g2"]),
+                            [Z.g1_from_raw(C, pk["gamma_abc_g1"][i * len(a):(i + 1) * len(a)]) for i in range(ell)])
+        assert G.verify(C, vk, list(z[1:ell]), G.Proof(Z.g1_from_raw(C, a), Z.g2_from_raw(C, b), Z.g1_from_raw(C, c)))
+
+
+def check_instance(lib, ctx, C, inst, rs_pairs, batch=0, inflight=4, sharded=False, equation=True, python_pairing=False,
+                   timing=None):
+    """Key from the oracle's generator; `ark355_prove` (and, with `sharded`, `ark355_prove_sharded` over the real RCCL at
+    world size 1 with both exchange modes; with `batch`, `ark355_prove_batch`) byte-compared with `cbase.prove`; with
+    `equation` every proof is also put through the Groth16 equation (check_equation)."""
+    import time
+    n, ell, w, mats, z = inst
+    t0 = time.perf_counter()
     pk, _ = cbase.setup_raw_c(C, n, ell, w, mats, TD)
+    t1 = time.perf_counter()
     zb = S._mont_bytes(C.r, z)
     sizes = lib.sizes(C.curve_id)
     pkh, rh = load(lib, ctx, C, inst, pk)
+    t2 = time.perf_counter()
+    comm = None
     try:
         assert lib.is_satisfied(ctx, rh, zb, len(z)) == -1
+        proofs = []
         for r_, s_ in rs_pairs:
             got = lib.prove(ctx, pkh, rh, zb, len(z), Z.fr_canon(C, r_), Z.fr_canon(C, s_), sizes)
             exp = cbase.prove(C, n, ell, w, mats, zb, pk, r_, s_)
             assert got == exp, (C.name, n, "ark355_prove vs oracle/c")
+            proofs.append(got)
+            if sharded:
+                # a whole key is shard 0 of 1: communicator creation, the all-gather / the (empty) ring and the combine
+                # run exactly as on 8 GPUs
+                from snark_amd._binding import SHARD_BUCKET_RING, SHARD_WINDOW
+                if comm is None:
+                    comm = lib.comm_init(ctx, lib.comm_unique_id(), 0, 1)
+                for mode in (SHARD_WINDOW, SHARD_BUCKET_RING):
+                    got_s = lib.prove_sharded(ctx, comm, pkh, rh, zb, len(z), Z.fr_canon(C, r_), Z.fr_canon(C, s_), sizes,
+                                              mode=mode)
+                    assert got_s == exp, (C.name, n, "ark355_prove_sharded vs oracle/c", mode)
+        t3 = time.perf_counter()
         if batch:
             rnd = random.Random(batch)
             rs = [(rnd.randrange(C.r), rnd.randrange(C.r)) for _ in range(batch)]
@@ -46,7 +90,14 @@ def check_instance(lib, ctx, C, inst, rs_pairs, batch=0, inflight=4):
                                    [Z.fr_canon(C, b) for _, b in rs], sizes, inflight=inflight)
             for (r_, s_), got in zip(rs, outs):
                 assert got == cbase.prove(C, n, ell, w, mats, zb, pk, r_, s_), (C.name, n, "ark355_prove_batch")
+            proofs += outs
+        if equation and proofs:
+            check_equation(lib, ctx, C, inst, pk, proofs, python_pairing=python_pairing)
+        if timing is not None:
+            timing.update(oracle_setup_s=t1 - t0, key_load_s=t2 - t1, prove_and_oracle_s=t3 - t2)
     finally:
+        if comm is not None:
+            lib.comm_destroy(comm)
         free(lib, pkh, rh)
 
 
@@ -94,3 +145,28 @@ def check_resident_msm(lib, ctx, C, group, n, to_dev, seed=1):
             assert got == cbase.msm(C, group, pts, sc, n), (group, n, dist)
     finally:
         lib.dll.ark355_bases_free(bh)
+
+
+def check_ntt_full(lib, ctx, C, log_n, seed=5):
+    """ark355_ntt_fr vs cb_ntt, four modes, whole vectors (Montgomery images in and out on both sides)."""
+    rnd = random.Random(seed * 100 + log_n)
+    n = 1 << log_n
+    raw = np.frombuffer(rnd.randbytes(32 * n), dtype="<u8").reshape(n, 4).copy()
+    raw[:, 3] &= (1 << (C.r.bit_length() - 1 - 192)) - 1                 # < 2^(bits-1) < r: valid residues
+    data = raw.tobytes()
+    for inv, cos in ((0, 0), (1, 0), (0, 1), (1, 1)):
+        got = lib.ntt(ctx, C.curve_id, data, log_n, inv, cos)
+        exp = cbase.ntt(C, data, log_n, bool(inv), bool(cos))
+        assert got == exp, (C.name, log_n, inv, cos)
+
+
+def check_witness_map_full(lib, ctx, C, inst):
+    n, ell, w, mats, z = inst
+    zb = S._mont_bytes(C.r, z)
+    rh = lib.r1cs_load(ctx, C.curve_id, n, ell, w, mats)
+    try:
+        got = lib.witness_map(ctx, rh, zb, len(z), 32)
+        exp = cbase.witness_map(C, n, ell, w, mats, zb)
+        assert len(got) == len(exp) and got == exp, (C.name, n)
+    finally:
+        lib.dll.ark355_r1cs_free(rh)

@@ -60,3 +60,14 @@ def test_window_sizes_that_negate_high_scalars(emul_lib, emul_ctx, monkeypatch, 
         O.check_resident_msm(emul_lib, emul_ctx, BLS12_381, 1, 1024, to_dev, seed=9)
         A, B, Cm, z, ell = S.mulchain_direct(BLS12_381.r, 1030)
         pc.prove_case(emul_lib, emul_ctx, BLS12_381, A, B, Cm, z, ell, rs=((5, 7),))
+
+
+def test_large_size_checks_on_the_emulator(emul_lib, emul_ctx):
+    """The checks the GPU tier runs at 2^21..2^23 (tests/test_gpu_o3_large.py): whole-vector NTT and witness map against
+    oracle/c, a proof through ark355_prove AND ark355_prove_sharded (world size 1, both exchange modes), every proof
+    through the Groth16 equation -- here at sizes the emulator finishes in seconds."""
+    O.check_ntt_full(emul_lib, emul_ctx, BLS12_381, 9)
+    O.check_ntt_full(emul_lib, emul_ctx, BN254, 4)
+    O.check_witness_map_full(emul_lib, emul_ctx, BLS12_381, S.mulchain_csr(BLS12_381.r, 61))
+    O.check_instance(emul_lib, emul_ctx, BLS12_381, S.mulchain_csr(BLS12_381.r, 33), [(9, 11)], sharded=True,
+                     python_pairing=True)

@@ -24,7 +24,7 @@ pytestmark = pytest.mark.gpu
 def test_s2_2p20_bls12_381_vs_o3(gpu_lib, gpu_ctx):
     """BASELINE configs[1]: S2 mulchain, n = 2^20 (N = 2^21), BLS12-381."""
     C = BLS12_381
-    O.check_instance(gpu_lib, gpu_ctx, C, S.mulchain_csr(C.r, 1 << 20), [(0x1234567, 0x89ABCDE)])
+    O.check_instance(gpu_lib, gpu_ctx, C, S.mulchain_csr(C.r, 1 << 20), [(0x1234567, 0x89ABCDE)], python_pairing=True)
 
 
 def test_s2_2p20_tight_bls12_381_vs_o3(gpu_lib, gpu_ctx):
@@ -37,6 +37,19 @@ def test_s2_2p20_bn254_vs_o3(gpu_lib, gpu_ctx):
     """BASELINE configs[3]: the second field instantiation at n = 2^20."""
     C = BN254
     O.check_instance(gpu_lib, gpu_ctx, C, S.mulchain_csr(C.r, 1 << 20), [(77, C.r - 2)])
+
+
+@pytest.mark.parametrize("n,label", [((1 << 22) - 100, "tight N=2^22"), (1 << 22, "literal N=2^23")], ids=["tight", "literal"])
+def test_s2_2p22_bls12_381_vs_o3_whole_and_sharded(gpu_lib, gpu_ctx, n, label):
+    """BASELINE configs[2]: S2 at n = 2^22 - 100 (N = 2^22) and the literal n = 2^22 (N = 2^23: the other radix split of the
+    NTT and the largest direct twiddle table), key from the oracle's generator: `ark355_prove` AND `ark355_prove_sharded`
+    (real RCCL, world size 1, window-level and bucket-ring exchange) byte-identical to `cbase.prove`; every proof through
+    the Groth16 equation (`ark355_verify_batch`)."""
+    C = BLS12_381
+    tm = {}
+    O.check_instance(gpu_lib, gpu_ctx, C, S.mulchain_csr(C.r, n), [(0xC0FFEE, C.r - 0x22)], sharded=True, timing=tm)
+    print("2^22 %s: oracle setup %.1f s, key load %.1f s, proofs + oracle proof %.1f s" % (
+        label, tm["oracle_setup_s"], tm["key_load_s"], tm["prove_and_oracle_s"]))
 
 
 def test_batch_2p18_vs_o3(gpu_lib, gpu_ctx):
@@ -68,3 +81,17 @@ def test_resident_msm_vs_o3(gpu_lib, gpu_ctx, group, log_n):
         return d.data_ptr(), d
 
     O.check_resident_msm(gpu_lib, gpu_ctx, BLS12_381, group, 1 << log_n, to_dev, seed=log_n)
+
+
+@pytest.mark.parametrize("C,log_n", [(BLS12_381, 21), (BLS12_381, 22), (BLS12_381, 23), (BN254, 22)],
+                         ids=lambda v: getattr(v, "name", str(v)))
+def test_ntt_large_vs_o3_in_full(gpu_lib, gpu_ctx, C, log_n):
+    """`ark355_ntt_fr` (the stand-alone entry point a host calls) in all four modes against `cb_ntt`, every element, at
+    the prover's domain sizes 2^21 / 2^22 / 2^23 (three different radix splits; 2^23 = the largest direct-table domain)."""
+    O.check_ntt_full(gpu_lib, gpu_ctx, C, log_n)
+
+
+@pytest.mark.parametrize("n", [(1 << 20), (1 << 21) - 7, (1 << 22)], ids=["N=2^21", "N=2^21-tight", "N=2^23"])
+def test_witness_map_large_vs_o3_in_full(gpu_lib, gpu_ctx, n):
+    """`ark355_witness_map` (SpMV + 7 NTTs + pointwise) against `cb_witness_map`, all N coefficients of h."""
+    O.check_witness_map_full(gpu_lib, gpu_ctx, BLS12_381, S.mulchain_csr(BLS12_381.r, n))
