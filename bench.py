@@ -102,6 +102,24 @@ def cpu_baseline(curve_name, log_n_sample=None):
             "sample": "pure-Python oracle (scalar, naive MSM), 2^7-constraint mulchain, 1 proof"}
 
 
+def thread_cpu_times():
+    """CPU seconds (user + system) of every thread of this process, keyed by (tid, comm): where the host cores of a rank go."""
+    out = {}
+    tick = os.sysconf("SC_CLK_TCK")
+    try:
+        for tid in os.listdir("/proc/self/task"):
+            try:
+                st = open("/proc/self/task/%s/stat" % tid).read()
+            except OSError:
+                continue
+            comm = st[st.index("(") + 1:st.rindex(")")]
+            f = st[st.rindex(")") + 2:].split()
+            out[(tid, comm)] = (int(f[11]) + int(f[12])) / tick
+    except OSError:
+        pass
+    return out
+
+
 def pmc_traffic(n, curve):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (FETCH_SIZE and
     WRITE_SIZE, separate runs; profiles/README.md).  None when no profile of this workload is on file."""
@@ -109,11 +127,13 @@ def pmc_traffic(n, curve):
     try:
         rec = json.load(open(path))
         if rec.get("workload") != "%s:n=%d" % (curve, n):
-            return None
+            return None, None
         k = rec["msm_accumulate_kernel"]
-        return k["fetch_bytes_per_launch"] + k["write_bytes_per_launch"]
+        note = ("static: FETCH_SIZE + WRITE_SIZE of rocprofv3 --pmc passes recorded in profiles/pmc_latest.json (%s), "
+                "not collected by this run" % rec.get("recorded", "date not recorded"))
+        return k["fetch_bytes_per_launch"] + k["write_bytes_per_launch"], note
     except Exception:
-        return None
+        return None, None
 
 
 def main():
@@ -203,16 +223,21 @@ def main():
     ctxs = [g.ctx] + [g.lib.ctx_create(dev_id) for _ in range(max(1, args.inflight) - 1)]
     lock = threading.Lock()
 
-    def prove_on(ctx, r_, s_):
+    def prove_on(ctx, r_, s_, z_host=None):
         if shard:
+            if z_host is not None:
+                return sg.prove(pk, r1, z_host, r_, s_, mode=shard_mode)
             return sg.prove(pk, r1, None, r_, s_, mode=shard_mode, z_device_ptr=z_dev.data_ptr())
-        a, b, c = g.lib.prove(ctx, pkh, rh, z_dev.data_ptr(), r1.m, cv.fr_canon(r_), cv.fr_canon(s_), g.sizes,
-                              z_is_device_ptr=True)
+        if z_host is not None:           # SURVEY 8d window: assignment in HOST memory -> proof in host memory (H2D included)
+            a, b, c = g.lib.prove(ctx, pkh, rh, z_host, r1.m, cv.fr_canon(r_), cv.fr_canon(s_), g.sizes)
+        else:
+            a, b, c = g.lib.prove(ctx, pkh, rh, z_dev.data_ptr(), r1.m, cv.fr_canon(r_), cv.fr_canon(s_), g.sizes,
+                                  z_is_device_ptr=True)
         return Proof(a, b, c)
 
     trace = [] if os.environ.get("ARK355_BENCH_TRACE") else None
 
-    def run(nsteps, record, per_worker=False):
+    def run(nsteps, record, per_worker=False, z_host=None):
         # per_worker: every context proves `nsteps` times (warm-up must touch each context's scratch and streams)
         todo = [(rnd.randrange(cv.r), rnd.randrange(cv.r)) for _ in range(nsteps * (len(ctxs) if per_worker else 1))]
         quota = {id(c): nsteps for c in ctxs}
@@ -226,7 +251,7 @@ def main():
                     quota[id(ctx)] -= 1
                     r_, s_ = todo.pop()
                 t_a = time.perf_counter()
-                p = prove_on(ctx, r_, s_)          # the C call releases the GIL; it returns after its streams drained
+                p = prove_on(ctx, r_, s_, z_host)  # the C call releases the GIL; it returns after its streams drained
                 t_b = time.perf_counter()
                 ks = g.lib.kernel_stats(ctx)
                 if trace is not None:
@@ -256,6 +281,7 @@ def main():
     if world > 1:
         dist.barrier()
     dev_sync()
+    thr0 = thread_cpu_times()
     cpu0 = time.process_time()
     t0 = time.perf_counter()
     results = run(args.steps, rec)
@@ -264,6 +290,13 @@ def main():
         dist.barrier()
     dt = time.perf_counter() - t0
     host_cpu_s = time.process_time() - cpu0          # CPU time of all threads of this rank over the timed region
+    thr1 = thread_cpu_times()
+    by_comm = {}
+    for key, t1_ in thr1.items():
+        d_ = t1_ - thr0.get(key, 0.0)
+        if d_ > 0:
+            by_comm[key[1]] = by_comm.get(key[1], 0.0) + d_
+    host_cpu_threads = {k: round(v / dt, 3) for k, v in sorted(by_comm.items(), key=lambda kv: -kv[1])[:8]} if dt > 0 else {}
     if trace is not None and rank == 0:
         tl = sorted(trace)[-args.steps:]
         sys.stderr.write("[bench] timed region: t0 -> first call %.2f ms; calls (start, duration ms): %s; last return -> end %.2f ms\n" % (
@@ -285,6 +318,44 @@ def main():
         dev_sync()
         solo = solo_rec[0] / max(1, solo_rec[1])
         tim = g.lib.timings(g.ctx)
+    # SURVEY.md 8d / BASELINE.md section 3: t_prove = assignment resident in HOST memory -> three affine points in host
+    # memory, median of >= 5 single proofs, H2D of z included.  Outside the timed region, rank 0's GPU only; page-locked
+    # (ark355_host_alloc) and pageable host buffers, next to the device-resident reading of the same loop; then the
+    # in-flight throughput of the timed region repeated from host buffers.
+    latency = None
+    if rank == 0 and not emul:
+        import ctypes
+        ptr = ctypes.c_void_p()
+        assert g.lib.dll.ark355_host_alloc(len(zb), ctypes.byref(ptr)) == 0
+        z_pinned = np.ctypeslib.as_array(ctypes.cast(ptr, ctypes.POINTER(ctypes.c_uint8)), shape=(len(zb),))
+        z_pinned[:] = np.frombuffer(zb, dtype=np.uint8)
+        z_page = np.frombuffer(zb, dtype=np.uint8).copy()
+
+        def med(z_host, reps=7):
+            ts = []
+            for _ in range(reps):
+                ta = time.perf_counter()
+                prove_on(g.ctx, rnd.randrange(cv.r), rnd.randrange(cv.r), z_host)
+                ts.append((time.perf_counter() - ta) * 1e3)
+            ts.sort()
+            return ts[len(ts) // 2]
+
+        def thr(z_host):
+            dev_sync()
+            ta = time.perf_counter()
+            res = run(args.steps, None, z_host=z_host)
+            dev_sync()
+            tb = time.perf_counter() - ta
+            results.extend(res)                       # checked against the closed form with the others
+            return {"ms_per_step": tb / args.steps * 1e3, "value": n * args.steps / tb}
+
+        latency = {"definition": "one proof at a time, wall clock of the C call: assignment z in host memory -> proof "
+                                 "(3 affine points) in host memory, H2D of z included; median of 7",
+                   "host_pinned_z_ms": med(z_pinned), "host_pageable_z_ms": med(z_page), "device_z_ms": med(None),
+                   "inflight_from_host_z": {"pinned": thr(z_pinned), "pageable": thr(z_page),
+                                            "note": "the timed region repeated with every proof reading z from host memory"}}
+        latency["constraints_per_s_single_proof_host_pinned_z"] = n / (latency["host_pinned_z_ms"] * 1e-3)
+        g.lib.dll.ark355_host_free(ptr)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=xdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -321,9 +392,11 @@ def main():
         mads_per_proof = windows * (g1_terms * mpa["g1"] + g2_terms * mpa["g2"])
         acc_ms_per_proof = acc_ms_sum / max(1, args.steps)
         mad_rate_t = mads_per_proof / (acc_ms_per_proof * 1e-3) / 1e12 if acc_ms_per_proof > 0 else 0.0
+        traffic, traffic_note = pmc_traffic(n, args.curve)
+        mode_txt = ("one proof sharded over %d GPU(s)" % world) if shard else (
+            "throughput: %d proofs in flight per GPU, z resident in HBM" % len(ctxs))
         out = {
-            "metric": "R1CS constraints/sec (Groth16 prove, BLS12-381)" if args.curve == "bls12_381"
-                      else "R1CS constraints/sec (Groth16 prove, BN254)",
+            "metric": "R1CS constraints/sec (Groth16 prove, %s; %s)" % ("BLS12-381" if args.curve == "bls12_381" else "BN254", mode_txt),
             "value": (1 if shard else world) * n * args.steps / dt,
             "unit": "constraints/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -341,7 +414,7 @@ def main():
                                       "replicas x%d (independent proofs, no collective), %d proofs in flight per GPU"
                                       % (world, len(ctxs))},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(n, args.curve),
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_note,
                          "kernel": "msm_accumulate_kernel (bucket accumulation, 4 G1 + 1 G2 launches per proof)",
                          "alg_bytes_per_launch": alg_bytes_per_launch, "avg_launch_ms": avg_launch_ms,
                          "single_stream": None if not solo else {
@@ -358,6 +431,9 @@ def main():
             "parity": parity,
             # host CPU seconds burnt per second of the timed region by this rank (launch threads, waits, the O(1) proof tail)
             "host_cpu_cores": host_cpu_s / dt if dt > 0 else None,
+            "host_cpu_threads": host_cpu_threads,      # cores per thread name over the timed region (top 8)
+            # the metric as SURVEY.md 8d defines it (host z -> host proof, single proofs) beside the throughput headline
+            "latency": latency,
             "phases_ms": tim,
             "prove_alg_bytes": prove_alg_bytes,
             "prove_hbm_frac": prove_alg_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS,

@@ -175,9 +175,22 @@ int32_t ark355_prove_sharded_dev(ark355_ctx* ctx, ark355_comm* comm, const ark35
 /* ---- ark-serialize wire formats (SNARK::{ProvingKey, VerifyingKey, Proof}: CanonicalSerialize +
  *      CanonicalDeserialize, snark/src/lib.rs:25-36) ------------------------------------------------------------------
  * Point encodings as upstream writes them: BLS12-381 zcash/IETF (big-endian, flags in the first byte), BN254 ark-ec
- * SWFlags (little-endian, flags in the last byte); compressed != 0 selects the compressed form.  validate != 0 performs
- * the on-curve test of Validate::Yes for uncompressed points (compressed points are on the curve by construction; the
- * prime-subgroup test -- a scalar multiplication per point -- is left to the party that trusts the key). */
+ * SWFlags (little-endian, flags in the last byte); compressed != 0 selects the compressed form.  `validate`:
+ *   ARK355_VALIDATE_FULL (1)   everything ark-serialize's Validate::Yes checks: reduced coordinates, the curve equation
+ *                              (uncompressed form; compressed points are on the curve by construction) AND membership in
+ *                              the prime-order subgroup ([r]P = O: BLS12-381 G1/G2, BN254 G2) -- use it for anything that
+ *                              comes from an untrusted party (proofs: a small-order component vanishes in the pairing, so
+ *                              without the test one proof has many accepted encodings); an encoding whose infinity flag
+ *                              is set must be all-zero otherwise;
+ *   ARK355_VALIDATE_CURVE (2)  the same without the subgroup test (a 255-bit scalar multiplication per point): the
+ *                              explicit opt-out for key material from a trusted source;
+ *   ARK355_VALIDATE_NONE (0)   Validate::No.
+ * Flag combinations upstream rejects in every mode are rejected in every mode here: BLS12-381 sort bit without the
+ * compressed bit or together with the infinity bit, a compressed bit that does not match the requested form
+ * (ark-bls12-381 EncodingFlags::get_flags); BN254 both flag bits set (ark-ec SWFlags::from_u8). */
+#define ARK355_VALIDATE_NONE 0
+#define ARK355_VALIDATE_FULL 1
+#define ARK355_VALIDATE_CURVE 2
 /* bytes of one encoded point of `group` (1 | 2) */
 uint64_t ark355_point_size(int32_t curve, int32_t group, int32_t compressed);
 /* the byte stream of an ark_groth16::ProvingKey<E> (vk, beta_g1, delta_g1, a_query, b_g1_query, b_g2_query, h_query,
@@ -188,6 +201,13 @@ int32_t ark355_pk_load_bytes(ark355_ctx* ctx, int32_t curve, const uint8_t* byte
                              int32_t validate, ark355_pk** out);
 /* dimensions of a resident key: num_instance (ell), num_witness (w), domain size N */
 int32_t ark355_pk_dims(const ark355_pk* pk, uint64_t* num_instance, uint64_t* num_witness, uint64_t* domain_size);
+/* How a resident key sits in HBM: Pippenger window size c, windows per scalar, window stride of its tables
+ * (1 = a table per window: one bucket set, no doublings; s > 1 = every s-th window has a table and an MSM keeps s
+ * bucket sets -- chosen at load time as the smallest stride whose tables fit the device next to the provers' scratch;
+ * ARK355_ENOMEM from the load when none does) and the bytes its five window tables occupy.  Any pointer may be NULL.
+ * (No counterpart in the reference: ark-groth16 keeps `ProvingKey<E>` as plain vectors in host memory.) */
+int32_t ark355_pk_table_info(const ark355_pk* pk, uint32_t* window_bits, uint32_t* windows, uint32_t* table_stride,
+                             uint64_t* table_bytes);
 /* n encoded points <-> n raw affine images (x || y Montgomery; the layout of every other entry point), on the device */
 int32_t ark355_points_decode(ark355_ctx* ctx, int32_t curve, int32_t group, const uint8_t* in, uint64_t n,
                              int32_t compressed, int32_t validate, uint8_t* out_raw);

@@ -114,16 +114,39 @@ fn registry() -> &'static Mutex<HashMap<Key, Arc<Resident>>> {
     R.get_or_init(|| Mutex::new(HashMap::new()))
 }
 
-/// Fingerprint of a proving key: FNV-1a-style mixing (4 lanes) over the compressed verifying key, the two prover-only
-/// points and the query lengths.  Collisions would need two keys with identical verifying keys.
+/// Fingerprint of a proving key.  Covers the verifying key, the two prover-only points, the query lengths AND the
+/// query vectors themselves: 256 evenly spaced elements (plus the last one) of each of the five vectors, and the address
+/// of `a_query`'s buffer.  The verifying key alone is not enough: two circuits of the same shape set up from the same
+/// deterministic seed (the usual `test_rng` pattern) that differ only in witness constraints share vk, beta_g1, delta_g1
+/// and every length, and a lookup keyed on those would prove with the other circuit's key and matrices.  Hashing all
+/// ~600 MB of a 2^20 key on every `prove` is not an option, hence samples + buffer identity: a different key object
+/// misses (and is uploaded), the same object hits.
 pub fn fingerprint<E: Mi355xCurve>(pk: &ProvingKey<E>) -> Key {
     let mut bytes = Vec::new();
     pk.vk.serialize_compressed(&mut bytes).expect("vk serialization");
     pk.beta_g1.serialize_compressed(&mut bytes).expect("point serialization");
     pk.delta_g1.serialize_compressed(&mut bytes).expect("point serialization");
-    for n in [pk.a_query.len(), pk.h_query.len(), pk.l_query.len(), E::CURVE_ID as usize] {
+    for n in [pk.a_query.len(), pk.b_g1_query.len(), pk.b_g2_query.len(), pk.h_query.len(), pk.l_query.len(), E::CURVE_ID as usize,
+              pk.a_query.as_ptr() as usize] {
         bytes.extend_from_slice(&(n as u64).to_le_bytes());
     }
+    fn sample<T: CanonicalSerialize>(v: &[T], bytes: &mut Vec<u8>) {
+        if v.is_empty() {
+            return;
+        }
+        let step = core::cmp::max(1, v.len() / 256);
+        let mut i = 0;
+        while i < v.len() {
+            v[i].serialize_uncompressed(&mut *bytes).expect("point serialization");
+            i += step;
+        }
+        v[v.len() - 1].serialize_uncompressed(&mut *bytes).expect("point serialization");
+    }
+    sample(&pk.a_query, &mut bytes);
+    sample(&pk.b_g1_query, &mut bytes);
+    sample(&pk.b_g2_query, &mut bytes);
+    sample(&pk.h_query, &mut bytes);
+    sample(&pk.l_query, &mut bytes);
     let mut lanes = [0xcbf29ce484222325u64, 0x84222325cbf29ce4, 0x9e3779b97f4a7c15, 0xd6e8feb86659fd93];
     for (i, b) in bytes.iter().enumerate() {
         let l = &mut lanes[i & 3];

@@ -41,6 +41,10 @@ pub const ARK355_E_POLY_DEGREE_TOO_LARGE: i32 = -18;
 pub const ARK355_COMM_ID_BYTES: usize = 128;
 pub const ARK355_SHARD_WINDOW: i32 = 0;
 pub const ARK355_SHARD_BUCKET_RING: i32 = 1;
+/// `validate` of the wire-format entry points: Validate::No / Validate::Yes (curve + prime-order subgroup) / curve only
+pub const ARK355_VALIDATE_NONE: i32 = 0;
+pub const ARK355_VALIDATE_FULL: i32 = 1;
+pub const ARK355_VALIDATE_CURVE: i32 = 2;
 
 #[repr(C)]
 pub struct ark355_pk_desc {
@@ -218,6 +222,7 @@ extern "C" {
         out: *mut *mut ark355_pk,
     ) -> i32;
     pub fn ark355_pk_dims(pk: *const ark355_pk, num_instance: *mut u64, num_witness: *mut u64, domain_size: *mut u64) -> i32;
+    pub fn ark355_pk_table_info(pk: *const ark355_pk, window_bits: *mut u32, windows: *mut u32, table_stride: *mut u32, table_bytes: *mut u64) -> i32;
     pub fn ark355_points_decode(
         ctx: *mut ark355_ctx,
         curve: i32,

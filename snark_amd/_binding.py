@@ -45,6 +45,7 @@ SYMBOLS = [
     "ark355_get_kernel_stats", "ark355_pk_load_shard", "ark355_partial_size", "ark355_prove_shard",
     "ark355_prove_combine", "ark355_prove_batch", "ark355_comm_unique_id", "ark355_comm_init", "ark355_comm_destroy",
     "ark355_prove_sharded", "ark355_prove_sharded_dev", "ark355_point_size", "ark355_pk_load_bytes", "ark355_pk_dims",
+    "ark355_pk_table_info",
     "ark355_points_decode", "ark355_points_encode", "ark355_proof_to_bytes", "ark355_proof_from_bytes",
     "ark355_setup_scalars", "ark355_verify_batch",
 ]
@@ -155,6 +156,7 @@ class Lib:
         d.ark355_point_size.restype = u64
         d.ark355_pk_load_bytes.argtypes = [vp, i32, vp, u64, i32, i32, P(vp)]
         d.ark355_pk_dims.argtypes = [vp, P(u64), P(u64), P(u64)]
+        d.ark355_pk_table_info.argtypes = [vp, P(C.c_uint32), P(C.c_uint32), P(C.c_uint32), P(u64)]
         d.ark355_points_decode.argtypes = [vp, i32, i32, vp, u64, i32, i32, vp]
         d.ark355_points_encode.argtypes = [vp, i32, i32, vp, u64, i32, vp]
         d.ark355_proof_to_bytes.argtypes = [i32, P(ProofRaw), i32, vp]
@@ -279,9 +281,14 @@ class Lib:
     def pk_load_bytes(self, ctx, curve, data: bytes, compressed=False, validate=True):
         h = C.c_void_p()
         db, k = _buf(data)
-        self.check(ctx, self.dll.ark355_pk_load_bytes(ctx, curve, db, len(data), int(bool(compressed)), int(bool(validate)),
+        self.check(ctx, self.dll.ark355_pk_load_bytes(ctx, curve, db, len(data), int(bool(compressed)), int(validate),
                                                       C.byref(h)))
         return h
+
+    def pk_table_info(self, pk):
+        c, w, st, by = C.c_uint32(0), C.c_uint32(0), C.c_uint32(0), C.c_uint64(0)
+        self.check(None, self.dll.ark355_pk_table_info(pk, C.byref(c), C.byref(w), C.byref(st), C.byref(by)))
+        return {"window_bits": c.value, "windows": w.value, "table_stride": st.value, "table_bytes": by.value}
 
     def pk_dims(self, pk):
         a, b, c = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
@@ -291,7 +298,7 @@ class Lib:
     def points_decode(self, ctx, curve, group, data: bytes, n, compressed, validate, raw_size):
         out = np.zeros(max(1, n * raw_size), dtype=np.uint8)
         db, k = _buf(data if n else None)
-        self.check(ctx, self.dll.ark355_points_decode(ctx, curve, group, db, n, int(bool(compressed)), int(bool(validate)),
+        self.check(ctx, self.dll.ark355_points_decode(ctx, curve, group, db, n, int(bool(compressed)), int(validate),
                                                       out.ctypes.data_as(C.c_void_p)))
         return out.tobytes()[:n * raw_size]
 
@@ -316,7 +323,7 @@ class Lib:
     def proof_from_bytes(self, curve, data: bytes, sizes, compressed=True, validate=True):
         p = ProofRaw()
         db, k = _buf(data)
-        rc = self.dll.ark355_proof_from_bytes(curve, db, len(data), int(bool(compressed)), int(bool(validate)), C.byref(p))
+        rc = self.dll.ark355_proof_from_bytes(curve, db, len(data), int(bool(compressed)), int(validate), C.byref(p))
         if rc != OK:
             raise Ark355Error(rc, "ark355_proof_from_bytes")
         return bytes(p.a)[:sizes["g1"]], bytes(p.b)[:sizes["g2"]], bytes(p.c)[:sizes["g1"]]

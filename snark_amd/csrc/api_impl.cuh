@@ -73,6 +73,7 @@ struct Api {
   using Fr = typename Curve::Fr;
   using Fq = typename Curve::Fq;
   using Fq2 = typename Curve::Fq2;
+  using W = Wire<Curve>;
 
   static void sizes(uint32_t what[4]) {
     what[0] = sizeof(Fr);
@@ -217,8 +218,12 @@ struct Api {
       const size_t psz = group == 1 ? sizeof(Affine<Fq>) : sizeof(Affine<Fq2>);
       DevBuf stage((n ? n : 1) * psz);
       if (n) ARK_CHECK_HIP(hipMemcpy(stage.p, bases, n * psz, hipMemcpyHostToDevice));
-      if (group == 1) precomp_build<Fq, Fr>(b->tab, stage.p, n, st);
-      else precomp_build<Fq2, Fr>(b->tab, stage.p, n, st);
+      const TableNeed need{n, 0, group == 2};
+      std::string why;
+      const uint32_t ws = table_stride_plan<Fq, Fq2, Fr>(&need, 1, table_budget_bytes((size_t)2 * 16 * 17 * n, true), &why);
+      if (ws == 0) throw HipError{ARK355_ENOMEM, "base set: " + why};
+      if (group == 1) precomp_build<Fq, Fr>(b->tab, stage.p, n, st, 0, ws);
+      else precomp_build<Fq2, Fr>(b->tab, stage.p, n, st, 0, ws);
     } catch (...) {
       delete b;
       throw;
@@ -310,6 +315,13 @@ struct Api {
     using P = typename Fr::Params;
     ARK_REQUIRE(ell >= 1, ARK355_EINVAL, "num_instance must include the constant One");
     const uint64_t m = ell + w;
+    // the three CSR matrices come from the caller: monotone row pointers, columns inside [0, ell + w)
+    for (int k = 0; k < 3; k++) {
+      ARK_REQUIRE(rp[k][0] == 0, ARK355_EINVAL, "CSR row_ptr must start at 0");
+      for (uint64_t i = 0; i < n; i++) ARK_REQUIRE(rp[k][i] <= rp[k][i + 1], ARK355_EINVAL, "CSR row_ptr is not monotone");
+      const uint64_t nnz = rp[k][n];
+      for (uint64_t t = 0; t < nnz; t++) ARK_REQUIRE(col[k][t] < m, ARK355_EINVAL, "CSR column index out of range");
+    }
     uint32_t lg = 0;
     while ((1ull << lg) < n + ell) lg++;
     ARK_REQUIRE(lg <= (uint32_t)P::TWO_ADICITY, ARK355_E_POLY_DEGREE_TOO_LARGE, "n + ell exceeds the largest radix-2 domain of Fr");
@@ -420,6 +432,17 @@ struct Api {
       memcpy(&a, p, sizeof(a));
       return a;
     };
+    // The raw entry point takes Montgomery images, not validated encodings: a point off the curve must not reach the
+    // affine Miller loop (its line functions never use the curve constant, (0, y) / y = 0 cases would divide by zero
+    // silently).  Three curve equations per proof on the host; subgroup membership is ark355_proof_from_bytes' job
+    // (ARK355_VALIDATE_FULL), as upstream splits it between deserialization and verification.
+    for (uint64_t j = 0; j < count; j++) {
+      const Affine<Fq> a = g1_of(proofs[j].a), c = g1_of(proofs[j].c);
+      const Affine<Fq2> b = g2_of(proofs[j].b);
+      if (!a.is_inf() && !(Fq::sqr_ni(a.y) == W::curve_rhs(a.x))) return false;
+      if (!c.is_inf() && !(Fq::sqr_ni(c.y) == W::curve_rhs(c.x))) return false;
+      if (!b.is_inf() && !(Fq2::sqr_ni(b.y) == W::curve_rhs(b.x))) return false;
+    }
     std::vector<Fr> r(count), coef(ell, Fr::zero());
     for (uint64_t j = 0; j < count; j++) {
       if (rho) {
@@ -483,22 +506,21 @@ struct Api {
   }
 
   // ---- ark-serialize wire formats (wire_impl.cuh) ------------------------------------------------------------------
-  using W = Wire<Curve>;
   static size_t point_size(int group, bool compressed) { return group == 1 ? W::g1_size(compressed) : W::g2_size(compressed); }
   static size_t raw_size(int group) { return group == 1 ? sizeof(Affine<Fq>) : sizeof(Affine<Fq2>); }
 
   // d_in: device byte stream of n encoded points -> d_out: n raw affine images (device).  Throws on a bad point.
-  static void decode_dev(int group, const uint8_t* d_in, uint64_t n, bool compressed, bool validate, void* d_out,
+  static void decode_dev(int group, const uint8_t* d_in, uint64_t n, bool compressed, int validate, void* d_out,
                          DevBuf& errbuf, hipStream_t st, const char* what) {
     if (n == 0) return;
     errbuf.ensure(8);
     ARK_CHECK_HIP(hipMemsetAsync(errbuf.p, 0, 8, st));
     const dim3 grid((uint32_t)((n + 127) / 128));
     if (group == 1)
-      ARK_LAUNCH((wire_decode_kernel<Curve, 1>), grid, dim3(128), 0, st, d_in, n, compressed ? 1 : 0, validate ? 1 : 0, d_out,
+      ARK_LAUNCH((wire_decode_kernel<Curve, 1>), grid, dim3(128), 0, st, d_in, n, compressed ? 1 : 0, validate, d_out,
                  errbuf.as<unsigned long long>());
     else
-      ARK_LAUNCH((wire_decode_kernel<Curve, 2>), grid, dim3(128), 0, st, d_in, n, compressed ? 1 : 0, validate ? 1 : 0, d_out,
+      ARK_LAUNCH((wire_decode_kernel<Curve, 2>), grid, dim3(128), 0, st, d_in, n, compressed ? 1 : 0, validate, d_out,
                  errbuf.as<unsigned long long>());
     ARK_CHECK_LAUNCH();
     unsigned long long e = 0;
@@ -509,7 +531,7 @@ struct Api {
   }
 
   static void points_decode(ark355_ctx* ctx, GenericScratch& g, int group, const uint8_t* in, uint64_t n, bool compressed,
-                            bool validate, uint8_t* out_raw) {
+                            int validate, uint8_t* out_raw) {
     hipStream_t st = ctx->stream;
     if (n == 0) return;
     g.a.ensure(n * point_size(group, compressed));
@@ -548,7 +570,7 @@ struct Api {
     W::g2_encode(b, compressed, out + W::g1_size(compressed));
     W::g1_encode(c, compressed, out + W::g1_size(compressed) + W::g2_size(compressed));
   }
-  static void proof_from_bytes(const uint8_t* in, uint64_t len, bool compressed, bool validate, ark355_proof_raw* out) {
+  static void proof_from_bytes(const uint8_t* in, uint64_t len, bool compressed, int validate, ark355_proof_raw* out) {
     ARK_REQUIRE(len == 2 * W::g1_size(compressed) + W::g2_size(compressed), ARK355_EINVAL, "bad proof length");
     Affine<Fq> a, c;
     Affine<Fq2> b;
@@ -565,7 +587,7 @@ struct Api {
   // ark_groth16::ProvingKey<E> stream (vk {alpha_g1, beta_g2, gamma_g2, delta_g2, gamma_abc_g1}, beta_g1, delta_g1,
   // a_query, b_g1_query, b_g2_query, h_query, l_query; Vec = u64 LE length + elements) -> resident key.  The host walks
   // the structure, the device decodes the points.
-  static PkDev* pk_load_bytes(ark355_ctx* ctx, const uint8_t* bytes, uint64_t len, bool compressed, bool validate) {
+  static PkDev* pk_load_bytes(ark355_ctx* ctx, const uint8_t* bytes, uint64_t len, bool compressed, int validate) {
     hipStream_t st = ctx->stream;
     const size_t s1 = W::g1_size(compressed), s2 = W::g2_size(compressed);
     uint64_t off = 0;

@@ -514,11 +514,11 @@ uint64_t ark355_point_size(int32_t curve, int32_t group, int32_t compressed) {
 
 int32_t ark355_pk_load_bytes(ark355_ctx* ctx, int32_t curve, const uint8_t* bytes, uint64_t len, int32_t compressed,
                              int32_t validate, ark355_pk** out) {
-  if (!ctx || !bytes || !out) return ARK355_EINVAL;
+  if (!ctx || !bytes || !out || validate < 0 || validate > 2) return ARK355_EINVAL;
   *out = nullptr;
   return guarded(ctx, [&] {
     PkDev* d = nullptr;
-    CURVE_DISPATCH(curve, d = A::pk_load_bytes(ctx, bytes, len, compressed != 0, validate != 0));
+    CURVE_DISPATCH(curve, d = A::pk_load_bytes(ctx, bytes, len, compressed != 0, validate));
     *out = new ark355_pk{d};
   });
 }
@@ -531,12 +531,23 @@ int32_t ark355_pk_dims(const ark355_pk* pk, uint64_t* num_instance, uint64_t* nu
   return ARK355_OK;
 }
 
+int32_t ark355_pk_table_info(const ark355_pk* pk, uint32_t* window_bits, uint32_t* windows, uint32_t* table_stride,
+                             uint64_t* table_bytes) {
+  if (!pk || !pk->d) return ARK355_EINVAL;
+  const MsmPlan& p = pk->d->a_ext.plan;
+  if (window_bits) *window_bits = p.c;
+  if (windows) *windows = p.windows;
+  if (table_stride) *table_stride = pk->d->wstride;
+  if (table_bytes) *table_bytes = pk->d->table_bytes();
+  return ARK355_OK;
+}
+
 int32_t ark355_points_decode(ark355_ctx* ctx, int32_t curve, int32_t group, const uint8_t* in, uint64_t n,
                              int32_t compressed, int32_t validate, uint8_t* out_raw) {
-  if (!ctx || (group != 1 && group != 2) || (n && (!in || !out_raw))) return ARK355_EINVAL;
+  if (!ctx || (group != 1 && group != 2) || (n && (!in || !out_raw)) || validate < 0 || validate > 2) return ARK355_EINVAL;
   return guarded(ctx, [&] {
     CtxExtra& ex = extra(ctx);
-    CURVE_DISPATCH(curve, A::points_decode(ctx, ex.generic, group, in, n, compressed != 0, validate != 0, out_raw));
+    CURVE_DISPATCH(curve, A::points_decode(ctx, ex.generic, group, in, n, compressed != 0, validate, out_raw));
   });
 }
 
@@ -556,8 +567,8 @@ int32_t ark355_proof_to_bytes(int32_t curve, const ark355_proof_raw* proof, int3
 
 int32_t ark355_proof_from_bytes(int32_t curve, const uint8_t* in, uint64_t len, int32_t compressed, int32_t validate,
                                 ark355_proof_raw* out) {
-  if (!in || !out) return ARK355_EINVAL;
-  return guarded(nullptr, [&] { CURVE_DISPATCH(curve, A::proof_from_bytes(in, len, compressed != 0, validate != 0, out)); });
+  if (!in || !out || validate < 0 || validate > 2) return ARK355_EINVAL;
+  return guarded(nullptr, [&] { CURVE_DISPATCH(curve, A::proof_from_bytes(in, len, compressed != 0, validate, out)); });
 }
 
 int32_t ark355_verify_batch(ark355_ctx* ctx, int32_t curve, const ark355_vk_desc* vk, const ark355_proof_raw* proofs,
@@ -578,10 +589,12 @@ int32_t ark355_setup_scalars(int32_t curve, uint64_t n, uint64_t ell, uint64_t w
                              const uint32_t* const col[3], const uint8_t* const coeff[3], const uint8_t* trapdoor,
                              uint8_t* out_u, uint8_t* out_v, uint8_t* out_w, uint8_t* out_l, uint8_t* out_gamma_abc,
                              uint8_t* out_h) {
-  if (!row_ptr || !col || !coeff || !trapdoor || !out_u || !out_v || !out_w || !out_l || !out_gamma_abc || !out_h)
+  // zero-length outputs may be NULL (l when num_witness == 0, h when the domain has one point)
+  if (!row_ptr || !col || !coeff || !trapdoor || !out_u || !out_v || !out_w || (w && !out_l) || !out_gamma_abc ||
+      (n + ell > 1 && !out_h))
     return ARK355_EINVAL;
   for (int i = 0; i < 3; i++)
-    if (!row_ptr[i] || !col[i] || !coeff[i]) return ARK355_EINVAL;
+    if (!row_ptr[i] || (row_ptr[i][n] && (!col[i] || !coeff[i]))) return ARK355_EINVAL;
   return guarded(nullptr, [&] {
     CURVE_DISPATCH(curve, A::setup_scalars(n, ell, w, row_ptr, col, coeff, trapdoor, out_u, out_v, out_w, out_l, out_gamma_abc, out_h));
   });

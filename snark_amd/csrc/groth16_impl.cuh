@@ -40,6 +40,10 @@ struct PkDev {
   uint32_t shard_index = 0, shard_count = 1;
   uint64_t z_lo = 0, z_cnt = 0;     // of the m+4 extended a/b/l terms
   uint64_t h_lo = 0, h_cnt = 0;     // of the N-1 h terms
+  uint32_t wstride = 1;             // MsmPlan::wstride of the five tables (1 = every window has its table)
+  uint64_t table_bytes() const {
+    return a_ext.table.bytes + b1_ext.table.bytes + b2_ext.table.bytes + h_query.table.bytes + l_ext.table.bytes;
+  }
 };
 
 static inline void shard_range(uint64_t total, uint32_t idx, uint32_t cnt, uint64_t* lo, uint64_t* n) {
@@ -268,22 +272,35 @@ static PkDev* pk_upload(const ark355_pk_desc* d, hipStream_t stream, uint32_t sh
     // every shard of a key uses the window size of the largest shard (see precomp_build)
     const uint64_t z_plan = shard_count > 1 ? (m + 4 + shard_count - 1) / shard_count : 0;
     const uint64_t h_plan = shard_count > 1 ? (hn + shard_count - 1) / shard_count : 0;
+    {
+      // Window stride of the five tables: 1 (a table per window) whenever that fits next to the scratch of the proving
+      // contexts that will work on this key (four of them: two sort areas of 16 B per (term, window), nine N-element NTT
+      // buffers / tables each), otherwise the smallest stride that does; ARK355_ENOMEM when not even the bare vectors fit.
+      const TableNeed need[5] = {{pk->z_cnt, z_plan, false}, {pk->z_cnt, z_plan, false}, {pk->z_cnt, z_plan, true},
+                                 {pk->h_cnt, h_plan, false}, {pk->z_cnt, z_plan, false}};
+      const size_t scratch = 4 * ((size_t)16 * 17 * (pk->z_cnt + pk->h_cnt) + (size_t)9 * 32 * pk->N);
+      std::string why;
+      pk->wstride = table_stride_plan<Fq, Fq2, Fr>(need, 5, table_budget_bytes(scratch, shard_count == 1), &why);
+      if (pk->wstride == 0) throw HipError{ARK355_ENOMEM, "proving key: " + why};
+    }
+    const uint32_t ws = pk->wstride;
     ext(d->a_query, G1, d->alpha_g1, d->delta_g1, nullptr);
-    precomp_build<Fq, Fr>(pk->a_ext, (uint8_t*)stage.p + pk->z_lo * G1, pk->z_cnt, stream, z_plan);
+    precomp_build<Fq, Fr>(pk->a_ext, (uint8_t*)stage.p + pk->z_lo * G1, pk->z_cnt, stream, z_plan, ws);
     ext(d->b_g1_query, G1, d->beta_g1, nullptr, d->delta_g1);
-    precomp_build<Fq, Fr>(pk->b1_ext, (uint8_t*)stage.p + pk->z_lo * G1, pk->z_cnt, stream, z_plan);
+    precomp_build<Fq, Fr>(pk->b1_ext, (uint8_t*)stage.p + pk->z_lo * G1, pk->z_cnt, stream, z_plan, ws);
     ext(d->b_g2_query, G2, d->beta_g2, nullptr, d->delta_g2);
-    precomp_build<Fq2, Fr>(pk->b2_ext, (uint8_t*)stage.p + pk->z_lo * G2, pk->z_cnt, stream, z_plan);
+    precomp_build<Fq2, Fr>(pk->b2_ext, (uint8_t*)stage.p + pk->z_lo * G2, pk->z_cnt, stream, z_plan, ws);
     stage.ensure((pk->h_cnt ? pk->h_cnt : 1) * G1);
     if (pk->h_cnt) ARK_CHECK_HIP(hipMemcpy(stage.p, d->h_query + pk->h_lo * G1, pk->h_cnt * G1, hipMemcpyDefault));
-    precomp_build<Fq, Fr>(pk->h_query, stage.p, pk->h_cnt, stream, h_plan);
+    precomp_build<Fq, Fr>(pk->h_query, stage.p, pk->h_cnt, stream, h_plan, ws);
     // l_ext aligned with zx: ell leading infinities (instance variables carry no l term), l_query, delta_1 at
     // the -rs slot, three trailing infinities
     stage.ensure((m + 4) * G1);
     ARK_CHECK_HIP(hipMemset(stage.p, 0, (m + 4) * G1));
     if (pk->w) ARK_CHECK_HIP(hipMemcpy((uint8_t*)stage.p + pk->ell * G1, d->l_query, pk->w * G1, hipMemcpyDefault));
     ARK_CHECK_HIP(hipMemcpy((uint8_t*)stage.p + m * G1, d->delta_g1, G1, hipMemcpyHostToDevice));
-    precomp_build<Fq, Fr>(pk->l_ext, (uint8_t*)stage.p + pk->z_lo * G1, pk->z_cnt, stream, z_plan);
+    precomp_build<Fq, Fr>(pk->l_ext, (uint8_t*)stage.p + pk->z_lo * G1, pk->z_cnt, stream, z_plan, ws);
+    stage.release();
   } catch (...) {
     delete pk;
     throw;

@@ -60,7 +60,13 @@ struct MsmPlan {
   // loaded; MI355X has the HBM for it), so every window shares ONE bucket set and the c*w doublings of the
   // window combination disappear from the per-proof path.
   bool precomp = false;
-  uint32_t key_windows = 0;     // bucket sets: 1 with precomp, `windows` without
+  // Window tables may hold only every wstride-th window (T[q*n + i] = 2^(c*wstride*q) * P_i, q < table_windows): a key
+  // whose full tables would not fit HBM trades table rows for bucket sets.  Window w = wstride*q + j then reads table
+  // row q and lands in bucket set j; the sets are combined as sum_j 2^(c*j) S_j (msm_combine_kernel), i.e. c*(wstride-1)
+  // doublings per MSM come back.  wstride = 1: one bucket set, no doubling at all (the default whenever it fits);
+  // without tables wstride = windows (every window its own set, every value indexes the base vector itself).
+  uint32_t wstride = 1, table_windows = 0;
+  uint32_t key_windows = 0;     // bucket sets: wstride with precomp, `windows` without
   // Scalars above (r - 1) / 2 are replaced by r - k with every digit's sign flipped (k P = (r - k)(-P)): the values
   // that remain are one bit shorter, which saves a whole window exactly when c divides the scalar width -- c = 17 for
   // 255-bit scalars: 15 windows instead of 16.  Derived from c alone, so a table and the MSMs over it always agree.
@@ -101,7 +107,7 @@ static inline uint32_t msm_seg_len(uint64_t entries, bool pair_lanes) {
 
 struct MsmPlan;
 static inline int msm_digit_flags(const MsmPlan& p);
-inline MsmPlan msm_plan(uint64_t n, uint32_t scalar_bits, bool precomp = false, int force_c = 0) {
+inline MsmPlan msm_plan(uint64_t n, uint32_t scalar_bits, bool precomp = false, int force_c = 0, uint32_t force_stride = 0) {
   MsmPlan p;
   p.n = n;
   p.precomp = precomp;
@@ -147,15 +153,17 @@ inline MsmPlan msm_plan(uint64_t n, uint32_t scalar_bits, bool precomp = false, 
     p.windows = (scalar_bits + p.c - 1) / p.c;
   }
   p.buckets_per_window = 1u << (p.c - 1);
-  p.key_windows = precomp ? 1u : p.windows;
+  p.wstride = precomp ? (force_stride ? force_stride : 1u) : p.windows;
+  if (p.wstride > p.windows) p.wstride = p.windows;
+  p.table_windows = precomp ? (p.windows + p.wstride - 1) / p.wstride : 0u;
+  p.key_windows = p.wstride;
   p.total_buckets = p.key_windows * p.buckets_per_window;
   return p;
 }
 
-static inline int msm_digit_flags(const MsmPlan& p) { return (p.precomp ? 1 : 0) | (p.negate_high ? 2 : 0); }
-
-// `precomp` of the digit kernels is a bit set: bit 0 = window tables (one bucket set, values index table rows),
-// bit 1 = MsmPlan::negate_high
+// `precomp` argument of the digit kernels: bit 0 = window tables, bit 1 = MsmPlan::negate_high, bits 8.. = wstride
+// (window w -> bucket set w % wstride, table row block w / wstride)
+static inline int msm_digit_flags(const MsmPlan& p) { return (p.precomp ? 1 : 0) | (p.negate_high ? 2 : 0) | (int)(p.wstride << 8); }
 constexpr int MSM_DIGITS_PRECOMP = 1, MSM_DIGITS_NEGATE_HIGH = 2;
 
 // k (canonical) > (r - 1) / 2: replace it by r - k and report it
@@ -224,11 +232,12 @@ msm_digits_kernel(const Fr* __restrict__ scalars, uint32_t n, int mont, uint32_t
   const bool in_range = i < n;                     // no early return: the wave-level primitives need every lane
   Fr k = in_range ? scalars[i] : Fr::zero();
   if (mont) k = Fr::from_mont(k);
-  const int precomp = precomp_flags & MSM_DIGITS_PRECOMP;
+  const uint32_t wstride = (uint32_t)precomp_flags >> 8;
   const uint32_t flip = ((precomp_flags & MSM_DIGITS_NEGATE_HIGH) && msm_negate_if_high(k)) ? 1u : 0u;
   const uint32_t B = 1u << (c - 1);
   const uint32_t full = 1u << c;
   uint32_t carry = 0;
+  uint32_t q = 0, j = 0;                              // w = wstride * q + j
   for (uint32_t w = 0; w < windows; w++) {
     const uint32_t bit = w * c;
     const uint32_t limb = bit >> 5, off = bit & 31;
@@ -249,13 +258,17 @@ msm_digits_kernel(const Fr* __restrict__ scalars, uint32_t n, int mont, uint32_t
     }
     const uint64_t e = (uint64_t)w * n + i;
     const bool valid = in_range && d != 0;
-    // precomp: one shared bucket set, the value indexes the window's table row
-    const uint32_t key = valid ? (precomp ? (d - 1) : (w * B + d - 1)) : MSM_INVALID;
+    // bucket set j, table row block q (window tables: table_stride rows per block; none: table_stride = 0)
+    const uint32_t key = valid ? (j * B + d - 1) : MSM_INVALID;
     if (in_range) {
       keys[e] = key;
-      vals[e] = valid ? ((precomp ? (w * table_stride + i) : i) | ((neg ^ flip) << 31)) : 0u;
+      vals[e] = valid ? ((q * table_stride + i) | ((neg ^ flip) << 31)) : 0u;
     }
     (void)wave_agg_inc(counts, valid ? key : 0u, valid);
+    if (++j == wstride) {
+      j = 0;
+      q++;
+    }
   }
 }
 
@@ -377,11 +390,12 @@ template <class Fr, class Fn>
 ARK_D void msm_for_each_digit(Fr k, int mont, uint32_t i, uint32_t n, uint32_t c, uint32_t windows, int precomp_flags,
                               uint32_t table_stride, Fn&& fn) {
   if (mont) k = Fr::from_mont(k);
-  const int precomp = precomp_flags & MSM_DIGITS_PRECOMP;
+  const uint32_t wstride = (uint32_t)precomp_flags >> 8;
   const uint32_t flip = ((precomp_flags & MSM_DIGITS_NEGATE_HIGH) && msm_negate_if_high(k)) ? 1u : 0u;
   const uint32_t B = 1u << (c - 1);
   const uint32_t full = 1u << c;
   uint32_t carry = 0;
+  uint32_t q = 0, j = 0;                              // w = wstride * q + j: bucket set j, table row block q
   for (uint32_t w = 0; w < windows; w++) {
     const uint32_t bit = w * c;
     const uint32_t limb = bit >> 5, off = bit & 31;
@@ -401,9 +415,13 @@ ARK_D void msm_for_each_digit(Fr k, int mont, uint32_t i, uint32_t n, uint32_t c
       carry = 0;
     }
     if (d != 0) {
-      const uint32_t key = precomp ? (d - 1) : (w * B + d - 1);
-      const uint32_t val = (precomp ? (w * table_stride + i) : i) | ((neg ^ flip) << 31);
+      const uint32_t key = j * B + d - 1;
+      const uint32_t val = (q * table_stride + i) | ((neg ^ flip) << 31);
       fn(w, key, val);
+    }
+    if (++j == wstride) {
+      j = 0;
+      q++;
     }
   }
 }
@@ -1219,59 +1237,156 @@ static inline bool msm_use_limb28(bool g2) {       // read when a table is built
   return e ? (e[0] == '1') : (ARK_LIMB28_DEFAULT != 0);
 }
 
+// ---- HBM footprint of window tables -------------------------------------------------------------------------------------
+// Full tables (every window) are W x the key: 16 x 128-byte rows per G1 base at c = 16, i.e. 15 GB for a 2^20-constraint
+// BLS12-381 key, 60 GB at 2^22, ~120 GB at 2^23 and more than one MI355X holds at 2^24.  table_row_bytes / the planner
+// below pick the smallest window stride (MsmPlan::wstride) whose tables fit the budget, so that such a key still loads
+// -- with every second (third, ...) window's table and that many bucket sets -- instead of failing in hipMalloc.
+template <class F>
+static inline size_t table_row_bytes(bool limb28) {
+  if (!limb28) return sizeof(Affine<F>);
+  if constexpr (is_fp2<F>::value) return sizeof(Affine28G2<typename F::Base::Params>);
+  else return sizeof(Affine28<typename F::Params>);
+}
+
+struct TableNeed {          // one base vector of a key
+  uint64_t n;               // rows per window block
+  uint64_t plan_n;          // length the window size is planned for (shards: the largest shard)
+  bool g2;
+};
+
+// HBM budget for the resident tables of ONE key / base set: ARK355_HBM_BUDGET_MB (tests, A/B) or 80 % of the device
+// minus a reserve for the proving contexts' scratch (`scratch_bytes`, the caller's estimate); `use_free`: also stay
+// inside what is free right now (whole keys; the shards of one key plan from the device size alone so that every rank
+// reaches the same stride -- the bucket-level exchange adds bucket arrays of different ranks).
+static inline size_t table_budget_bytes(size_t scratch_bytes, bool use_free) {
+  if (const char* e = getenv("ARK355_HBM_BUDGET_MB")) {
+    const long long v = atoll(e);
+    if (v > 0) return (size_t)v << 20;
+  }
+#if defined(ARK_EMUL)
+  (void)scratch_bytes;
+  (void)use_free;
+  return ~(size_t)0 >> 1;
+#else
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || total_b == 0) return ~(size_t)0 >> 1;
+  size_t budget = total_b / 5 * 4;
+  if (use_free && free_b < budget) budget = free_b;
+  return budget > scratch_bytes ? budget - scratch_bytes : 0;
+#endif
+}
+
+// smallest stride whose tables (all vectors resident + the two-window staging area of the one being built) fit `budget`;
+// 0 when not even the bare base vectors do
+template <class Fq, class Fq2, class Fr>
+static inline uint32_t table_stride_plan(const TableNeed* need, int count, size_t budget, std::string* why) {
+  if (const char* e = getenv("ARK355_TABLE_STRIDE")) {       // tests / A/B: force a stride
+    const int v = atoi(e);
+    if (v >= 1 && v <= 64) return (uint32_t)v;
+  }
+  uint32_t max_windows = 1;
+  for (uint32_t s = 1;; s++) {
+    size_t resident = 0, stage = 0;
+    for (int i = 0; i < count; i++) {
+      const MsmPlan p = msm_plan(need[i].n, Fr::Params::BITS, true,
+                                 need[i].plan_n ? (int)msm_plan(need[i].plan_n, Fr::Params::BITS, true).c : 0, s);
+      if (p.windows > max_windows) max_windows = p.windows;
+      const bool l28 = msm_use_limb28(need[i].g2) && !msm_use_batch_affine(need[i].g2);
+      const size_t row = need[i].g2 ? table_row_bytes<Fq2>(l28) : table_row_bytes<Fq>(l28);
+      const size_t aff = need[i].g2 ? sizeof(Affine<Fq2>) : sizeof(Affine<Fq>);
+      const size_t xyzz = need[i].g2 ? sizeof(XYZZ<Fq2>) : sizeof(XYZZ<Fq>);
+      resident += (size_t)p.table_windows * need[i].n * row;
+      const size_t st = need[i].n * (2 * aff + xyzz);
+      if (st > stage) stage = st;
+    }
+    if (resident + stage <= budget) return s;
+    if (s >= max_windows) {
+      if (why)
+        *why = "window tables do not fit HBM: " + std::to_string((resident + stage) >> 20) + " MiB needed even with one table window, budget " +
+               std::to_string(budget >> 20) + " MiB";
+      return 0;
+    }
+  }
+}
+
 // plan_n: the length the window size is chosen for (0 = n).  The shards of one key pass the LARGEST shard length so
 // that every rank uses the same window size -- the bucket-level exchange adds bucket arrays of different ranks.
+// wstride: MsmPlan::wstride (from table_stride_plan).
 template <class F, class Fr>
-static void precomp_build(PrecompTable& t, const void* d_bases, uint64_t n, hipStream_t stream, uint64_t plan_n = 0) {
+static void precomp_build(PrecompTable& t, const void* d_bases, uint64_t n, hipStream_t stream, uint64_t plan_n = 0,
+                          uint32_t wstride = 1) {
   t.n = n;
   t.plan = msm_plan(n, Fr::Params::BITS, /*precomp=*/true,
-                    plan_n ? (int)msm_plan(plan_n, Fr::Params::BITS, /*precomp=*/true).c : 0);
+                    plan_n ? (int)msm_plan(plan_n, Fr::Params::BITS, /*precomp=*/true).c : 0, wstride);
   const MsmPlan& p = t.plan;
-  ARK_REQUIRE((uint64_t)p.windows * n < (1ull << 31), ARK355_EINVAL, "window table too large for 31-bit indices");
+  const uint32_t TW = p.table_windows;
+  ARK_REQUIRE((uint64_t)TW * n < (1ull << 31), ARK355_EINVAL, "window table too large for 31-bit indices");
   if (getenv("ARK355_TRACE_HOST"))
-    fprintf(stderr, "[ark355] window table: %llu bases, c = %u, %u windows%s\n", (unsigned long long)n, p.c, p.windows,
-            p.negate_high ? ", scalars above (r - 1) / 2 negated" : "");
-  t.table.alloc((size_t)p.windows * (n ? n : 1) * sizeof(Affine<F>));
-  if (n == 0) return;
-  ARK_CHECK_HIP(hipMemcpyAsync(t.table.p, d_bases, n * sizeof(Affine<F>), hipMemcpyDeviceToDevice, stream));
-  DevBuf tmp(n * sizeof(XYZZ<F>));
-  Affine<F>* T = t.table.as<Affine<F>>();
+    fprintf(stderr, "[ark355] window table: %llu bases, c = %u, %u windows (%u table blocks, %u bucket sets)%s\n",
+            (unsigned long long)n, p.c, p.windows, TW, p.key_windows, p.negate_high ? ", scalars above (r - 1) / 2 negated" : "");
+  const bool ba = msm_use_batch_affine(is_fp2<F>::value) && p.wstride == 1;
+  const bool l28 = !ba && msm_use_limb28(is_fp2<F>::value);
   const uint32_t grid = (uint32_t)((n + MSM_THREADS - 1) / MSM_THREADS);
   const uint32_t gridb = (uint32_t)(((n + PRE_K - 1) / PRE_K + MSM_THREADS - 1) / MSM_THREADS);
-  for (uint32_t w = 1; w < p.windows; w++) {
-    ARK_LAUNCH((precomp_shift_kernel<F>), dim3(grid), dim3(MSM_THREADS), 0, stream, (const Affine<F>*)(T + (size_t)(w - 1) * n),
-               tmp.as<XYZZ<F>>(), (uint32_t)n, p.c);
-    ARK_CHECK_LAUNCH();
-    ARK_LAUNCH((batch_to_affine_kernel<F>), dim3(gridb), dim3(MSM_THREADS), 0, stream, (const XYZZ<F>*)tmp.as<XYZZ<F>>(),
-               T + (size_t)w * n, (uint32_t)n);
-    ARK_CHECK_LAUNCH();
-  }
-  ARK_CHECK_HIP(hipStreamSynchronize(stream));     // tmp is freed on return
-  if (msm_use_batch_affine(is_fp2<F>::value)) {
-    t.batch_affine = true;
+  const uint32_t shift = p.c * p.wstride;              // consecutive table blocks differ by 2^(c * wstride)
+  if (!l28) {
+    // canonical affine rows are the final form: blocks are built in place, one after the other
+    t.table.alloc((size_t)TW * (n ? n : 1) * sizeof(Affine<F>));
+    if (n == 0) return;
+    ARK_CHECK_HIP(hipMemcpyAsync(t.table.p, d_bases, n * sizeof(Affine<F>), hipMemcpyDeviceToDevice, stream));
+    DevBuf tmp(n * sizeof(XYZZ<F>));
+    Affine<F>* T = t.table.as<Affine<F>>();
+    for (uint32_t w = 1; w < TW; w++) {
+      ARK_LAUNCH((precomp_shift_kernel<F>), dim3(grid), dim3(MSM_THREADS), 0, stream, (const Affine<F>*)(T + (size_t)(w - 1) * n),
+                 tmp.as<XYZZ<F>>(), (uint32_t)n, shift);
+      ARK_CHECK_LAUNCH();
+      ARK_LAUNCH((batch_to_affine_kernel<F>), dim3(gridb), dim3(MSM_THREADS), 0, stream, (const XYZZ<F>*)tmp.as<XYZZ<F>>(),
+                 T + (size_t)w * n, (uint32_t)n);
+      ARK_CHECK_LAUNCH();
+    }
+    ARK_CHECK_HIP(hipStreamSynchronize(stream));     // tmp is freed on return
+    t.batch_affine = ba;
     return;
   }
-  if (msm_use_limb28(is_fp2<F>::value)) {
-    // re-encode the finished table for the 28-bit accumulation kernels; the 32-bit rows are dropped
-    const uint64_t rows = (uint64_t)p.windows * n;
-    const dim3 grid28((uint32_t)((rows + 255) / 256));
-    DevBuf t28;
+  // radix-2^28 rows (msm28_impl.cuh): the canonical form of a block only lives in a two-block staging area while the
+  // next block is derived from it; each finished block is re-encoded straight into the final table.  (The first version
+  // built the whole canonical table first: 75 % more HBM at the peak than the key keeps -- what a 2^23-constraint key
+  // cannot spare.)
+  const size_t row = table_row_bytes<F>(true);
+  t.table.alloc((size_t)TW * (n ? n : 1) * row);
+  t.limb28 = true;
+  if (n == 0) return;
+  DevBuf stage[2] = {DevBuf(n * sizeof(Affine<F>)), DevBuf(n * sizeof(Affine<F>))};
+  DevBuf tmp(n * sizeof(XYZZ<F>));
+  const dim3 grid28((uint32_t)((n + 255) / 256));
+  auto encode = [&](const DevBuf& src, uint32_t w) {
+    uint8_t* dst = t.table.as<uint8_t>() + (size_t)w * n * row;
     if constexpr (is_fp2<F>::value) {
       using P = typename F::Base::Params;
-      t28.alloc(rows * sizeof(Affine28G2<P>));
-      ARK_LAUNCH((table_to28_g2_kernel<P>), grid28, dim3(256), 0, stream, (const Affine<F>*)T,
-                 t28.as<Affine28G2<P>>(), rows);
+      ARK_LAUNCH((table_to28_g2_kernel<P>), grid28, dim3(256), 0, stream, (const Affine<F>*)src.as<Affine<F>>(),
+                 reinterpret_cast<Affine28G2<P>*>(dst), n);
     } else {
       using P = typename F::Params;
-      t28.alloc(rows * sizeof(Affine28<P>));
-      ARK_LAUNCH((table_to28_kernel<P>), grid28, dim3(256), 0, stream, (const Affine<F>*)T,
-                 t28.as<Affine28<P>>(), rows);
+      ARK_LAUNCH((table_to28_kernel<P>), grid28, dim3(256), 0, stream, (const Affine<F>*)src.as<Affine<F>>(),
+                 reinterpret_cast<Affine28<P>*>(dst), n);
     }
     ARK_CHECK_LAUNCH();
-    ARK_CHECK_HIP(hipStreamSynchronize(stream));
-    t.table = std::move(t28);
-    t.limb28 = true;
+  };
+  ARK_CHECK_HIP(hipMemcpyAsync(stage[0].p, d_bases, n * sizeof(Affine<F>), hipMemcpyDeviceToDevice, stream));
+  encode(stage[0], 0);
+  for (uint32_t w = 1; w < TW; w++) {
+    DevBuf& prev = stage[(w - 1) & 1];
+    DevBuf& cur = stage[w & 1];
+    ARK_LAUNCH((precomp_shift_kernel<F>), dim3(grid), dim3(MSM_THREADS), 0, stream, (const Affine<F>*)prev.as<Affine<F>>(),
+               tmp.as<XYZZ<F>>(), (uint32_t)n, shift);
+    ARK_CHECK_LAUNCH();
+    ARK_LAUNCH((batch_to_affine_kernel<F>), dim3(gridb), dim3(MSM_THREADS), 0, stream, (const XYZZ<F>*)tmp.as<XYZZ<F>>(),
+               cur.as<Affine<F>>(), (uint32_t)n);
+    ARK_CHECK_LAUNCH();
+    encode(cur, w);
   }
+  ARK_CHECK_HIP(hipStreamSynchronize(stream));     // staging buffers are freed on return
 }
 
 // ---- host driver ---------------------------------------------------------------------------------------------
@@ -1288,7 +1403,7 @@ static void msm_sort(ark355_ctx* ctx, MsmSort& s, const void* d_scalars, uint64_
   const bool precomp = tab != nullptr;
   if (tab) ARK_REQUIRE(n <= tab->n, ARK355_EINVAL, "more scalars than table rows");
   // with window tables the window size is the one the tables were built for
-  s.plan = msm_plan(n, Fr::Params::BITS, precomp, tab ? (int)tab->plan.c : 0);
+  s.plan = msm_plan(n, Fr::Params::BITS, precomp, tab ? (int)tab->plan.c : 0, tab ? tab->plan.wstride : 0);
   const uint32_t stride = tab ? (uint32_t)tab->n : 0;
   const MsmPlan& p = s.plan;
   const uint64_t entries = (uint64_t)p.windows * n;

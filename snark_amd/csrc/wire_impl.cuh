@@ -18,14 +18,48 @@
 
 namespace ark355 {
 
-enum WireStatus : int { WIRE_OK = 0, WIRE_NOT_REDUCED = 1, WIRE_NOT_ON_CURVE = 2, WIRE_BAD_FLAGS = 3 };
+enum WireStatus : int { WIRE_OK = 0, WIRE_NOT_REDUCED = 1, WIRE_NOT_ON_CURVE = 2, WIRE_BAD_FLAGS = 3, WIRE_NOT_IN_SUBGROUP = 4 };
+// `validate` of the decoders (include/ark355.h ARK355_VALIDATE_*): 0 = none, 1 = everything ark-serialize's Validate::Yes
+// checks (canonical flags, on the curve, in the prime-order subgroup), 2 = flags and curve only -- the explicit opt-out
+// for key material from a trusted source (the subgroup test is a 255-bit scalar multiplication per point)
+constexpr int WIRE_VALIDATE_NONE = 0, WIRE_VALIDATE_FULL = 1, WIRE_VALIDATE_CURVE = 2;
 
 template <class Curve>
 struct Wire {
   using Fq = typename Curve::Fq;
   using Fq2 = typename Curve::Fq2;
+  using Fr = typename Curve::Fr;
   using K = typename Curve::Consts;
   static constexpr bool BLS = Curve::ID == ARK355_BLS12_381;
+  static constexpr bool G1_HAS_COFACTOR = BLS;             // BN254's G1 is the whole curve group (cofactor 1)
+
+  // [r] P == O: membership in the prime-order subgroup (`is_in_correct_subgroup_assuming_on_curve` upstream).  Points of
+  // small order pair to 1, so a proof carrying one would still verify: many encodings per proof for callers that key
+  // on proof bytes.
+  template <class F>
+  ARK_HD static bool in_subgroup(const Affine<F>& p) {
+    uint32_t r[Fr::N];
+    for (int i = 0; i < Fr::N; i++) r[i] = Fr::Params::mod(i);
+    return xyzz_mul_scalar(XYZZ<F>::from_affine(p), r, Fr::N).is_inf();
+  }
+  // every payload bit of an encoding whose infinity flag is set must be zero (flag bits masked)
+  ARK_HD static bool payload_is_zero(const uint8_t* in, size_t size) {
+    uint8_t acc = 0;
+    for (size_t i = 0; i < size; i++) {
+      uint8_t v = in[i];
+      if (i == 0) v &= FIRST_MASK;
+      if (i == size - 1) v &= LAST_MASK;
+      acc |= v;
+    }
+    return acc == 0;
+  }
+  // Flag combinations upstream refuses whatever the validation mode: ark-bls12-381 EncodingFlags::get_flags (the sort
+  // bit needs the compressed bit and excludes infinity; the compressed bit must match the requested form),
+  // ark-ec SWFlags::from_u8 (both bits set is no flag value).
+  ARK_HD static bool flags_ok(bool compressed, bool inf, bool sign, bool cbit) {
+    if (BLS) return cbit == compressed && !(sign && (!compressed || inf));
+    return !(inf && sign);
+  }
   static constexpr int NB = Fq::N * 4;                     // bytes per base-field element
 
   ARK_HD static Fq g1_b() {
@@ -164,12 +198,13 @@ struct Wire {
     }
   }
 
-  ARK_HD static int g1_decode(const uint8_t* in, bool compressed, bool validate, Affine<Fq>* out) {
+  ARK_HD static int g1_decode(const uint8_t* in, bool compressed, int validate, Affine<Fq>* out) {
     const size_t size = g1_size(compressed);
     bool inf, sign, cbit;
     read_flags(in, size, &inf, &sign, &cbit);
-    if (BLS && cbit != compressed) return WIRE_BAD_FLAGS;
+    if (!flags_ok(compressed, inf, sign, cbit)) return WIRE_BAD_FLAGS;
     if (inf) {
+      if (validate && !payload_is_zero(in, size)) return WIRE_BAD_FLAGS;
       *out = Affine<Fq>::inf();
       return WIRE_OK;
     }
@@ -188,15 +223,17 @@ struct Wire {
       if (validate && !(Fq::sqr_ni(y) == curve_rhs(x))) return WIRE_NOT_ON_CURVE;
     }
     *out = Affine<Fq>{x, y};
+    if (G1_HAS_COFACTOR && validate == WIRE_VALIDATE_FULL && !in_subgroup(*out)) return WIRE_NOT_IN_SUBGROUP;
     return WIRE_OK;
   }
 
-  ARK_HD static int g2_decode(const uint8_t* in, bool compressed, bool validate, Affine<Fq2>* out) {
+  ARK_HD static int g2_decode(const uint8_t* in, bool compressed, int validate, Affine<Fq2>* out) {
     const size_t size = g2_size(compressed);
     bool inf, sign, cbit;
     read_flags(in, size, &inf, &sign, &cbit);
-    if (BLS && cbit != compressed) return WIRE_BAD_FLAGS;
+    if (!flags_ok(compressed, inf, sign, cbit)) return WIRE_BAD_FLAGS;
     if (inf) {
+      if (validate && !payload_is_zero(in, size)) return WIRE_BAD_FLAGS;
       *out = Affine<Fq2>::inf();
       return WIRE_OK;
     }
@@ -220,6 +257,7 @@ struct Wire {
       if (validate && !(Fq2::sqr_ni(y) == curve_rhs(x))) return WIRE_NOT_ON_CURVE;
     }
     *out = Affine<Fq2>{x, y};
+    if (validate == WIRE_VALIDATE_FULL && !in_subgroup(*out)) return WIRE_NOT_IN_SUBGROUP;
     return WIRE_OK;
   }
 
@@ -277,11 +315,11 @@ wire_decode_kernel(const uint8_t* __restrict__ in, uint64_t n, int compressed, i
   int st;
   if constexpr (GROUP == 1) {
     Affine<typename Curve::Fq> p = Affine<typename Curve::Fq>::inf();
-    st = W::g1_decode(in + i * W::g1_size(compressed != 0), compressed != 0, validate != 0, &p);
+    st = W::g1_decode(in + i * W::g1_size(compressed != 0), compressed != 0, validate, &p);
     reinterpret_cast<Affine<typename Curve::Fq>*>(out)[i] = p;
   } else {
     Affine<typename Curve::Fq2> p = Affine<typename Curve::Fq2>::inf();
-    st = W::g2_decode(in + i * W::g2_size(compressed != 0), compressed != 0, validate != 0, &p);
+    st = W::g2_decode(in + i * W::g2_size(compressed != 0), compressed != 0, validate, &p);
     reinterpret_cast<Affine<typename Curve::Fq2>*>(out)[i] = p;
   }
   if (st != WIRE_OK) {
@@ -315,6 +353,7 @@ static inline const char* wire_status_name(int st) {
     case WIRE_NOT_REDUCED: return "coordinate not reduced";
     case WIRE_NOT_ON_CURVE: return "point not on curve";
     case WIRE_BAD_FLAGS: return "bad flag bits";
+    case WIRE_NOT_IN_SUBGROUP: return "point not in the prime-order subgroup";
     default: return "ok";
   }
 }

@@ -475,6 +475,15 @@ class Groth16 {
           const auto& inner = cs.borrow();
           const size_t zi = inner.instance_assignment.size(), zw = inner.witness_assignment.size();
           Item it{i, take_buf(zi + zw)};
+          // the page-locked buffer goes back to the backend's pool unless the queue takes it over (a failing batch must
+          // not leak pinned host memory)
+          struct Return {
+            decltype(give_buf)& give;
+            Item* it;
+            ~Return() {
+              if (it) give(it->z);
+            }
+          } guard{give_buf, &it};
           std::memcpy(it.z.p, inner.instance_assignment.data(), zi * sizeof(Fr));       // z = instance || witness
           std::memcpy(it.z.p + zi, inner.witness_assignment.data(), zw * sizeof(Fr));
           it.z.n = zi + zw;
@@ -482,6 +491,7 @@ class Groth16 {
           std::unique_lock<std::mutex> lk(mu);
           cv_not_full.wait(lk, [&] { return queue.size() < cap || failed; });
           if (failed) break;
+          guard.it = nullptr;
           queue.push_back(std::move(it));
           cv_not_empty.notify_one();
         }

@@ -71,3 +71,55 @@ def test_large_size_checks_on_the_emulator(emul_lib, emul_ctx):
     O.check_witness_map_full(emul_lib, emul_ctx, BLS12_381, S.mulchain_csr(BLS12_381.r, 61))
     O.check_instance(emul_lib, emul_ctx, BLS12_381, S.mulchain_csr(BLS12_381.r, 33), [(9, 11)], sharded=True,
                      python_pairing=True)
+
+
+@pytest.mark.parametrize("stride", ["2", "3", "16"])
+def test_strided_window_tables_on_the_emulator(emul_lib, emul_ctx, monkeypatch, stride):
+    """MsmPlan::wstride (the fallback for keys whose full window tables do not fit HBM): tables for every s-th window,
+    s bucket sets combined as sum_j 2^(c j) S_j.  s = 2, 3 (does not divide the window count) and 16 >= windows (no
+    table beyond the bases themselves); resident MSMs against oracle/c for both groups and whole proofs -- incl.
+    ark355_prove_sharded with the bucket-level ring -- against cbase.prove."""
+    monkeypatch.setenv("ARK355_TABLE_STRIDE", stride)
+
+    def to_dev(b):
+        a = np.frombuffer(b, dtype=np.uint8).copy()
+        return a.ctypes.data, a
+
+    O.check_resident_msm(emul_lib, emul_ctx, BLS12_381, 1, 1100, to_dev, seed=21)     # c = 8: 32 windows
+    O.check_resident_msm(emul_lib, emul_ctx, BN254, 2, 150, to_dev, seed=22)          # c = 4: 64 windows
+    if stride == "3":
+        O.check_instance(emul_lib, emul_ctx, BLS12_381, S.mulchain_csr(BLS12_381.r, 300), [(5, 7)], sharded=True,
+                         equation=False)
+
+
+def test_table_budget_picks_a_stride_or_reports_enomem(emul_lib, emul_ctx, monkeypatch):
+    """The planner behind ark355_pk_load: with a budget below the full tables the key still loads with the smallest
+    stride that fits (ark355_pk_table_info shows it) and proves the same bytes; with a budget below the bare vectors the
+    load fails with ARK355_ENOMEM and a message, not a HIP error."""
+    from oracle.c import cbase
+    from snark_amd._binding import Ark355Error, ENOMEM
+    C = BLS12_381
+    inst = S.mulchain_csr(C.r, 600)
+    n, ell, w, mats, z = inst
+    pk, _ = cbase.setup_raw_c(C, n, ell, w, mats, O.TD)
+    pkh, rh = O.load(emul_lib, emul_ctx, C, inst, pk)
+    full = emul_lib.pk_table_info(pkh)
+    O.free(emul_lib, pkh, rh)
+    assert full["table_stride"] == 1 and full["windows"] * full["window_bits"] >= 256
+    monkeypatch.setenv("ARK355_HBM_BUDGET_MB", str(max(1, (full["table_bytes"] // 3) >> 20)))
+    pkh, rh = O.load(emul_lib, emul_ctx, C, inst, pk)
+    try:
+        info = emul_lib.pk_table_info(pkh)
+        assert info["table_stride"] > 1 and info["table_bytes"] < full["table_bytes"] // 2
+        zb = S._mont_bytes(C.r, z)
+        got = emul_lib.prove(emul_ctx, pkh, rh, zb, len(z), O.Z.fr_canon(C, 3), O.Z.fr_canon(C, 4), emul_lib.sizes(C.curve_id))
+        assert got == cbase.prove(C, n, ell, w, mats, zb, pk, 3, 4)
+    finally:
+        O.free(emul_lib, pkh, rh)
+    monkeypatch.setenv("ARK355_HBM_BUDGET_MB", "1")
+    big = S.mulchain_csr(C.r, 5000)
+    n2, ell2, w2, mats2, z2 = big
+    pk2, _ = cbase.setup_raw_c(C, n2, ell2, w2, mats2, O.TD)
+    with pytest.raises(Ark355Error) as e:
+        O.load(emul_lib, emul_ctx, C, big, pk2)
+    assert e.value.code == ENOMEM and "do not fit" in str(e.value)

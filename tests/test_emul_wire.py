@@ -14,3 +14,8 @@ def test_point_codecs(emul_lib, emul_ctx, C):
                          ids=["bls-uncompressed", "bls-compressed", "bn-compressed"])
 def test_key_stream_to_proof_bytes(emul_lib, emul_ctx, C, compressed):
     W.key_stream_case(emul_lib, emul_ctx, C, n=12, compressed=compressed)
+
+
+@pytest.mark.parametrize("C", [BLS12_381, BN254], ids=lambda c: c.name)
+def test_validation_modes(emul_lib, emul_ctx, C):
+    W.validation_case(emul_lib, emul_ctx, C)

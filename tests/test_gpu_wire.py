@@ -17,3 +17,10 @@ def test_point_codecs(gpu_lib, gpu_ctx, C):
                          ids=["bls-uncompressed", "bls-compressed", "bn-uncompressed", "bn-compressed"])
 def test_key_stream_to_proof_bytes(gpu_lib, gpu_ctx, C, compressed):
     W.key_stream_case(gpu_lib, gpu_ctx, C, n=150, compressed=compressed)
+
+
+@pytest.mark.parametrize("C", [BLS12_381, BN254], ids=lambda c: c.name)
+def test_validation_modes(gpu_lib, gpu_ctx, C):
+    """Validate::Yes semantics on the device decoders and on the proof path: subgroup membership, canonical infinity,
+    flag combinations (tests/wire_cases.py)."""
+    W.validation_case(gpu_lib, gpu_ctx, C)
