@@ -136,8 +136,21 @@ def pmc_traffic(n, curve):
         return None, None
 
 
+_T0 = time.perf_counter()
+
+
+def stage(msg):
+    """progress marker on stderr (stdout carries the one JSON line only)"""
+    sys.stderr.write("[bench %7.1f s] %s\n" % (time.perf_counter() - _T0, msg))
+    sys.stderr.flush()
+
+
 def main():
     args = parse_args()
+    wd = os.environ.get("ARK355_BENCH_WATCHDOG")
+    if wd:                                   # diagnostic: dump every thread's Python stack and exit if the run takes longer
+        import faulthandler
+        faulthandler.dump_traceback_later(float(wd), exit=True)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args))
     rank = int(os.environ.get("RANK", "0"))
@@ -176,6 +189,7 @@ def main():
     import random
 
     shard = args.mode == "shard"
+    stage("start: rank %d of %d" % (rank, world))
     cv = params.CURVES[args.curve]
     n = (1 << args.log_n) - (100 if args.tight else 0)
     t_prep = time.perf_counter()
@@ -185,7 +199,9 @@ def main():
     seed = 0x355 + (0 if shard else rank)
     r1, z = synthetic.mulchain(cv, n, seed=seed)
     rnd = random.Random(seed)
+    stage("statement built (n = %d)" % n)
     pk, vk = g.circuit_specific_setup(r1, lambda: rnd.randrange(1, cv.r), keep_trapdoor=not args.no_check)
+    stage("key generated")
     sg = None
     if shard:
         from snark_amd.parallel import ShardedGroth16, SHARD_BUCKET_RING, SHARD_WINDOW
@@ -212,6 +228,7 @@ def main():
         z_dev = torch.from_numpy(np.frombuffer(zb, dtype=np.uint8).copy()).cuda()     # z resident in HBM
     dev_sync()
     prep_s = time.perf_counter() - t_prep
+    stage("key, matrices and z resident")
 
     # Throughput mode: `inflight` independent proving contexts (own streams and scratch) share the resident key and
     # CSR handles; while one proof is in its serial head (sort) or tail (last bucket reduction, O(1) host finish)
@@ -270,6 +287,7 @@ def main():
         return results
 
     run(max(1, -(-args.warmup // len(ctxs))) if args.warmup else 0, None, per_worker=True)
+    stage("warm-up done")
     # The harness keeps the assignment as a list of 2^20 Python ints (for the closed-form check) next to other large
     # containers; a full cyclic-GC pass over them costs ~24 ms and fired once per timed region (seen with
     # ARK355_BENCH_TRACE=1: one call of 56 ms among calls of 32 ms, while the library's own timer showed 32 ms for all).
@@ -291,6 +309,7 @@ def main():
     dt = time.perf_counter() - t0
     host_cpu_s = time.process_time() - cpu0          # CPU time of all threads of this rank over the timed region
     thr1 = thread_cpu_times()
+    stage("timed region done: %.2f ms per step" % (dt / args.steps * 1e3))
     by_comm = {}
     for key, t1_ in thr1.items():
         d_ = t1_ - thr0.get(key, 0.0)
@@ -322,8 +341,9 @@ def main():
     # memory, median of >= 5 single proofs, H2D of z included.  Outside the timed region, rank 0's GPU only; page-locked
     # (ark355_host_alloc) and pageable host buffers, next to the device-resident reading of the same loop; then the
     # in-flight throughput of the timed region repeated from host buffers.
+    stage("single-stream reading done")
     latency = None
-    if rank == 0 and not emul:
+    if rank == 0 and (not emul or os.environ.get('ARK355_BENCH_EMUL_LATENCY')):
         import ctypes
         ptr = ctypes.c_void_p()
         assert g.lib.dll.ark355_host_alloc(len(zb), ctypes.byref(ptr)) == 0
@@ -356,6 +376,7 @@ def main():
                                             "note": "the timed region repeated with every proof reading z from host memory"}}
         latency["constraints_per_s_single_proof_host_pinned_z"] = n / (latency["host_pinned_z_ms"] * 1e-3)
         g.lib.dll.ark355_host_free(ptr)
+        stage("latency / host-z readings done")
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=xdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -371,6 +392,7 @@ def main():
             if int(f.item()) != 0:
                 parity = "MISMATCH"
         assert parity != "MISMATCH", "proof differs from the closed form"
+    stage("parity: %s (%d proofs)" % (parity, len(results)))
 
     if rank == 0:
         N = r1.domain_size

@@ -149,10 +149,11 @@ def check_resident_msm(lib, ctx, C, group, n, to_dev, seed=1):
 
 def check_ntt_full(lib, ctx, C, log_n, seed=5):
     """ark355_ntt_fr vs cb_ntt, four modes, whole vectors (Montgomery images in and out on both sides)."""
-    rnd = random.Random(seed * 100 + log_n)
     n = 1 << log_n
-    raw = np.frombuffer(rnd.randbytes(32 * n), dtype="<u8").reshape(n, 4).copy()
-    raw[:, 3] &= (1 << (C.r.bit_length() - 1 - 192)) - 1                 # < 2^(bits-1) < r: valid residues
+    rng = np.random.default_rng(seed * 100 + log_n)
+    raw = rng.integers(0, 1 << 63, size=(n, 4), dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, size=(n, 4), dtype=np.uint64)
+    raw[:, 3] &= np.uint64((1 << (C.r.bit_length() - 1 - 192)) - 1)      # < 2^(bits-1) < r: valid residues
+    raw = raw.astype("<u8")
     data = raw.tobytes()
     for inv, cos in ((0, 0), (1, 0), (0, 1), (1, 1)):
         got = lib.ntt(ctx, C.curve_id, data, log_n, inv, cos)
