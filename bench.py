@@ -253,6 +253,7 @@ def main():
         return Proof(a, b, c)
 
     trace = [] if os.environ.get("ARK355_BENCH_TRACE") else None
+    worker_cpu = [0.0]                   # CPU seconds of the proving threads (they are created and joined per run())
 
     def run(nsteps, record, per_worker=False, z_host=None):
         # per_worker: every context proves `nsteps` times (warm-up must touch each context's scratch and streams)
@@ -261,9 +262,11 @@ def main():
         results = []
 
         def worker(ctx):
+            cpu_a = time.thread_time()
             while True:
                 with lock:
                     if not todo or (per_worker and quota[id(ctx)] == 0):
+                        worker_cpu[0] += time.thread_time() - cpu_a      # the thread is gone when /proc is read
                         return
                     quota[id(ctx)] -= 1
                     r_, s_ = todo.pop()
@@ -300,6 +303,7 @@ def main():
         dist.barrier()
     dev_sync()
     thr0 = thread_cpu_times()
+    worker_cpu[0] = 0.0
     cpu0 = time.process_time()
     t0 = time.perf_counter()
     results = run(args.steps, rec)
@@ -310,12 +314,11 @@ def main():
     host_cpu_s = time.process_time() - cpu0          # CPU time of all threads of this rank over the timed region
     thr1 = thread_cpu_times()
     stage("timed region done: %.2f ms per step" % (dt / args.steps * 1e3))
-    by_comm = {}
-    for key, t1_ in thr1.items():
-        d_ = t1_ - thr0.get(key, 0.0)
-        if d_ > 0:
-            by_comm[key[1]] = by_comm.get(key[1], 0.0) + d_
-    host_cpu_threads = {k: round(v / dt, 3) for k, v in sorted(by_comm.items(), key=lambda kv: -kv[1])[:8]} if dt > 0 else {}
+    resident = sum(max(0.0, t1_ - thr0.get(key, 0.0)) for key, t1_ in thr1.items())
+    # where the cores go: the proving threads (launches, event polling, result copies), the threads that live through the
+    # region (main thread, the HIP runtime's own), and what is left: short-lived native threads (the O(1) proof tail)
+    host_cpu_threads = {"proving_threads": round(worker_cpu[0] / dt, 3), "resident_threads": round(resident / dt, 3),
+                        "short_lived_native_threads": round(max(0.0, host_cpu_s - worker_cpu[0] - resident) / dt, 3)} if dt > 0 else {}
     if trace is not None and rank == 0:
         tl = sorted(trace)[-args.steps:]
         sys.stderr.write("[bench] timed region: t0 -> first call %.2f ms; calls (start, duration ms): %s; last return -> end %.2f ms\n" % (

@@ -58,7 +58,11 @@ static inline void shard_range(uint64_t total, uint32_t idx, uint32_t cnt, uint6
 // those are the cores the synthesis threads of an end-to-end prover and the other ranks of a multi-GPU node need.  A proof
 // takes tens of milliseconds, so the proving thread polls the event and sleeps 100 us in between.  ARK355_WAIT_SPIN=1
 // hands the wait back to the runtime.
-static inline void wait_event_polite(hipEvent_t ev) {
+// expect_ms: how long proofs of this shape took to drain on this context lately (0 = unknown).  The thread sleeps through
+// most of that in ONE go before it starts polling: a 2^20 proof with four in flight is ~95 ms of waiting, i.e. ~900 polls
+// at 100 us, each a runtime call -- a fifth of a host core per proof in flight that the synthesis threads of an end-to-end
+// prover and the other ranks of a node need (bench.py host_cpu_threads).
+static inline void wait_event_polite(hipEvent_t ev, double expect_ms = 0.0, bool* overslept = nullptr) {
   static const bool spin = [] {
     const char* e = getenv("ARK355_WAIT_SPIN");
     return e && e[0] == '1';
@@ -67,15 +71,38 @@ static inline void wait_event_polite(hipEvent_t ev) {
     ARK_CHECK_HIP(hipEventSynchronize(ev));
     return;
   }
-  for (;;) {
+  if (overslept) *overslept = false;
+  const bool slept = expect_ms > 0.5;
+  if (slept) std::this_thread::sleep_for(std::chrono::microseconds((long long)(expect_ms * 1000.0)));
+  for (bool first = true;; first = false) {
     const hipError_t e = hipEventQuery(ev);
-    if (e == hipSuccess) return;
+    if (e == hipSuccess) {
+      if (overslept) *overslept = slept && first;
+      return;
+    }
     if (e != hipErrorNotReady) ARK_CHECK_HIP(e);
     std::this_thread::sleep_for(std::chrono::microseconds(100));
   }
 }
 
 struct ProverScratch {
+  // Estimate of the drain time (all work queued -> last event) of proofs of one shape on this context.  The wait sleeps
+  // through 3/4 of it before polling (wait_event_polite); a wait that found the event already complete when it woke up
+  // halves the estimate instead of trusting the (sleep-dominated) reading, so a context that goes from four proofs in
+  // flight to one re-converges within two proofs.
+  double drain_est_ms = 0.0;
+  uint64_t drain_shape = 0;
+  double drain_hint(uint64_t shape) const {
+    static const bool adapt = [] {                  // ARK355_WAIT_ADAPT=0: poll from the start (A/B)
+      const char* e = getenv("ARK355_WAIT_ADAPT");
+      return !(e && e[0] == '0');
+    }();
+    return (adapt && shape == drain_shape) ? 0.75 * drain_est_ms : 0.0;
+  }
+  void drain_record(uint64_t shape, double ms, bool overslept) {
+    drain_est_ms = (overslept && shape == drain_shape) ? 0.5 * drain_est_ms : ms;
+    drain_shape = shape;
+  }
   // one sort per distinct scalar vector (zx for A/B1/B2/L', h for H) and one bucket set per MSM: the five MSMs of
   // a proof are in flight together on separate streams (sized for 288 GB of HBM, not for reuse)
   MsmSort sortZ, sortH;
@@ -511,8 +538,11 @@ static void prove_run(ark355_ctx* ctx, ProverScratch& sc, const PkDev& pk, const
       ARK_CHECK_HIP(hipMemcpyAsync(land, g1res, sizeof(h1) + sizeof(h2), hipMemcpyDeviceToHost, sR));
       ARK_CHECK_HIP(hipEventRecord(ev[E_END], sR));
       t_launched = since(t_enter);
-      wait_event_polite(ev[E_END]);
+      const uint64_t shape = (pk.N << 8) ^ (pk.m << 1) ^ (uint64_t)Curve::ID;
+      bool overslept = false;
+      wait_event_polite(ev[E_END], sc.drain_hint(shape), &overslept);
       t_synced = since(t_enter);
+      sc.drain_record(shape, t_synced - t_launched, overslept);
       memcpy(h1, land, sizeof(h1));
       memcpy(&h2, land + sizeof(h1), sizeof(h2));
       finalize_host<Curve>(h1, h2, rc, scn, out);

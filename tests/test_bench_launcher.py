@@ -46,3 +46,18 @@ def test_bench_refuses_a_world_size_that_contradicts_gpus():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dry-run-emul", "--gpus", "2"],
                        capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
     assert r.returncode != 0 and "--gpus 2 but the launcher started 1 ranks" in r.stderr
+
+
+@pytest.mark.parametrize("mode", ["replica", "shard"])
+def test_bench_gpus_8_ranks(mode):
+    """The driver's 8-GPU launch shape on CPU: eight ranks (one per GPU), one JSON line from rank 0, whole-job value.
+    Replica: eight independent proof streams, no collective on the data path; shard: ONE proof whose MSM term ranges are
+    spread over the eight ranks, exchanged through the (emulated) RCCL behind the C ABI."""
+    extra = ["--gpus", "8", "--steps", "1", "--warmup", "1"]
+    if mode == "shard":
+        extra += ["--mode", "shard", "--log-n", "7"]
+    d = _run(*extra)
+    assert d["n_gpus"] == 8 and d["steps"] == 1
+    assert d["parity"] == "proof == trapdoor closed form"
+    assert d["scaling"] == ("strong" if mode == "shard" else "weak")
+    assert ("msm-shard x8" if mode == "shard" else "replicas x8") in d["config"]["parallelism"]
