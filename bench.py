@@ -466,6 +466,8 @@ def main():
             "msm_g1_mscalar_mul_per_s": (N - 1) / (world if shard else 1) / (tim["msm_h_ms"] * 1e-3) / 1e6 if tim["msm_h_ms"] > 0 else None,
             "msm_g2_mscalar_mul_per_s": (m + 4) / (world if shard else 1) / (tim["msm_b_g2_ms"] * 1e-3) / 1e6 if tim["msm_b_g2_ms"] > 0 else None,
             "prep_s": prep_s,
+            # how the resident key sits in HBM (window size, windows, table stride, bytes of its five window tables)
+            "key_tables": g.lib.pk_table_info(pkh if pkh is not None else sg.load_pk_shard(pk)),
         }
         if not args.no_cpu_baseline and world == 1 and not emul:
             out["cpu_baseline"] = cpu_baseline(args.curve)

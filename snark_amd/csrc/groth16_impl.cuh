@@ -85,6 +85,9 @@ static inline void wait_event_polite(hipEvent_t ev, double expect_ms = 0.0, bool
   }
 }
 
+// small proofs (N < 2^20) poll from the start: with eight 2^18 proofs in flight the long sleep cost 4 % (profiles/r03_epilogue_ab.txt)
+static inline bool epi_sleep_ok(uint64_t domain) { return domain >= (1ull << 20); }
+
 struct ProverScratch {
   // Estimate of the drain time (all work queued -> last event) of proofs of one shape on this context.  The wait sleeps
   // through 3/4 of it before polling (wait_event_polite); a wait that found the event already complete when it woke up
@@ -120,6 +123,7 @@ struct ProverScratch {
   }
   ~ProverScratch() {
     release_pinned();
+    release_stage();
     for (hipStream_t st : {sW, sS, sA, sR})
       if (st) (void)hipStreamDestroy(st);
     for (auto& e : events)
@@ -135,6 +139,24 @@ struct ProverScratch {
   // the stream has run, i.e. for the whole proof (profiles/r02_host_wait.txt: one host core per proof in flight).
   void* h_pinned = nullptr;
   size_t h_pinned_bytes = 0;
+  // page-locked staging area of the proof's small H2D copies (tail scalars, r, s): from pageable memory (the stack) such a
+  // copy is not asynchronous either -- the runtime stages it and waits for the stream
+  void* h_stage = nullptr;
+  static constexpr size_t STAGE_BYTES = 1024;
+  void* stage() {
+    if (!h_stage) {
+#if defined(ARK_EMUL)
+      h_stage = malloc(STAGE_BYTES);
+      if (!h_stage) throw HipError{ARK355_ENOMEM, "host allocation failed"};
+#else
+      if (hipHostMalloc(&h_stage, STAGE_BYTES, hipHostMallocDefault) != hipSuccess) {
+        h_stage = nullptr;
+        throw HipError{ARK355_ENOMEM, "hipHostMalloc failed"};
+      }
+#endif
+    }
+    return h_stage;
+  }
   void* pinned(size_t bytes) {
     if (bytes > h_pinned_bytes) {
       release_pinned();
@@ -160,6 +182,15 @@ struct ProverScratch {
 #endif
     h_pinned = nullptr;
     h_pinned_bytes = 0;
+  }
+  void release_stage() {
+    if (!h_stage) return;
+#if defined(ARK_EMUL)
+    free(h_stage);
+#else
+    (void)hipHostFree(h_stage);
+#endif
+    h_stage = nullptr;
   }
 };
 
@@ -415,8 +446,13 @@ static void prove_run(ark355_ctx* ctx, ProverScratch& sc, const PkDev& pk, const
 
     ARK_CHECK_HIP(hipEventRecord(ev[E_START], sM));
     ARK_CHECK_HIP(hipMemcpyAsync(sc.zx.p, z_src, m * sizeof(Fr), z_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, sM));
-    ARK_CHECK_HIP(hipMemcpyAsync((uint8_t*)sc.zx.p + m * sizeof(Fr), tail, sizeof(tail), hipMemcpyHostToDevice, sM));
-    ARK_CHECK_HIP(hipMemcpyAsync(sc.rs.p, rs_c, sizeof(rs_c), hipMemcpyHostToDevice, sM));
+    // (the previous proof of this context has drained: its staging area is free)
+    static_assert(sizeof(tail) + sizeof(rs_c) <= ProverScratch::STAGE_BYTES, "staging area too small");
+    uint8_t* stg = static_cast<uint8_t*>(sc.stage());
+    memcpy(stg, tail, sizeof(tail));
+    memcpy(stg + sizeof(tail), rs_c, sizeof(rs_c));
+    ARK_CHECK_HIP(hipMemcpyAsync((uint8_t*)sc.zx.p + m * sizeof(Fr), stg, sizeof(tail), hipMemcpyHostToDevice, sM));
+    ARK_CHECK_HIP(hipMemcpyAsync(sc.rs.p, stg + sizeof(tail), sizeof(rs_c), hipMemcpyHostToDevice, sM));
     ARK_CHECK_HIP(hipEventRecord(ev[E_Z], sM));
 
     // witness map -> h
@@ -540,7 +576,7 @@ static void prove_run(ark355_ctx* ctx, ProverScratch& sc, const PkDev& pk, const
       t_launched = since(t_enter);
       const uint64_t shape = (pk.N << 8) ^ (pk.m << 1) ^ (uint64_t)Curve::ID;
       bool overslept = false;
-      wait_event_polite(ev[E_END], sc.drain_hint(shape), &overslept);
+      wait_event_polite(ev[E_END], epi_sleep_ok(pk.N) ? sc.drain_hint(shape) : 0.0, &overslept);
       t_synced = since(t_enter);
       sc.drain_record(shape, t_synced - t_launched, overslept);
       memcpy(h1, land, sizeof(h1));
@@ -548,10 +584,33 @@ static void prove_run(ark355_ctx* ctx, ProverScratch& sc, const PkDev& pk, const
       finalize_host<Curve>(h1, h2, rc, scn, out);
       t_tail = since(t_enter);
     }
-    // every stream has drained into sR through the event chain; make the host view consistent
-    ARK_CHECK_HIP(hipStreamSynchronize(sA));
-    ARK_CHECK_HIP(hipStreamSynchronize(sS));
-    ARK_CHECK_HIP(hipStreamSynchronize(sW));
+    // Every stream has drained into sR through the event chain: E_END completes only after the last event of sW (E_H),
+    // sS (E_SORT2) and sA (E_ACC_DONE0 + 4); nothing else is queued on them.  The prover used to call hipStreamSynchronize
+    // on the three streams here.  That is NOT free: HIP streams share a handful of hardware queues, and a synchronise on
+    // an idle stream of this proof waits -- spinning -- for the other proofs' kernels in the same queue: 22 and 82 ms in
+    // two of six traced 2^20 proofs with four in flight (profiles/r03_host_cpu.txt), i.e. 0.3 host cores per proof in
+    // flight and as many milliseconds in which the proving thread cannot start its next proof.  Measured, same box
+    // (profiles/r03_epilogue_ab.txt): without them 2^20 x 4 in flight runs 23.9 instead of 24.7 ms per proof on 0.8 instead
+    // of 1.5 host cores -- but 2^18 x 8 in flight runs 10.8 instead of 8.5 ms (the spinning threads evidently keep the
+    // runtime's dependency handling prompt when eight short proofs are in flight; not understood further).  So: large
+    // proofs check the three events (complete by construction), small ones keep the synchronises.
+    // ARK355_EPILOGUE_SYNC=0|1 forces either behaviour (A/B).
+    static const int epi_force = [] {
+      const char* e = getenv("ARK355_EPILOGUE_SYNC");
+      return e ? (e[0] == '1' ? 1 : 0) : -1;
+    }();
+    const bool epi_sync = epi_force >= 0 ? epi_force == 1 : pk.N < (1ull << 20);
+    if (epi_sync) {
+      ARK_CHECK_HIP(hipStreamSynchronize(sA));
+      ARK_CHECK_HIP(hipStreamSynchronize(sS));
+      ARK_CHECK_HIP(hipStreamSynchronize(sW));
+    } else {
+      for (hipEvent_t last : {ev[E_ACC_DONE0 + 4], ev[E_SORT2], ev[E_H]}) {
+        const hipError_t q = hipEventQuery(last);
+        if (q == hipErrorNotReady) wait_event_polite(last);
+        else if (q != hipSuccess) ARK_CHECK_HIP(q);
+      }
+    }
     auto el = [&](hipEvent_t a, hipEvent_t b) {
       float ms = 0;
       (void)hipEventElapsedTime(&ms, a, b);

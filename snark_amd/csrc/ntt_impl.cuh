@@ -33,6 +33,9 @@ namespace ark355 {
 constexpr uint32_t NTT_EMAX_LOG = ARK_NTT_EMAX_LOG;
 constexpr uint32_t NTT_RMAX_LOG = ARK_NTT_RMAX_LOG;
 constexpr uint32_t NTT_THREADS = 256;
+#ifndef ARK_NTT_WAVES
+#define ARK_NTT_WAVES 3       // waves per SIMD the pass kernels' register budget is sized for (3: 168 VGPRs, 2: 256)
+#endif
 // Direct inter-pass twiddle tables up to 2^23 entries (256 MiB each; MI355X has the HBM for it).  The kernel is bound by
 // the integer multiplier, so a 32-byte table read per element (+50 % of that pass's traffic) is cheaper than the second
 // multiplication of the hi/lo composition: the FIRST pass of a 2^21-point transform has a table of 2^21 entries.
@@ -215,7 +218,6 @@ ARK_D void ntt_first_pos(const NttGeo& geo, uint32_t tid, uint32_t (&pos)[8]) {
 }
 
 struct NttPassArgs {
-  uint32_t pair_store;   // host switch (ARK355_NTT_PAIR_STORE); the kernel still checks that its pairs are adjacent
   const void* in;        // Fr*
   void* out;
   uint32_t log_n, s_log, p_log;
@@ -267,22 +269,10 @@ ARK_D void ntt_out_pos(const NttGeo& geo, uint32_t tid, uint32_t s_log, uint32_t
   }
 }
 
-// Do the two lanes of a pair (tid, tid ^ 1) write ADJACENT elements in every slot?  (ntt_out_pos: yes when the pass
-// output is contiguous in k -- first pass, s = 1 -- or in c with at least two columns per tile.)
-ARK_D bool ntt_pair_adjacent(const NttGeo& geo, uint32_t s_log, uint32_t r_log) {
-  if (geo.nt < 2) return false;
-  return s_log < geo.p_log ? (s_log == 0 && r_log >= 1) : geo.p_log >= 1;
-}
-
 // inter-pass twiddle w^(s p k) from the direct table (when the pass has one) and store.
-// pair_store: the 32-byte element of a lane goes out as two 16-byte instructions; with every lane storing its own two
-// halves, each instruction of a wave touches only HALF of every 32-byte sector it covers (rocprofv3 WRITE_SIZE read
-// 1.56 x the vector per pass, profiles/r02_final_pmc_summary.txt).  When the two lanes of a pair hold adjacent elements
-// E, E' they swap a half each (four DPP moves): instruction 1 then writes E.lo | E.hi, instruction 2 E'.lo | E'.hi --
-// whole sectors per instruction.  ARK355_NTT_PAIR_STORE=0 keeps the plain stores (A/B).
 template <class Fr, int R_LOG>
 ARK_D void ntt_store_outputs(NttLane<Fr>& v, const NttPassArgs& a, const uint32_t (&kout)[8], const uint32_t (&cout)[8],
-                             uint64_t pq0, bool active, bool pair_store) {
+                             uint64_t pq0, bool active) {
   if (!active) return;
   Fr* out = reinterpret_cast<Fr*>(a.out);
   const uint64_t s_mask = (1ull << a.s_log) - 1ull;
@@ -292,25 +282,6 @@ ARK_D void ntt_store_outputs(NttLane<Fr>& v, const NttPassArgs& a, const uint32_
       const uint64_t p = (pq0 + cout[i]) >> a.s_log;
       v.x[i] = Fr::mul(v.x[i], reinterpret_cast<const Fr*>(a.direct)[(p << R_LOG) | kout[i]]);
     }
-  }
-  if (pair_store) {
-    const bool odd = (threadIdx.x & 1u) != 0;
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-      const uint64_t pq = pq0 + cout[i];
-      const uint64_t q = pq & s_mask, p = pq >> a.s_log;
-      uint4* own = reinterpret_cast<uint4*>(out + (q + ((p * (1u << R_LOG) + kout[i]) << a.s_log)));
-      const uint32_t* l = v.x[i].l;
-      uint32_t rcv[4];
-#pragma unroll
-      for (int d = 0; d < 4; d++) rcv[d] = ark_pair_xchg(odd ? l[d] : l[4 + d]);     // even sends hi, odd sends lo
-      const uint4 first = odd ? make_uint4(rcv[0], rcv[1], rcv[2], rcv[3]) : make_uint4(l[0], l[1], l[2], l[3]);
-      const uint4 second = odd ? make_uint4(l[4], l[5], l[6], l[7]) : make_uint4(rcv[0], rcv[1], rcv[2], rcv[3]);
-      // even lane (element E at own): E.lo -> own[0], E'.lo -> own[2];  odd lane (E' at own): E.hi -> own[-1], E'.hi -> own[1]
-      own[odd ? -1 : 0] = first;
-      own[odd ? 1 : 2] = second;
-    }
-    return;
   }
 #pragma unroll
   for (int i = 0; i < 8; i++) {
@@ -322,7 +293,7 @@ ARK_D void ntt_store_outputs(NttLane<Fr>& v, const NttPassArgs& a, const uint32_
 
 // One pass.  grid = N / (R P) tiles, NTT_THREADS lanes, dynamic LDS = exchange buffer (R P x 16 B) + twiddles (R/2 x 32 B)
 template <class Fr, int R_LOG>
-__global__ void __launch_bounds__(NTT_THREADS, 3)
+__global__ void __launch_bounds__(NTT_THREADS, ARK_NTT_WAVES)
 ntt_pass_kernel(const NttPassArgs a) {
   ARK_DYN_SMEM(uint4, lds);
   const uint32_t tid = threadIdx.x;
@@ -344,7 +315,7 @@ ntt_pass_kernel(const NttPassArgs a) {
   uint32_t opos[8], kout[8], cout[8];
   ntt_out_pos<R_LOG>(geo, tid, a.s_log, opos, kout, cout);
   ntt_exchange<Fr>(v, xbuf, pos, opos, active);
-  ntt_store_outputs<Fr, R_LOG>(v, a, kout, cout, pq0, active, a.pair_store && ntt_pair_adjacent(geo, a.s_log, R_LOG));
+  ntt_store_outputs<Fr, R_LOG>(v, a, kout, cout, pq0, active);
 }
 
 // The seam of inverse NTT -> coset NTT in one kernel: LAST pass of the first transform (stride N/R), the factor
@@ -353,7 +324,7 @@ ntt_pass_kernel(const NttPassArgs a) {
 //   a  : arguments of the last pass (its output scaling fields are ignored)
 //   b  : arguments of the first pass (its `in` is ignored; tw / direct / w tables / out belong to the second transform)
 template <class Fr, int R_LOG>
-__global__ void __launch_bounds__(NTT_THREADS, 3)       // 56 KiB of LDS per workgroup: three per CU
+__global__ void __launch_bounds__(NTT_THREADS, ARK_NTT_WAVES)       // 56 KiB of LDS per workgroup: three per CU
 ntt_seam_kernel(const NttPassArgs a, const NttPassArgs b, const Fr* __restrict__ seam) {
   ARK_DYN_SMEM(uint4, lds);
   const uint32_t tid = threadIdx.x;
@@ -395,7 +366,7 @@ ntt_seam_kernel(const NttPassArgs a, const NttPassArgs b, const Fr* __restrict__
   uint32_t opos[8], kout[8], cout[8];
   ntt_out_pos<R_LOG>(geo, tid, b.s_log, opos, kout, cout);
   ntt_exchange<Fr>(v, xbuf, npos, opos, active);
-  ntt_store_outputs<Fr, R_LOG>(v, b, kout, cout, pq0, active, b.pair_store && ntt_pair_adjacent(geo, b.s_log, R_LOG));
+  ntt_store_outputs<Fr, R_LOG>(v, b, kout, cout, pq0, active);
 }
 
 // ---- host side -----------------------------------------------------------------------------------
@@ -600,14 +571,6 @@ static inline std::vector<uint32_t> ntt_radices(uint32_t log_n) {
   return r;
 }
 
-static inline uint32_t ntt_pair_store_enabled() {
-  static const uint32_t on = [] {
-    const char* e = getenv("ARK355_NTT_PAIR_STORE");
-    return (e && e[0] == '0') ? 0u : 1u;
-  }();
-  return on;
-}
-
 template <class Fr, int R_LOG>
 static void ntt_launch_pass(const NttPassArgs& a, hipStream_t stream) {
   const uint32_t grid = 1u << (a.log_n - R_LOG - a.p_log);
@@ -741,7 +704,6 @@ static void* ntt_run(ark355_ctx* ctx, void* data, void* scratch, uint32_t log_n,
   for (size_t pass = 0; pass < radices.size(); pass++) {
     const uint32_t r = radices[pass];
     NttPassArgs a{};
-    a.pair_store = ntt_pair_store_enabled();
     a.in = src;
     a.out = dst;
     a.log_n = log_n;
@@ -787,7 +749,6 @@ static void* ntt_inverse_then_coset(ark355_ctx* ctx, void* data, void* scratch, 
   auto make = [&](bool inverse, size_t pass, uint32_t s_log) {
     const uint32_t r = radices[pass];
     NttPassArgs a{};
-    a.pair_store = ntt_pair_store_enabled();
     a.log_n = log_n;
     a.s_log = s_log;
     a.p_log = ntt_p_log(log_n, r);

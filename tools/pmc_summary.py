@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Aggregate rocprofv3 --pmc counter_collection CSVs per kernel (dev tool; run on the GPU box).
 
-usage: pmc_summary.py [--json OUT.json] [--workload TEXT]
+usage: pmc_summary.py [--json OUT.json] [--workload TEXT] [--recorded TEXT]
 Reads gpurun_out/prof_fetch and gpurun_out/prof_write (two separate passes: FETCH_SIZE, WRITE_SIZE).
 Counter unit: KiB.  With --json also writes the per-launch figures of the dominant kernel
 (msm_accumulate_kernel) that bench.py reports as `roofline.traffic`."""
@@ -26,7 +26,8 @@ for (k, c), (n, v) in sorted(agg.items(), key=lambda x: (x[0][1], -x[1][1])):
 if "--json" in sys.argv:
     out = sys.argv[sys.argv.index("--json") + 1]
     wl = sys.argv[sys.argv.index("--workload") + 1] if "--workload" in sys.argv else ""
-    rec = {"workload": wl, "unit": "KiB", "kernels": {}}
+    recorded = sys.argv[sys.argv.index("--recorded") + 1] if "--recorded" in sys.argv else ""
+    rec = {"workload": wl, "recorded": recorded, "unit": "KiB", "kernels": {}}
     for (k, c), (n, v) in agg.items():
         rec["kernels"].setdefault(k, {})[c] = {"dispatches": n, "sum_kib": v}
     acc = {c: [0, 0.0] for c in ("FETCH_SIZE", "WRITE_SIZE")}
