@@ -89,22 +89,38 @@ static inline void wait_event_polite(hipEvent_t ev, double expect_ms = 0.0, bool
 static inline bool epi_sleep_ok(uint64_t domain) { return domain >= (1ull << 20); }
 
 struct ProverScratch {
-  // Estimate of the drain time (all work queued -> last event) of proofs of one shape on this context.  The wait sleeps
-  // through 3/4 of it before polling (wait_event_polite); a wait that found the event already complete when it woke up
-  // halves the estimate instead of trusting the (sleep-dominated) reading, so a context that goes from four proofs in
-  // flight to one re-converges within two proofs.
-  double drain_est_ms = 0.0;
+  // Drain times (all work queued -> last event) of the last four proofs of one shape on this context.  The wait sleeps
+  // through HALF of the shortest of them before polling (wait_event_polite): with several proofs in flight consecutive
+  // drains of one context differ by 2x (46 .. 107 ms in one trace), and a thread that oversleeps starts its next proof late
+  // (BN254 2^20 x 4 in flight lost 10 % with a sleep of 3/4 of the LAST drain).  A wait that found the event complete
+  // when it woke up halves the history instead of trusting its (sleep-dominated) reading.
+  double drain_hist[4] = {0, 0, 0, 0};
+  uint32_t drain_n = 0;
   uint64_t drain_shape = 0;
   double drain_hint(uint64_t shape) const {
-    static const bool adapt = [] {                  // ARK355_WAIT_ADAPT=0: poll from the start (A/B)
+    // OFF by default (ARK355_WAIT_ADAPT=1 turns it on): with the synchronises gone the proving threads cost 0.07-0.1 host
+    // cores with or without the sleep, and BN254 2^20 x 4 in flight ran 17.8 ms per proof with it against 16.6 without
+    // (profiles/r03_epilogue_ab.txt) -- a thread that wakes up late starts its next proof late.
+    static const bool adapt = [] {
       const char* e = getenv("ARK355_WAIT_ADAPT");
-      return !(e && e[0] == '0');
+      return e && e[0] == '1';
     }();
-    return (adapt && shape == drain_shape) ? 0.75 * drain_est_ms : 0.0;
+    if (!adapt || shape != drain_shape || drain_n < 4) return 0.0;
+    double mn = drain_hist[0];
+    for (int i = 1; i < 4; i++) mn = drain_hist[i] < mn ? drain_hist[i] : mn;
+    return 0.5 * mn;
   }
   void drain_record(uint64_t shape, double ms, bool overslept) {
-    drain_est_ms = (overslept && shape == drain_shape) ? 0.5 * drain_est_ms : ms;
-    drain_shape = shape;
+    if (shape != drain_shape) {
+      drain_shape = shape;
+      drain_n = 0;
+    }
+    if (overslept) {
+      for (double& d : drain_hist) d *= 0.5;
+      return;
+    }
+    drain_hist[drain_n & 3] = ms;
+    drain_n++;
   }
   // one sort per distinct scalar vector (zx for A/B1/B2/L', h for H) and one bucket set per MSM: the five MSMs of
   // a proof are in flight together on separate streams (sized for 288 GB of HBM, not for reuse)
@@ -599,7 +615,9 @@ static void prove_run(ark355_ctx* ctx, ProverScratch& sc, const PkDev& pk, const
       const char* e = getenv("ARK355_EPILOGUE_SYNC");
       return e ? (e[0] == '1' ? 1 : 0) : -1;
     }();
-    const bool epi_sync = epi_force >= 0 ? epi_force == 1 : pk.N < (1ull << 20);
+    // measured regimes: BLS12-381 N = 2^21 / 2^22 / 2^23 win without (23.9 vs 24.7 ms at 2^20 x 4 in flight); BLS12-381 2^18 x 8
+    // in flight (8.5 vs 10.8 ms) and BN254 2^20 x 4 in flight (15.6 vs 16.6 ms) win with them
+    const bool epi_sync = epi_force >= 0 ? epi_force == 1 : !(pk.N >= (1ull << 20) && sizeof(Fq) >= 48);
     if (epi_sync) {
       ARK_CHECK_HIP(hipStreamSynchronize(sA));
       ARK_CHECK_HIP(hipStreamSynchronize(sS));
