@@ -10,9 +10,11 @@ from oracle.fields import BLS12_381, BN254
 
 @pytest.mark.parametrize("C", [BLS12_381, BN254], ids=lambda c: c.name)
 def test_instances_vs_o3_on_the_emulator(emul_lib, emul_ctx, C):
-    O.check_instance(emul_lib, emul_ctx, C, S.mulchain_csr(C.r, 40), [(5, 7)], batch=2 if C is BLS12_381 else 0, inflight=1)
+    # (the Groth16 equation -- emulated MSMs + the library's host pairing -- once per curve: it is the slow part here)
+    O.check_instance(emul_lib, emul_ctx, C, S.mulchain_csr(C.r, 40), [(5, 7)], batch=2 if C is BLS12_381 else 0, inflight=1,
+                     equation=False)
     if C is BLS12_381:
-        O.check_instance(emul_lib, emul_ctx, C, S.dummy_csr(C.r, 64), [(0, 1)])
+        O.check_instance(emul_lib, emul_ctx, C, S.dummy_csr(C.r, 64), [(0, 1)], equation=False)
     O.check_instance(emul_lib, emul_ctx, C, S.bench_lc_csr(C.r, 24), [(C.r - 1, C.r - 1)])
 
 
@@ -88,7 +90,7 @@ def test_strided_window_tables_on_the_emulator(emul_lib, emul_ctx, monkeypatch, 
     O.check_resident_msm(emul_lib, emul_ctx, BLS12_381, 1, 1100, to_dev, seed=21)     # c = 8: 32 windows
     O.check_resident_msm(emul_lib, emul_ctx, BN254, 2, 150, to_dev, seed=22)          # c = 4: 64 windows
     if stride == "3":
-        O.check_instance(emul_lib, emul_ctx, BLS12_381, S.mulchain_csr(BLS12_381.r, 300), [(5, 7)], sharded=True,
+        O.check_instance(emul_lib, emul_ctx, BLS12_381, S.mulchain_csr(BLS12_381.r, 140), [(5, 7)], sharded=True,
                          equation=False)
 
 
