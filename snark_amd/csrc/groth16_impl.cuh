@@ -20,6 +20,7 @@
 // library's own host-compiled field code finishes the proof; ARK355_DEVICE_FINALIZE=1 keeps it on the device
 // (groth16_finalize_kernel) and must give the same bytes.
 #pragma once
+#include <atomic>
 #include <chrono>
 #include <future>
 #include "common.h"
@@ -434,8 +435,28 @@ static void prove_run(ark355_ctx* ctx, ProverScratch& sc, const PkDev& pk, const
     ARK_CHECK_HIP(hipStreamCreate(st));
   }
   if (!sc.sA) ARK_CHECK_HIP(hipStreamCreate(&sc.sA));      // default = lowest of the two levels gfx950 exposes
-  const char* serial = getenv("ARK355_SERIAL");
-  const bool one_stream = serial && serial[0] == '1';
+  // Schedule.  A proof ALONE on the device runs as the five-stream pipeline below (the latency-bound tails of one MSM hide
+  // under the next MSM's accumulation: 26.9 against 31.7 ms for a single 2^20 proof).  With OTHER proofs in flight the same
+  // proof runs on ONE stream: the gaps are filled by the other proofs' kernels anyway, and the pipeline's cross-stream
+  // waits cost more than they buy -- HIP maps its streams onto a few in-order hardware queues, so a kernel that waits for
+  // an event of its own proof blocks the ready kernels of other proofs queued behind it (the 2^18 x 8 timeline shows a
+  // kernel running 99.9 % of the time but an accumulation only 77 %).  Measured, same box (profiles/r03_one_stream_ab.txt):
+  // BLS12-381 2^20 23.81 -> 23.42 ms per proof at four in flight (23.25 at eight) on 0.14 instead of 0.93 host cores,
+  // BN254 2^20 16.1 -> 15.0 ms, 2^18 8.28 -> 7.38 ms at six in flight (7.23 at twelve).  The choice is made per proof from
+  // the number of proofs in flight on the device when it starts; ARK355_SERIAL=1 / 0 forces one stream / the pipeline.
+  struct InFlight {
+    std::atomic<int>& c;
+    int mine;
+    explicit InFlight(std::atomic<int>& counter) : c(counter), mine(++counter) {}
+    ~InFlight() { --c; }
+  };
+  static std::atomic<int> g_inflight[64];
+  InFlight inflight(g_inflight[(unsigned)ctx->device & 63u]);
+  const int serial_force = [] {                      // read per proof: the tests flip it
+    const char* e = getenv("ARK355_SERIAL");
+    return e ? (e[0] == '1' ? 1 : 0) : -1;
+  }();
+  const bool one_stream = serial_force >= 0 ? serial_force == 1 : (inflight.mine >= 2 && !cm);
   hipStream_t sW = one_stream ? sM : sc.sW, sS = one_stream ? sM : sc.sS, sA = one_stream ? sM : sc.sA,
               sR = one_stream ? sM : sc.sR;
   const uint64_t m = pk.m, ell = pk.ell;
@@ -617,7 +638,8 @@ static void prove_run(ark355_ctx* ctx, ProverScratch& sc, const PkDev& pk, const
     }();
     // measured regimes: BLS12-381 N = 2^21 / 2^22 / 2^23 win without (23.9 vs 24.7 ms at 2^20 x 4 in flight); BLS12-381 2^18 x 8
     // in flight (8.5 vs 10.8 ms) and BN254 2^20 x 4 in flight (15.6 vs 16.6 ms) win with them
-    const bool epi_sync = epi_force >= 0 ? epi_force == 1 : !(pk.N >= (1ull << 20) && sizeof(Fq) >= 48);
+    // (one-stream schedule: the only stream has drained when E_END fired)
+    const bool epi_sync = epi_force >= 0 ? epi_force == 1 : (!one_stream && !(pk.N >= (1ull << 20) && sizeof(Fq) >= 48));
     if (epi_sync) {
       ARK_CHECK_HIP(hipStreamSynchronize(sA));
       ARK_CHECK_HIP(hipStreamSynchronize(sS));

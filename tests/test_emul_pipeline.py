@@ -76,6 +76,16 @@ def test_prove_bytes_equal_oracle(emul_lib, emul_ctx, C):
     pc.prove_case(emul_lib, emul_ctx, C, A, B, Cm, z, ell, rs=((0x1234567890abcdef, 0xfedcba0987654321aabbccdd), (0, 5)))
 
 
+@pytest.mark.parametrize("serial", ["1", "0"])
+def test_prove_schedules_give_the_same_bytes(emul_lib, emul_ctx, monkeypatch, serial):
+    """prove_run picks its schedule per proof: one stream when other proofs are in flight on the device, the five-stream
+    pipeline when the proof is alone (ARK355_SERIAL=1 / 0 force either).  Same bytes as the oracle both ways."""
+    monkeypatch.setenv("ARK355_SERIAL", serial)
+    C = BLS12_381
+    A, B, Cm, z, ell = S.mulchain_direct(C.r, 21)
+    pc.prove_case(emul_lib, emul_ctx, C, A, B, Cm, z, ell, rs=((7, 9),))
+
+
 def test_prove_device_finalize_kernel_gives_same_bytes(emul_lib, emul_ctx, monkeypatch):
     """ARK355_DEVICE_FINALIZE=1 keeps s*A + r*B1 and the normalisations in groth16_finalize_kernel."""
     monkeypatch.setenv("ARK355_DEVICE_FINALIZE", "1")

@@ -257,3 +257,13 @@ def test_prove_with_window_17_negating_high_scalars(gpu_lib, gpu_ctx, monkeypatc
     C = BLS12_381
     A, B, Cm, z, ell = S.mulchain_direct(C.r, 1030)
     pc.prove_case(gpu_lib, gpu_ctx, C, A, B, Cm, z, ell, rs=((C.r - 3, 12345),))
+
+
+@pytest.mark.parametrize("serial", ["1", "0"])
+def test_prove_one_stream_schedule(gpu_lib, gpu_ctx, monkeypatch, serial):
+    """The schedule prove_run picks with other proofs in flight (one stream) and the one it picks for a proof alone (five
+    streams), forced through ARK355_SERIAL: proof bytes == oracle, pairing equation."""
+    monkeypatch.setenv("ARK355_SERIAL", serial)
+    C = BLS12_381
+    A, B, Cm, z, ell = S.mulchain_direct(C.r, 300)
+    pc.prove_case(gpu_lib, gpu_ctx, C, A, B, Cm, z, ell, verify=True)

@@ -9,6 +9,7 @@
 #   f  host cost of HIP calls, host time to queue a proof, NTT kernels at two waves per SIMD -> profiles/r03_host_cpu.txt
 #   g  proof epilogue without stream synchronisations, GPU_MAX_HW_QUEUES                  -> profiles/r03_epilogue_ab.txt
 #   h  validation of the final epilogue / wait policy (BN254, default)                    -> profiles/r03_epilogue_ab.txt
+#   jkl  one stream per proof against the pipeline, several proofs in flight; final library -> profiles/r03_one_stream_ab.txt
 stage=$1
 run_a() {
   # round 3, run A (prepared at the end of round 2, not yet run): same-box A/B of the window size for resident keys,
@@ -213,4 +214,18 @@ b default A=1
 EXTRA="--curve bn254 --steps 24 --warmup 6"
 b bn254_b A=1
 }
-case "$stage" in a|b|c|d|e|f|g|h) run_$stage ;; *) echo "usage: $0 <a|b|c|d|e|f|g|h>"; exit 2 ;; esac
+run_jkl() {
+  # runs j, k, l: the whole proof on one stream (ARK355_SERIAL=1) against the five-stream pipeline, several proofs in flight;
+  # l = the final library (schedule picked per proof), parity checks on
+  R=$PWD; O=$R/gpurun_out; mkdir -p $O
+  b() { tag=$1; shift; ARK355_BENCH_WATCHDOG=70 timeout 80 env "$@" python bench.py --no-cpu-baseline ${EXTRA} > $O/r3jkl_$tag.log 2> $O/r3jkl_$tag.err; grep -c "^{" $O/r3jkl_$tag.log; }
+  EXTRA="--no-check --steps 32 --warmup 8 --inflight 4"; b n20_if4_pipe ARK355_SERIAL=0; b n20_if4_serial ARK355_SERIAL=1
+  EXTRA="--no-check --steps 32 --warmup 8 --inflight 8"; b n20_if8_serial ARK355_SERIAL=1
+  EXTRA="--no-check --curve bn254 --steps 32 --warmup 8 --inflight 6"; b bn_if6_serial ARK355_SERIAL=1
+  EXTRA="--no-check --log-n 18 --inflight 8 --steps 64 --warmup 8"; b n18_if8_pipe ARK355_SERIAL=0; b n18_if8_serial ARK355_SERIAL=1
+  EXTRA="--no-check --log-n 18 --inflight 12 --steps 96 --warmup 12"; b n18_if12_serial ARK355_SERIAL=1
+  EXTRA="--steps 20 --warmup 5"; b default A=1
+  EXTRA="--curve bn254 --steps 20 --warmup 5"; b bn254 A=1
+  EXTRA="--log-n 18 --inflight 8 --steps 64 --warmup 8"; b n18_if8 A=1
+}
+case "$stage" in a|b|c|d|e|f|g|h|jkl) run_$stage ;; *) echo "usage: $0 <a|b|c|d|e|f|g|h|jkl>"; exit 2 ;; esac
