@@ -99,6 +99,23 @@ pub struct Resident {
 // SAFETY: the handles are immutable after load and the library allows concurrent readers (include/ark355.h).
 unsafe impl Send for Resident {}
 unsafe impl Sync for Resident {}
+/// How a resident key sits in HBM (`ark355_pk_table_info`): Pippenger window size, windows per scalar, window stride of the
+/// tables (1 = a table per window; larger = the key did not fit with full tables) and the bytes its five tables occupy.
+#[derive(Clone, Copy, Debug, PartialEq, Eq)]
+pub struct TableInfo {
+    pub window_bits: u32,
+    pub windows: u32,
+    pub table_stride: u32,
+    pub table_bytes: u64,
+}
+impl Resident {
+    pub fn table_info(&self) -> TableInfo {
+        let (mut c, mut w, mut s, mut b) = (0u32, 0u32, 0u32, 0u64);
+        // SAFETY: `self.pk` is a live handle until drop; the out-pointers are valid for the call.
+        unsafe { ffi::ark355_pk_table_info(self.pk, &mut c, &mut w, &mut s, &mut b) };
+        TableInfo { window_bits: c, windows: w, table_stride: s, table_bytes: b }
+    }
+}
 impl Drop for Resident {
     fn drop(&mut self) {
         unsafe {
