@@ -335,7 +335,10 @@ struct Api {
     const Fr tau = td[0], alpha = td[1], beta = td[2], gamma = td[3], delta = td[4];
     const Fr omega = ntt_root<Fr>(lg, false);
     const Fr zt = Fr::sub(fr_pow_u64(tau, N), Fr::one());
-    ARK_REQUIRE(!zt.is_zero(), ARK355_EINVAL, "tau lies in the evaluation domain");
+    // tau inside the evaluation domain (Z(tau) = 0; probability N / r for an honest trapdoor, but a legal input): the
+    // Lagrange coefficients degenerate to an indicator, L_k(tau) = [w^k == tau], as `evaluate_all_lagrange_coefficients`
+    // upstream returns them; h_i = Z(tau) tau^i / delta = 0.
+    const bool tau_in_domain = zt.is_zero();
     Fr nn = Fr::zero();
     nn.l[0] = (uint32_t)N;
     nn.l[1] = (uint32_t)(N >> 32);
@@ -353,6 +356,15 @@ struct Api {
       for (auto& x : th) x.join();
     };
     std::vector<Fr> L(N), wk(N);
+    if (tau_in_domain) {
+      parallel(N, [&](uint64_t a, uint64_t b) {
+        Fr p = fr_pow_u64(omega, a);
+        for (uint64_t k = a; k < b; k++) {
+          L[k] = (p == tau) ? Fr::one() : Fr::zero();
+          p = Fr::mul(p, omega);
+        }
+      });
+    } else
     parallel(N, [&](uint64_t a, uint64_t b) {
       Fr p = fr_pow_u64(omega, a), acc = Fr::one();
       for (uint64_t k = a; k < b; k++) {            // prefix products of the denominators of this chunk

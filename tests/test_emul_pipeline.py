@@ -245,3 +245,46 @@ def test_prove_with_batch_affine_accumulation(emul_lib, emul_ctx, monkeypatch, C
     if C is BLS12_381:
         monkeypatch.setenv("ARK355_G1_BATCH_AFFINE", "1")
         pc.prove_case(emul_lib, emul_ctx, C, A, B, Cm, z, ell, rs=((7, 9),))
+
+
+def test_setup_scalars_vs_oracle_incl_tau_in_the_domain_and_bad_csr(emul_lib):
+    """ark355_setup_scalars (host code of the library) against the oracle's generator scalars -- also for a tau INSIDE the
+    evaluation domain (Lagrange coefficients degenerate to an indicator, h = 0, as upstream's
+    evaluate_all_lagrange_coefficients handles it) -- and its input validation (column indices and row
+    pointers of the caller's CSR are checked before three threads write through them)."""
+    import numpy as np
+    from helpers import csr_from_rows
+    from oracle import groth16 as G, serialize as Z
+    from oracle.ntt import Domain
+    from snark_amd._binding import Ark355Error, EINVAL
+    C = BLS12_381
+    A, B, Cm, z, ell = S.cs_to_instance(S.bench_lc_cs(C.r, 11))
+    n, m = len(A), len(z)
+    w = m - ell
+    mats = [csr_from_rows(C, M) for M in (A, B, Cm)]
+    dom = Domain.for_size(C, n + ell)
+    for tau in (0xABCDEF0123456789, pow(dom.omega, 3, C.r)):
+        alpha, beta, gamma, delta = 3, 5, 7, 11
+        td = b"".join(Z.fr_canon(C, x) for x in (tau, alpha, beta, gamma, delta))
+        sc = emul_lib.setup_scalars(C.curve_id, n, ell, w, mats, td)
+        u, v, ww, zt, _ = G.qap_scalars(C, A, B, Cm, n, ell, m, tau)
+        canon = lambda xs: b"".join(Z.fr_canon(C, x) for x in xs)          # noqa: E731
+        assert sc["u"].tobytes() == canon(u) and sc["v"].tobytes() == canon(v) and sc["w"].tobytes() == canon(ww)
+        di, gi = pow(delta, -1, C.r), pow(gamma, -1, C.r)
+        abc = [(beta * u[i] + alpha * v[i] + ww[i]) % C.r for i in range(m)]
+        assert sc["l"].tobytes() == canon([abc[i] * di % C.r for i in range(ell, m)])
+        assert sc["gamma_abc"].tobytes() == canon([abc[i] * gi % C.r for i in range(ell)])
+        assert sc["h"].tobytes() == canon([zt * di % C.r * pow(tau, i, C.r) % C.r for i in range(dom.n - 1)])
+        if zt == 0:
+            assert sc["h"].tobytes() == bytes(32 * (dom.n - 1))
+    bad = [(rp, col.copy(), cf) for rp, col, cf in mats]
+    bad[1][1][0] = m                                                        # column index out of range
+    with pytest.raises(Ark355Error) as e:
+        emul_lib.setup_scalars(C.curve_id, n, ell, w, bad, td)
+    assert e.value.code == EINVAL
+    bad = [(rp.copy(), col, cf) for rp, col, cf in mats]
+    bad[0][0][2] = bad[0][0][1] - 1 if bad[0][0][1] > 0 else 5             # row pointers not monotone
+    bad[0][0][1] = bad[0][0][2] + 2
+    with pytest.raises(Ark355Error) as e:
+        emul_lib.setup_scalars(C.curve_id, n, ell, w, bad, td)
+    assert e.value.code == EINVAL
