@@ -42,6 +42,7 @@ struct PkDev {
   uint64_t z_lo = 0, z_cnt = 0;     // of the m+4 extended a/b/l terms
   uint64_t h_lo = 0, h_cnt = 0;     // of the N-1 h terms
   uint32_t wstride = 1;             // MsmPlan::wstride of the five tables (1 = every window has its table)
+  mutable std::atomic<bool> shard_plan_checked{false};   // ark355_prove_sharded compared this shard's plan with the other ranks' once
   uint64_t table_bytes() const {
     return a_ext.table.bytes + b1_ext.table.bytes + b2_ext.table.bytes + h_query.table.bytes + l_ext.table.bytes;
   }
@@ -460,6 +461,25 @@ static void prove_run(ark355_ctx* ctx, ProverScratch& sc, const PkDev& pk, const
   hipStream_t sW = one_stream ? sM : sc.sW, sS = one_stream ? sM : sc.sS, sA = one_stream ? sM : sc.sA,
               sR = one_stream ? sM : sc.sR;
   const uint64_t m = pk.m, ell = pk.ell;
+  if (cm && !pk.shard_plan_checked.load()) {
+    // Every rank must have planned the same window size and table stride for its shard: the bucket-level exchange adds
+    // bucket arrays of different ranks element by element.  The planners are deterministic functions of the key's
+    // dimensions and the device size, but an environment override on one rank (ARK355_MSM_C, ARK355_TABLE_STRIDE,
+    // ARK355_HBM_BUDGET_MB) would break that silently -- so the ranks compare notes once per key, over the communicator.
+    const uint32_t mine[4] = {pk.a_ext.plan.c, pk.a_ext.plan.wstride, pk.h_query.plan.c, pk.h_query.plan.wstride};
+    cm->gather.ensure(sizeof(mine) * (size_t)(cm->world + 1));
+    uint8_t* d_mine = cm->gather.as<uint8_t>() + sizeof(mine) * (size_t)cm->world;
+    ARK_CHECK_HIP(hipMemcpyAsync(d_mine, mine, sizeof(mine), hipMemcpyHostToDevice, sM));
+    ARK_CHECK_NCCL(ncclAllGather(d_mine, cm->gather.p, sizeof(mine), ncclUint8, cm->comm, sM));
+    std::vector<uint32_t> all(4 * (size_t)cm->world);
+    ARK_CHECK_HIP(hipMemcpyAsync(all.data(), cm->gather.p, sizeof(mine) * (size_t)cm->world, hipMemcpyDeviceToHost, sM));
+    ARK_CHECK_HIP(hipStreamSynchronize(sM));
+    for (int g = 0; g < cm->world; g++)
+      for (int k = 0; k < 4; k++)
+        ARK_REQUIRE(all[4 * (size_t)g + k] == mine[k], ARK355_EINVAL,
+                    "key shards of different ranks were planned with different window sizes / table strides");
+    pk.shard_plan_checked.store(true);
+  }
   enum { E_START, E_Z, E_H, E_SORT0, E_SORT1, E_SORT2, E_ACC_DONE0, E_END = E_ACC_DONE0 + 5, E_COUNT };
   static_assert(E_COUNT + 10 <= ProverScratch::N_EVENTS, "event pool too small");
   sc.ensure_events();

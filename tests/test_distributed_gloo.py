@@ -37,8 +37,10 @@ def _make_key(n, path):
                                                                      gamma=td.gamma, delta=td.delta, **ints)), f)
 
 
-def _worker(rank, world, port, n, key_path, modes, whole, q):
+def _worker(rank, world, port, n, key_path, modes, whole, q, stride_on_rank1=None):
     try:
+        if stride_on_rank1 and rank == 1:
+            os.environ["ARK355_TABLE_STRIDE"] = stride_on_rank1      # this rank alone plans its tables differently
         os.environ["MASTER_ADDR"] = "127.0.0.1"
         os.environ["MASTER_PORT"] = str(port)
         for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "emul")):
@@ -67,6 +69,17 @@ def _worker(rank, world, port, n, key_path, modes, whole, q):
         sg = ShardedGroth16(g, device="cpu")
         zb = synthetic.z_to_mont_bytes(cv, z)
         closed = g.prove_closed_form(pk, z, 12345, 67890)
+        if stride_on_rank1:
+            # every rank must refuse: the ranks compare their plans over the communicator before the first exchange
+            try:
+                sg.prove(pk, r1, zb, r=12345, s=67890, mode=SHARD_BUCKET_RING)
+                q.put((rank, False, False, "mismatching plans were not detected"))
+            except Exception as e:
+                q.put((rank, "different window sizes / table strides" in str(e), True, "refused"))
+            sg.close()
+            g.close()
+            dist.destroy_process_group()
+            return
         proofs = [sg.prove(pk, r1, zb, r=12345, s=67890, mode={"window": SHARD_WINDOW, "ring": SHARD_BUCKET_RING}[m])
                   for m in modes]
         proof_w = proofs[0]
@@ -89,7 +102,7 @@ def _worker(rank, world, port, n, key_path, modes, whole, q):
         q.put((rank, False, False, traceback.format_exc()))
 
 
-def _run(world, n, tmp_path, modes=("window", "ring"), whole=True):
+def _run(world, n, tmp_path, modes=("window", "ring"), whole=True, stride_on_rank1=None):
     import torch.multiprocessing as mp
     sys.path.insert(0, os.path.join(ROOT, "tests", "emul"))
     import build_emul
@@ -99,7 +112,7 @@ def _run(world, n, tmp_path, modes=("window", "ring"), whole=True):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, n, key_path, modes, whole, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, key_path, modes, whole, q, stride_on_rank1)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=900) for _ in procs]
@@ -126,3 +139,10 @@ def test_sharded_prove_small_instance_all_modes(world, tmp_path):
 def test_sharded_prove_tiny_instance_with_empty_shards(tmp_path):
     """n = 3 over 8 ranks: several shards of the h query are empty and still take part in the exchange."""
     _run(8, 3, tmp_path)
+
+
+def test_sharded_prove_refuses_ranks_with_different_table_plans(tmp_path):
+    """One rank plans its window tables with another stride (an environment override on that rank only): the bucket-level
+    exchange would add bucket arrays of different shapes.  The ranks compare their plans over the communicator once per
+    key and every one of them returns ARK355_EINVAL instead."""
+    _run(2, 150, tmp_path, stride_on_rank1="2")
