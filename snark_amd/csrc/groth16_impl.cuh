@@ -461,7 +461,7 @@ static void prove_run(ark355_ctx* ctx, ProverScratch& sc, const PkDev& pk, const
   hipStream_t sW = one_stream ? sM : sc.sW, sS = one_stream ? sM : sc.sS, sA = one_stream ? sM : sc.sA,
               sR = one_stream ? sM : sc.sR;
   const uint64_t m = pk.m, ell = pk.ell;
-  if (cm && !pk.shard_plan_checked.load()) {
+  if (cm && cm->world > 1 && !pk.shard_plan_checked.load()) {
     // Every rank must have planned the same window size and table stride for its shard: the bucket-level exchange adds
     // bucket arrays of different ranks element by element.  The planners are deterministic functions of the key's
     // dimensions and the device size, but an environment override on one rank (ARK355_MSM_C, ARK355_TABLE_STRIDE,
