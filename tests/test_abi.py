@@ -56,3 +56,31 @@ def test_product_never_imports_the_oracle():
                 if re.search(r"^\s*(from|import)\s+oracle\b", txt, re.M) or "oracle/" in txt and "#include" in txt and "oracle/" in "".join(l for l in txt.splitlines() if l.strip().startswith("#include")):
                     bad.append(f)
     assert not bad, bad
+
+
+def test_host_only_entry_points_reject_bad_arguments(built_lib):
+    """Entry points that need no device (argument checks run before any HIP call): NULL handles, out-of-range `validate`,
+    a proof of the wrong length -- ARK355_EINVAL, never a crash."""
+    import ctypes as C
+    import snark_amd
+    lib = snark_amd.lib()
+    EINVAL = snark_amd.EINVAL
+    c, w, s, b = C.c_uint32(7), C.c_uint32(7), C.c_uint32(7), C.c_uint64(7)
+    assert lib.dll.ark355_pk_table_info(None, C.byref(c), C.byref(w), C.byref(s), C.byref(b)) == EINVAL
+    assert lib.dll.ark355_pk_dims(None, None, None, None) == EINVAL
+    from snark_amd._binding import ProofRaw
+    buf = (C.c_uint8 * 512)()
+    raw = ProofRaw()
+    out = C.byref(raw)
+    for validate in (-1, 3):
+        assert lib.dll.ark355_proof_from_bytes(snark_amd.BLS12_381, buf, 192, 1, validate, out) == EINVAL
+    assert lib.dll.ark355_proof_from_bytes(snark_amd.BLS12_381, buf, 191, 1, 1, out) == EINVAL         # bad length
+    assert lib.dll.ark355_proof_from_bytes(99, buf, 192, 1, 1, out) == EINVAL                          # unknown curve
+    # an all-zero compressed BLS12-381 "proof": the compressed bit is missing -> bad flags, in every validation mode
+    for validate in (0, 1, 2):
+        assert lib.dll.ark355_proof_from_bytes(snark_amd.BLS12_381, buf, 192, 1, validate, out) == EINVAL
+    # three compressed points at infinity are a well-formed (if useless) proof encoding
+    inf = bytes([0xC0]) + bytes(47) + bytes([0xC0]) + bytes(95) + bytes([0xC0]) + bytes(47)
+    ib = (C.c_uint8 * 192)(*inf)
+    assert lib.dll.ark355_proof_from_bytes(snark_amd.BLS12_381, ib, 192, 1, 1, out) == 0
+    assert bytes(raw.a) == bytes(96) and bytes(raw.b) == bytes(192) and bytes(raw.c) == bytes(96)

@@ -61,3 +61,27 @@ def test_bench_gpus_8_ranks(mode):
     assert d["parity"] == "proof == trapdoor closed form"
     assert d["scaling"] == ("strong" if mode == "shard" else "weak")
     assert ("msm-shard x8" if mode == "shard" else "replicas x8") in d["config"]["parallelism"]
+
+
+def test_bench_line_carries_the_8d_latency_and_host_cpu_fields():
+    """The fields round 3 added to the bench line, exercised over the emulator (ARK355_BENCH_EMUL_LATENCY=1 runs the
+    host-z latency / in-flight readings that are otherwise GPU-only): SURVEY-8d latency from page-locked and pageable
+    host memory, the in-flight throughput from host z, host CPU by thread class, the key's table layout, the named
+    source of roofline.traffic, the mode in `metric`."""
+    env = dict(os.environ, ARK355_BENCH_EMUL_LATENCY="1")
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dry-run-emul", "--steps", "1", "--warmup", "1",
+                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert "proofs in flight per GPU, z resident in HBM" in d["metric"]
+    lat = d["latency"]
+    for k in ("host_pinned_z_ms", "host_pageable_z_ms", "device_z_ms", "constraints_per_s_single_proof_host_pinned_z"):
+        assert lat[k] > 0
+    for k in ("pinned", "pageable"):
+        assert lat["inflight_from_host_z"][k]["value"] > 0
+    assert set(d["host_cpu_threads"]) == {"proving_threads", "resident_threads", "short_lived_native_threads"}
+    assert d["key_tables"]["table_stride"] == 1 and d["key_tables"]["table_bytes"] > 0
+    assert "traffic_source" in d["roofline"] and d["roofline"]["bound"] == "hbm"
+    assert "[bench" in r.stderr and "parity" in r.stderr            # stage markers go to stderr, one JSON line to stdout
