@@ -346,7 +346,9 @@ def main():
     # in-flight throughput of the timed region repeated from host buffers.
     stage("single-stream reading done")
     latency = None
-    if rank == 0 and (not emul or os.environ.get('ARK355_BENCH_EMUL_LATENCY')):
+    # (a sharded proof is a collective: with several ranks rank 0 cannot prove on its own -- there every step already IS a
+    # single proof from start to finish, so ms_per_step is the latency)
+    if rank == 0 and not (shard and world > 1) and (not emul or os.environ.get('ARK355_BENCH_EMUL_LATENCY')):
         import ctypes
         ptr = ctypes.c_void_p()
         assert g.lib.dll.ark355_host_alloc(len(zb), ctypes.byref(ptr)) == 0
