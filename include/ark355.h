@@ -60,6 +60,38 @@ uint32_t ark355_version(void);
 /* sizes in bytes for `curve`: what[0]=Fr, [1]=Fq, [2]=G1 affine, [3]=G2 affine */
 int32_t ark355_sizes(int32_t curve, uint32_t what[4]);
 
+/* ---- runtime policy ------------------------------------------------------------------------------------------------
+ * Every runtime switch of the library lives in ONE per-context struct (snark_amd/csrc/policy.h).  The environment
+ * variables ARK355_<NAME> are read exactly once, by ark355_ctx_create; afterwards a context's policy changes only through
+ * ark355_ctx_set_policy -- nothing on the proving path reads the environment, and two contexts of a process may differ
+ * (A/B measurements inside one process).  Names (value = integer):
+ *   per proof     SCHED (-1 measured choice [default], 0 one stream, 1 five-stream pipeline, 2 pipeline + epilogue stream
+ *                 synchronises, 3 one stream + wait inside the HIP runtime), SCHED_EXPLORE (samples per schedule before the
+ *                 measured choice latches; 0 = static defaults), WAIT_SPIN, WAIT_ADAPT, STREAM_PRIO, DEVICE_FINALIZE,
+ *                 TRACE_HOST; legacy spellings SERIAL (1 -> SCHED 0, 0 -> SCHED 1) and EPILOGUE_SYNC (on a pipeline: 1 -> 2);
+ *   per key load  MSM_C, MSM_C_H (window size of all tables / of the h_query table; 0 = planner), LIMB28, G2_LIMB28,
+ *                 G1_BATCH_AFFINE, G2_BATCH_AFFINE, BA_LEVELS, TABLE_STRIDE, HBM_BUDGET_MB -- read when a key or base set is
+ *                 loaded THROUGH this context;
+ *   per call      MSM_SEG, SORT_LEGACY, G2_INLINE, G2_WHOLE, G2_PAIR_TAILS, MSM_TWO_LEVEL_MIN, NTT_RMAX, NTT_DIRECT_MAX,
+ *                 NTT_NOFUSE (A/B and test knobs).
+ * ARK355_EINVAL for an unknown name.  ark355_prove_batch runs its worker contexts under the caller's policy.
+ * (No counterpart in the reference: ark-groth16 has no runtime knobs; rayon's thread count is its only one.) */
+int32_t ark355_ctx_set_policy(ark355_ctx* ctx, const char* name, int64_t value);
+int32_t ark355_ctx_get_policy(ark355_ctx* ctx, const char* name, int64_t* value);
+
+/* What the measured schedule choice (SCHED = -1) has seen for proofs shaped like `pk` on this context's device, for the
+ * class "alone on the device" (in_flight = 0) or "other proofs in flight" (in_flight != 0): the schedule it latched
+ * (-1 while still exploring / never run), per schedule the samples taken and their mean wall time in ms, and the
+ * schedule the LAST proof of this context ran as.  ark355_sched_reset forgets the device's measurements. */
+typedef struct {
+  int32_t latched;
+  int32_t last;
+  uint32_t samples[4];
+  double mean_ms[4];
+} ark355_sched_report;
+int32_t ark355_sched_info(const ark355_ctx* ctx, const ark355_pk* pk, int32_t in_flight, ark355_sched_report* out);
+int32_t ark355_sched_reset(const ark355_ctx* ctx);
+
 /* Page-locked host memory for assignments / key vectors handed to the entry points below: H2D copies from pinned
  * memory run at PCIe rate (~55 GB/s) and truly asynchronously; pageable memory is staged by the runtime at a fraction
  * of that (a 32 MiB assignment at n = 2^20: ~0.6 ms pinned vs several ms pageable).  Optional: every entry point accepts

@@ -94,12 +94,27 @@ pub struct ark355_timings {
     pub finalize_ms: f32,
 }
 
+/// What the measured schedule choice has seen for one (proof shape, alone | in flight) class: `ark355_sched_info`.
+#[repr(C)]
+#[derive(Clone, Copy, Default, Debug)]
+pub struct ark355_sched_report {
+    pub latched: i32,
+    pub last: i32,
+    pub samples: [u32; 4],
+    pub mean_ms: [f64; 4],
+}
+
 extern "C" {
     pub fn ark355_ctx_create(device_id: i32, out: *mut *mut ark355_ctx) -> i32;
     pub fn ark355_ctx_destroy(ctx: *mut ark355_ctx);
     pub fn ark355_last_error(ctx: *const ark355_ctx) -> *const c_char;
     pub fn ark355_version() -> u32;
     pub fn ark355_sizes(curve: i32, what: *mut u32) -> i32;
+
+    pub fn ark355_ctx_set_policy(ctx: *mut ark355_ctx, name: *const c_char, value: i64) -> i32;
+    pub fn ark355_ctx_get_policy(ctx: *mut ark355_ctx, name: *const c_char, value: *mut i64) -> i32;
+    pub fn ark355_sched_info(ctx: *const ark355_ctx, pk: *const ark355_pk, in_flight: i32, out: *mut ark355_sched_report) -> i32;
+    pub fn ark355_sched_reset(ctx: *const ark355_ctx) -> i32;
 
     pub fn ark355_host_alloc(bytes: u64, out: *mut *mut c_void) -> i32;
     pub fn ark355_host_free(p: *mut c_void);

@@ -48,7 +48,10 @@ SYMBOLS = [
     "ark355_pk_table_info",
     "ark355_points_decode", "ark355_points_encode", "ark355_proof_to_bytes", "ark355_proof_from_bytes",
     "ark355_setup_scalars", "ark355_verify_batch",
+    "ark355_ctx_set_policy", "ark355_ctx_get_policy", "ark355_sched_info", "ark355_sched_reset",
 ]
+
+SCHED_NAMES = {-1: "auto", 0: "one_stream", 1: "pipeline", 2: "pipeline_sync", 3: "one_stream_spin"}
 
 
 class Ark355Error(RuntimeError):
@@ -74,6 +77,10 @@ class VkDesc(C.Structure):
 
 class ProofRaw(C.Structure):
     _fields_ = [("a", C.c_uint8 * 96), ("b", C.c_uint8 * 192), ("c", C.c_uint8 * 96)]
+
+
+class SchedReport(C.Structure):
+    _fields_ = [("latched", C.c_int32), ("last", C.c_int32), ("samples", C.c_uint32 * 4), ("mean_ms", C.c_double * 4)]
 
 
 class Timings(C.Structure):
@@ -163,12 +170,51 @@ class Lib:
         d.ark355_proof_from_bytes.argtypes = [i32, vp, u64, i32, i32, P(ProofRaw)]
         d.ark355_setup_scalars.argtypes = [i32, u64, u64, u64, P(vp * 3), P(vp * 3), P(vp * 3), vp, vp, vp, vp, vp, vp, vp]
         d.ark355_verify_batch.argtypes = [vp, i32, P(VkDesc), vp, vp, vp, u64, P(i32)]
+        d.ark355_ctx_set_policy.argtypes = [vp, C.c_char_p, i64]
+        d.ark355_ctx_get_policy.argtypes = [vp, C.c_char_p, P(i64)]
+        d.ark355_sched_info.argtypes = [vp, vp, i32, P(SchedReport)]
+        d.ark355_sched_reset.argtypes = [vp]
         d.ark355_get_timings.argtypes = [vp, P(Timings)]
         d.ark355_get_kernel_stats.argtypes = [vp, P(C.c_float), P(u64), P(u64)]
         for name in SYMBOLS:
             fn = getattr(d, name)
             if fn.restype is C.c_int:      # default: make every status-returning call int32
                 fn.restype = i32
+
+    # ---- runtime policy (include/ark355.h "runtime policy") ------------------------------------------
+    def ctx_set_policy(self, ctx, name, value):
+        self.check(ctx, self.dll.ark355_ctx_set_policy(ctx, name.encode(), int(value)))
+
+    def ctx_get_policy(self, ctx, name):
+        v = C.c_int64()
+        self.check(ctx, self.dll.ark355_ctx_get_policy(ctx, name.encode(), C.byref(v)))
+        return int(v.value)
+
+    def policy(self, ctx, **kw):
+        """context manager: set policy values on `ctx`, restore the previous ones on exit"""
+        import contextlib
+
+        @contextlib.contextmanager
+        def cm():
+            old = {k: self.ctx_get_policy(ctx, k) for k in kw}
+            try:
+                for k, v in kw.items():
+                    self.ctx_set_policy(ctx, k, v)
+                yield
+            finally:
+                for k, v in old.items():
+                    self.ctx_set_policy(ctx, k, v)
+        return cm()
+
+    def sched_info(self, ctx, pk, in_flight):
+        r = SchedReport()
+        self.check(ctx, self.dll.ark355_sched_info(ctx, pk, 1 if in_flight else 0, C.byref(r)))
+        return {"latched": SCHED_NAMES.get(r.latched, str(r.latched)), "last": SCHED_NAMES.get(r.last, str(r.last)),
+                "samples": {SCHED_NAMES[i]: int(r.samples[i]) for i in range(4) if r.samples[i]},
+                "mean_ms": {SCHED_NAMES[i]: round(float(r.mean_ms[i]), 3) for i in range(4) if r.samples[i]}}
+
+    def sched_reset(self, ctx):
+        self.check(ctx, self.dll.ark355_sched_reset(ctx))
 
     # ---- helpers ---------------------------------------------------------------------------------
     def check(self, ctx, rc):

@@ -82,8 +82,9 @@ struct Api {
     what[3] = sizeof(Affine<Fq2>);
   }
 
-  static PkDev* pk_load(const ark355_pk_desc* d, hipStream_t st, uint32_t shard_index = 0, uint32_t shard_count = 1) {
-    return pk_upload<Curve>(d, st, shard_index, shard_count);
+  static PkDev* pk_load(const TunePolicy& pol, const ark355_pk_desc* d, hipStream_t st, uint32_t shard_index = 0,
+                        uint32_t shard_count = 1) {
+    return pk_upload<Curve>(pol, d, st, shard_index, shard_count);
   }
 
   static R1csDev* r1cs_load(uint64_t n, uint64_t ell, uint64_t w, const uint64_t* const rp[3],
@@ -209,7 +210,7 @@ struct Api {
     else msm_generic<Fq2>(ctx, g, g.a.as<Affine<Fq2>>(), g.b.p, n, 0, out, true);
   }
 
-  static BasesDev* bases_load(int group, const uint8_t* bases, uint64_t n, hipStream_t st) {
+  static BasesDev* bases_load(const TunePolicy& pol, int group, const uint8_t* bases, uint64_t n, hipStream_t st) {
     auto* b = new BasesDev();
     try {
       b->curve = Curve::ID;
@@ -220,10 +221,10 @@ struct Api {
       if (n) ARK_CHECK_HIP(hipMemcpy(stage.p, bases, n * psz, hipMemcpyHostToDevice));
       const TableNeed need{n, 0, group == 2};
       std::string why;
-      const uint32_t ws = table_stride_plan<Fq, Fq2, Fr>(&need, 1, table_budget_bytes((size_t)2 * 16 * 17 * n, true), &why);
+      const uint32_t ws = table_stride_plan<Fq, Fq2, Fr>(pol, &need, 1, table_budget_bytes(pol, (size_t)2 * 16 * 17 * n, true), &why);
       if (ws == 0) throw HipError{ARK355_ENOMEM, "base set: " + why};
-      if (group == 1) precomp_build<Fq, Fr>(b->tab, stage.p, n, st, 0, ws);
-      else precomp_build<Fq2, Fr>(b->tab, stage.p, n, st, 0, ws);
+      if (group == 1) precomp_build<Fq, Fr>(pol, b->tab, stage.p, n, st, 0, ws);
+      else precomp_build<Fq2, Fr>(pol, b->tab, stage.p, n, st, 0, ws);
     } catch (...) {
       delete b;
       throw;
@@ -679,7 +680,7 @@ struct Api {
     d.delta_g1 = reinterpret_cast<const uint8_t*>(&h_delta1);
     d.beta_g2 = reinterpret_cast<const uint8_t*>(&h_beta2);
     d.delta_g2 = reinterpret_cast<const uint8_t*>(&h_delta2);
-    return pk_upload<Curve>(&d, st);
+    return pk_upload<Curve>(ctx->policy, &d, st);
   }
 };
 

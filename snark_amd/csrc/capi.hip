@@ -104,6 +104,7 @@ int32_t ark355_ctx_create(int32_t device_id, ark355_ctx** out) {
   ark355_ctx* ctx = new (std::nothrow) ark355_ctx();
   if (!ctx) return ARK355_ENOMEM;
   ctx->device = device_id;
+  ctx->policy = TunePolicy::from_env();       // the ONLY place the environment is read (policy.h)
   if (hipSetDevice(device_id) != hipSuccess || hipStreamCreate(&ctx->stream) != hipSuccess) {
     delete ctx;
     return ARK355_EHIP;
@@ -155,12 +156,51 @@ void ark355_host_free(void* p) {
 
 const char* ark355_last_error(const ark355_ctx* ctx) { return ctx ? ctx->last_error.c_str() : "null context"; }
 
+int32_t ark355_ctx_set_policy(ark355_ctx* ctx, const char* name, int64_t value) {
+  if (!ctx || !name) return ARK355_EINVAL;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  if (ctx->policy.set(name, value) != 0) {
+    ctx->last_error = std::string("unknown policy name: ") + name;
+    return ARK355_EINVAL;
+  }
+  return ARK355_OK;
+}
+int32_t ark355_ctx_get_policy(ark355_ctx* ctx, const char* name, int64_t* value) {
+  if (!ctx || !name || !value) return ARK355_EINVAL;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  return ctx->policy.get(name, value) == 0 ? ARK355_OK : ARK355_EINVAL;
+}
+int32_t ark355_sched_info(const ark355_ctx* ctx, const ark355_pk* pk, int32_t in_flight, ark355_sched_report* out) {
+  if (!ctx || !pk || !pk->d || !out) return ARK355_EINVAL;
+  memset(out, 0, sizeof(*out));
+  out->latched = -1;
+  out->last = ctx->last_sched;
+  double mean[SCHED_COUNT];
+  uint32_t n[SCHED_COUNT];
+  int latched = -1;
+  const uint64_t key = SchedTuner::key(prove_shape(pk->d->curve, pk->d->N, pk->d->m), in_flight != 0);
+  if (SchedTuner::of(ctx->device).info(key, &latched, mean, n)) {
+    out->latched = latched;
+    static_assert(SCHED_COUNT == 4, "ark355_sched_report holds four schedules");
+    for (int v = 0; v < SCHED_COUNT; v++) {
+      out->mean_ms[v] = mean[v];
+      out->samples[v] = n[v];
+    }
+  }
+  return ARK355_OK;
+}
+int32_t ark355_sched_reset(const ark355_ctx* ctx) {
+  if (!ctx) return ARK355_EINVAL;
+  SchedTuner::of(ctx->device).reset();
+  return ARK355_OK;
+}
+
 int32_t ark355_pk_load(ark355_ctx* ctx, int32_t curve, const ark355_pk_desc* desc, ark355_pk** out) {
   if (!ctx || !desc || !out) return ARK355_EINVAL;
   *out = nullptr;
   return guarded(ctx, [&] {
     PkDev* d = nullptr;
-    CURVE_DISPATCH(curve, d = A::pk_load(desc, ctx->stream));
+    CURVE_DISPATCH(curve, d = A::pk_load(ctx->policy, desc, ctx->stream));
     *out = new ark355_pk{d};
   });
 }
@@ -170,7 +210,7 @@ int32_t ark355_pk_load_shard(ark355_ctx* ctx, int32_t curve, const ark355_pk_des
   *out = nullptr;
   return guarded(ctx, [&] {
     PkDev* d = nullptr;
-    CURVE_DISPATCH(curve, d = A::pk_load(desc, ctx->stream, shard_index, shard_count));
+    CURVE_DISPATCH(curve, d = A::pk_load(ctx->policy, desc, ctx->stream, shard_index, shard_count));
     *out = new ark355_pk{d};
   });
 }
@@ -246,6 +286,7 @@ int32_t ark355_prove_batch(ark355_ctx* ctx, const ark355_pk* pk, const ark355_r1
       if (e != ARK355_OK) throw HipError{e, "ark355_prove_batch: cannot create a worker context"};
       ex.lanes.push_back(c);
     }
+    for (ark355_ctx* c : ex.lanes) c->policy = ctx->policy;       // the workers prove under the caller's policy
     std::atomic<uint64_t> next{0};
     std::mutex err_mu;
     auto work = [&](ark355_ctx* lane) {
@@ -455,7 +496,7 @@ int32_t ark355_bases_load(ark355_ctx* ctx, int32_t curve, int32_t group, const u
   *out = nullptr;
   return guarded(ctx, [&] {
     BasesDev* d = nullptr;
-    CURVE_DISPATCH(curve, d = A::bases_load(group, bases, n, ctx->stream));
+    CURVE_DISPATCH(curve, d = A::bases_load(ctx->policy, group, bases, n, ctx->stream));
     *out = new ark355_bases{d};
   });
 }

@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "hd.h"
+#include "policy.h"
 #include "curve.cuh"
 #include "../../include/ark355.h"
 
@@ -104,10 +105,12 @@ struct ark355_ctx {
   hipStream_t stream = nullptr;
   std::string last_error;
   std::mutex mu;
+  ark355::TunePolicy policy;    // every runtime switch; read from the environment once, at ark355_ctx_create (policy.h)
   ark355_timings timings{};
   float acc_ms = 0.f;           // bucket-accumulation kernel time of the last MSM/prove
   uint64_t acc_launches = 0;
   uint64_t acc_points = 0;
+  int last_sched = -1;          // schedule the last prove on this context ran as (ark355::Sched)
   // NTT twiddle tables keyed by (curve << 8 | log_n)
   std::map<uint32_t, std::shared_ptr<ark355::NttTables>> ntt_tables;   // shared with the other contexts of the device
   // grow-only scratch buffers reused across calls (sized for 288 GB HBM: never shrunk)

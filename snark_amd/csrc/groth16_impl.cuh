@@ -42,7 +42,6 @@ struct PkDev {
   uint64_t z_lo = 0, z_cnt = 0;     // of the m+4 extended a/b/l terms
   uint64_t h_lo = 0, h_cnt = 0;     // of the N-1 h terms
   uint32_t wstride = 1;             // MsmPlan::wstride of the five tables (1 = every window has its table)
-  mutable std::atomic<bool> shard_plan_checked{false};   // ark355_prove_sharded compared this shard's plan with the other ranks' once
   uint64_t table_bytes() const {
     return a_ext.table.bytes + b1_ext.table.bytes + b2_ext.table.bytes + h_query.table.bytes + l_ext.table.bytes;
   }
@@ -58,17 +57,13 @@ static inline void shard_range(uint64_t total, uint32_t idx, uint32_t cnt, uint6
 // spins -- hipStreamSynchronize, hipEventSynchronize on a hipEventBlockingSync event, torch.cuda.synchronize alike
 // (profiles/r02_host_wait.txt: 1.00 cores per waiting thread, 4.8 cores for a bench with four proofs in flight) -- and
 // those are the cores the synthesis threads of an end-to-end prover and the other ranks of a multi-GPU node need.  A proof
-// takes tens of milliseconds, so the proving thread polls the event and sleeps 100 us in between.  ARK355_WAIT_SPIN=1
-// hands the wait back to the runtime.
+// takes tens of milliseconds, so the proving thread polls the event and sleeps 100 us in between.  spin (policy
+// WAIT_SPIN=1, or the SCHED_ONE_STREAM_SPIN schedule) hands the wait back to the runtime.
 // expect_ms: how long proofs of this shape took to drain on this context lately (0 = unknown).  The thread sleeps through
 // most of that in ONE go before it starts polling: a 2^20 proof with four in flight is ~95 ms of waiting, i.e. ~900 polls
 // at 100 us, each a runtime call -- a fifth of a host core per proof in flight that the synthesis threads of an end-to-end
 // prover and the other ranks of a node need (bench.py host_cpu_threads).
-static inline void wait_event_polite(hipEvent_t ev, double expect_ms = 0.0, bool* overslept = nullptr) {
-  static const bool spin = [] {
-    const char* e = getenv("ARK355_WAIT_SPIN");
-    return e && e[0] == '1';
-  }();
+static inline void wait_event_polite(hipEvent_t ev, bool spin, double expect_ms = 0.0, bool* overslept = nullptr) {
   if (spin) {
     ARK_CHECK_HIP(hipEventSynchronize(ev));
     return;
@@ -87,6 +82,97 @@ static inline void wait_event_polite(hipEvent_t ev, double expect_ms = 0.0, bool
   }
 }
 
+// ---- measured choice of the per-proof schedule (policy SCHED = AUTO) -------------------------------------------------------
+// Rounds 1-3 picked the schedule from thresholds fitted on two or three boxes (one stream when other proofs are in
+// flight, the pipeline for a proof alone; epilogue synchronises for everything but large BLS12-381 proofs) -- and the
+// round-3 driver box ran 30-40 % slower than any box those thresholds were fitted on, in exactly the phases where
+// streams overlap.  So the library measures instead: per (device, proof shape, alone | in flight) class the first warm
+// proofs run the candidate schedules in turn (policy SCHED_EXPLORE samples each, default 3), their wall time inside
+// prove_run is recorded, and the class then keeps the fastest.  With k proofs in flight and threads that start the next
+// proof as soon as one returns, throughput = k / mean latency, so the proof's own wall time is the right objective in
+// both classes.  A context's first proof of a shape (allocations, table builds) is neither explored nor recorded.  The
+// spinning wait is only taken when it beats the best polite candidate by 10 %: it costs a host core per proof in flight.
+struct SchedTuner {
+  struct Entry {
+    int latched = -1;
+    uint32_t started[SCHED_COUNT] = {}, done[SCHED_COUNT] = {};
+    double sum_ms[SCHED_COUNT] = {};
+    uint32_t ncand = 0;
+    int cand[SCHED_COUNT] = {};
+  };
+  std::mutex mu;
+  std::map<uint64_t, Entry> entries;
+  static SchedTuner& of(int device) {
+    static SchedTuner t[64];
+    return t[(unsigned)device & 63u];
+  }
+  static uint64_t key(uint64_t shape, bool concurrent) { return (shape << 1) | (concurrent ? 1u : 0u); }
+  // the schedule for a proof of class `k`; *explore = this proof is a sample and must be reported
+  int pick(uint64_t k, bool concurrent, int explore_n, int fallback, bool* explore) {
+    *explore = false;
+    if (explore_n <= 0) return fallback;
+    std::lock_guard<std::mutex> lk(mu);
+    Entry& e = entries[k];
+    if (e.latched >= 0) return e.latched;
+    if (e.ncand == 0) {
+      if (concurrent) {
+        const int c[] = {SCHED_ONE_STREAM, SCHED_PIPELINE, SCHED_PIPELINE_SYNC, SCHED_ONE_STREAM_SPIN};
+        for (int v : c) e.cand[e.ncand++] = v;
+      } else {
+        const int c[] = {SCHED_PIPELINE, SCHED_PIPELINE_SYNC, SCHED_ONE_STREAM};
+        for (int v : c) e.cand[e.ncand++] = v;
+      }
+    }
+    int best = -1;
+    for (uint32_t i = 0; i < e.ncand; i++) {
+      const int v = e.cand[i];
+      if (e.started[v] >= (uint32_t)explore_n) continue;
+      if (best < 0 || e.started[v] < e.started[best]) best = v;
+    }
+    if (best < 0) return fallback;          // every sample is under way: wait for the reports
+    e.started[best]++;
+    *explore = true;
+    return best;
+  }
+  void report(uint64_t k, int variant, double ms, int explore_n) {
+    std::lock_guard<std::mutex> lk(mu);
+    Entry& e = entries[k];
+    if (e.latched >= 0 || variant < 0 || variant >= SCHED_COUNT) return;
+    e.done[variant]++;
+    e.sum_ms[variant] += ms;
+    int best = -1, best_polite = -1;
+    for (uint32_t i = 0; i < e.ncand; i++) {
+      const int v = e.cand[i];
+      if (e.done[v] < (uint32_t)explore_n) return;
+      const double mean = e.sum_ms[v] / e.done[v];
+      if (best < 0 || mean < e.sum_ms[best] / e.done[best]) best = v;
+      if (v != SCHED_ONE_STREAM_SPIN && (best_polite < 0 || mean < e.sum_ms[best_polite] / e.done[best_polite])) best_polite = v;
+    }
+    if (best == SCHED_ONE_STREAM_SPIN && best_polite >= 0 &&
+        e.sum_ms[best] / e.done[best] > 0.9 * e.sum_ms[best_polite] / e.done[best_polite])
+      best = best_polite;
+    e.latched = best;
+  }
+  // forget what was measured (ark355_sched_reset: tests, benches that change the load pattern)
+  void reset() {
+    std::lock_guard<std::mutex> lk(mu);
+    entries.clear();
+  }
+  bool info(uint64_t k, int* latched, double mean_ms[SCHED_COUNT], uint32_t samples[SCHED_COUNT]) {
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = entries.find(k);
+    if (it == entries.end()) return false;
+    *latched = it->second.latched;
+    for (int v = 0; v < SCHED_COUNT; v++) {
+      samples[v] = it->second.done[v];
+      mean_ms[v] = it->second.done[v] ? it->second.sum_ms[v] / it->second.done[v] : 0.0;
+    }
+    return true;
+  }
+};
+
+static inline uint64_t prove_shape(int curve, uint64_t N, uint64_t m) { return (N << 8) ^ (m << 1) ^ (uint64_t)curve; }
+
 // small proofs (N < 2^20) poll from the start: with eight 2^18 proofs in flight the long sleep cost 4 % (profiles/r03_epilogue_ab.txt)
 static inline bool epi_sleep_ok(uint64_t domain) { return domain >= (1ull << 20); }
 
@@ -99,14 +185,10 @@ struct ProverScratch {
   double drain_hist[4] = {0, 0, 0, 0};
   uint32_t drain_n = 0;
   uint64_t drain_shape = 0;
-  double drain_hint(uint64_t shape) const {
-    // OFF by default (ARK355_WAIT_ADAPT=1 turns it on): with the synchronises gone the proving threads cost 0.07-0.1 host
+  double drain_hint(bool adapt, uint64_t shape) const {
+    // OFF by default (policy WAIT_ADAPT=1 turns it on): with the synchronises gone the proving threads cost 0.07-0.1 host
     // cores with or without the sleep, and BN254 2^20 x 4 in flight ran 17.8 ms per proof with it against 16.6 without
     // (profiles/r03_epilogue_ab.txt) -- a thread that wakes up late starts its next proof late.
-    static const bool adapt = [] {
-      const char* e = getenv("ARK355_WAIT_ADAPT");
-      return e && e[0] == '1';
-    }();
     if (!adapt || shape != drain_shape || drain_n < 4) return 0.0;
     double mn = drain_hist[0];
     for (int i = 1; i < 4; i++) mn = drain_hist[i] < mn ? drain_hist[i] : mn;
@@ -129,7 +211,32 @@ struct ProverScratch {
   MsmSort sortZ, sortH;
   MsmBuckets bkA, bkB1, bkB2, bkL, bkH;
   BaScratch baA, baB1, baB2, baL, baH;      // batch-affine tree levels (msm_ba_impl.cuh), used when a table asks for them
-  hipStream_t sW = nullptr, sS = nullptr, sA = nullptr, sR = nullptr;
+  // feeder streams of the five-stream pipeline (witness map, sorts, reductions); the accumulations run on the
+  // context's own stream.  Created in ONE block under a process-wide lock (ensure_streams): the runtime hands out its
+  // few hardware queues per priority class round-robin in creation order, so three streams created back to back land
+  // on three different queues -- whereas four proving threads that create theirs concurrently can interleave so that
+  // all three feeder streams of one context share ONE in-order hardware queue (a reduction kernel waiting for its
+  // accumulation then blocks the NTT passes queued behind it): the box-to-box spread of the pipelined schedule.
+  hipStream_t sW = nullptr, sS = nullptr, sR = nullptr;
+  uint64_t warm_shape = 0;          // shape of the last proof on this context (its scratch and tables exist)
+  void ensure_streams(bool prio) {
+    if (sW) return;
+    static std::mutex create_mu;
+    std::lock_guard<std::mutex> lk(create_mu);
+    int prio_lo = 0, prio_hi = 0;
+#if !defined(ARK_EMUL)
+    if (prio) (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);     // hi is the numerically smaller value
+#endif
+    for (hipStream_t* st : {&sW, &sS, &sR}) {
+#if !defined(ARK_EMUL)
+      if (prio && prio_hi != prio_lo) {
+        ARK_CHECK_HIP(hipStreamCreateWithPriority(st, hipStreamDefault, prio_hi));
+        continue;
+      }
+#endif
+      ARK_CHECK_HIP(hipStreamCreate(st));
+    }
+  }
   // events of one proof, created once per context (prove_run used to create and destroy 23 of them per proof)
   static constexpr int N_EVENTS = 32;
   hipEvent_t events[N_EVENTS] = {};
@@ -142,7 +249,7 @@ struct ProverScratch {
   ~ProverScratch() {
     release_pinned();
     release_stage();
-    for (hipStream_t st : {sW, sS, sA, sR})
+    for (hipStream_t st : {sW, sS, sR})
       if (st) (void)hipStreamDestroy(st);
     for (auto& e : events)
       if (e) (void)hipEventDestroy(e);
@@ -311,7 +418,8 @@ static void combine_partials_host(const uint8_t* partials, uint64_t count, const
 }
 
 template <class Curve>
-static PkDev* pk_upload(const ark355_pk_desc* d, hipStream_t stream, uint32_t shard_index = 0, uint32_t shard_count = 1) {
+static PkDev* pk_upload(const TunePolicy& pol, const ark355_pk_desc* d, hipStream_t stream, uint32_t shard_index = 0,
+                        uint32_t shard_count = 1) {
   using Fq = typename Curve::Fq;
   using Fq2 = typename Curve::Fq2;
   constexpr size_t G1 = sizeof(Affine<Fq>), G2 = sizeof(Affine<Fq2>);
@@ -352,30 +460,34 @@ static PkDev* pk_upload(const ark355_pk_desc* d, hipStream_t stream, uint32_t sh
       // Window stride of the five tables: 1 (a table per window) whenever that fits next to the scratch of the proving
       // contexts that will work on this key (four of them: two sort areas of 16 B per (term, window), nine N-element NTT
       // buffers / tables each), otherwise the smallest stride that does; ARK355_ENOMEM when not even the bare vectors fit.
-      const TableNeed need[5] = {{pk->z_cnt, z_plan, false}, {pk->z_cnt, z_plan, false}, {pk->z_cnt, z_plan, true},
-                                 {pk->h_cnt, h_plan, false}, {pk->z_cnt, z_plan, false}};
-      const size_t scratch = 4 * ((size_t)16 * 17 * (pk->z_cnt + pk->h_cnt) + (size_t)9 * 32 * pk->N);
+      // The shards of one key must reach the SAME stride on every rank (the bucket-level exchange adds bucket arrays of
+      // different ranks): they plan from the device size alone and with the LARGEST shard's lengths -- the actual shard
+      // lengths differ by one between ranks.
+      const uint64_t zn = shard_count > 1 ? z_plan : pk->z_cnt, hn_ = shard_count > 1 ? h_plan : pk->h_cnt;
+      const TableNeed need[5] = {{zn, z_plan, false}, {zn, z_plan, false}, {zn, z_plan, true},
+                                 {hn_, h_plan, false, pol.msm_c_h}, {zn, z_plan, false}};
+      const size_t scratch = 4 * ((size_t)16 * 17 * (zn + hn_) + (size_t)9 * 32 * pk->N);
       std::string why;
-      pk->wstride = table_stride_plan<Fq, Fq2, Fr>(need, 5, table_budget_bytes(scratch, shard_count == 1), &why);
+      pk->wstride = table_stride_plan<Fq, Fq2, Fr>(pol, need, 5, table_budget_bytes(pol, scratch, shard_count == 1), &why);
       if (pk->wstride == 0) throw HipError{ARK355_ENOMEM, "proving key: " + why};
     }
     const uint32_t ws = pk->wstride;
     ext(d->a_query, G1, d->alpha_g1, d->delta_g1, nullptr);
-    precomp_build<Fq, Fr>(pk->a_ext, (uint8_t*)stage.p + pk->z_lo * G1, pk->z_cnt, stream, z_plan, ws);
+    precomp_build<Fq, Fr>(pol, pk->a_ext, (uint8_t*)stage.p + pk->z_lo * G1, pk->z_cnt, stream, z_plan, ws);
     ext(d->b_g1_query, G1, d->beta_g1, nullptr, d->delta_g1);
-    precomp_build<Fq, Fr>(pk->b1_ext, (uint8_t*)stage.p + pk->z_lo * G1, pk->z_cnt, stream, z_plan, ws);
+    precomp_build<Fq, Fr>(pol, pk->b1_ext, (uint8_t*)stage.p + pk->z_lo * G1, pk->z_cnt, stream, z_plan, ws);
     ext(d->b_g2_query, G2, d->beta_g2, nullptr, d->delta_g2);
-    precomp_build<Fq2, Fr>(pk->b2_ext, (uint8_t*)stage.p + pk->z_lo * G2, pk->z_cnt, stream, z_plan, ws);
+    precomp_build<Fq2, Fr>(pol, pk->b2_ext, (uint8_t*)stage.p + pk->z_lo * G2, pk->z_cnt, stream, z_plan, ws);
     stage.ensure((pk->h_cnt ? pk->h_cnt : 1) * G1);
     if (pk->h_cnt) ARK_CHECK_HIP(hipMemcpy(stage.p, d->h_query + pk->h_lo * G1, pk->h_cnt * G1, hipMemcpyDefault));
-    precomp_build<Fq, Fr>(pk->h_query, stage.p, pk->h_cnt, stream, h_plan, ws);
+    precomp_build<Fq, Fr>(pol, pk->h_query, stage.p, pk->h_cnt, stream, h_plan, ws, pol.msm_c_h);
     // l_ext aligned with zx: ell leading infinities (instance variables carry no l term), l_query, delta_1 at
     // the -rs slot, three trailing infinities
     stage.ensure((m + 4) * G1);
     ARK_CHECK_HIP(hipMemset(stage.p, 0, (m + 4) * G1));
     if (pk->w) ARK_CHECK_HIP(hipMemcpy((uint8_t*)stage.p + pk->ell * G1, d->l_query, pk->w * G1, hipMemcpyDefault));
     ARK_CHECK_HIP(hipMemcpy((uint8_t*)stage.p + m * G1, d->delta_g1, G1, hipMemcpyHostToDevice));
-    precomp_build<Fq, Fr>(pk->l_ext, (uint8_t*)stage.p + pk->z_lo * G1, pk->z_cnt, stream, z_plan, ws);
+    precomp_build<Fq, Fr>(pol, pk->l_ext, (uint8_t*)stage.p + pk->z_lo * G1, pk->z_cnt, stream, z_plan, ws);
     stage.release();
   } catch (...) {
     delete pk;
@@ -403,48 +515,24 @@ static void prove_run(ark355_ctx* ctx, ProverScratch& sc, const PkDev& pk, const
   ARK_REQUIRE(pk.curve == Curve::ID && r1.curve == Curve::ID, ARK355_EINVAL, "curve mismatch");
   ARK_REQUIRE(pk.ell == r1.ell && pk.w == r1.w && pk.N == r1.N, ARK355_EINVAL,
               "proving key and R1CS dimensions differ");
+  const TunePolicy& pol = ctx->policy;          // (the context's mutex is held: the policy cannot change under this proof)
   const auto t_enter = std::chrono::steady_clock::now();
   auto since = [&](std::chrono::steady_clock::time_point t) {
     return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count();
   };
-  static const bool trace_host = [] {
-    const char* e = getenv("ARK355_TRACE_HOST");
-    return e && e[0] == '1';
-  }();
+  const bool trace_host = pol.trace_host != 0;
   double t_launched = 0, t_synced = 0, t_tail = 0;
   hipStream_t sM = ctx->stream;
-  // The short kernels that feed the accumulations (witness map, sorts) and the latency-bound reductions outrank the
-  // long accumulation launches: when workgroup slots free up, a waiting NTT pass or sort of ANOTHER proof in flight
-  // is dispatched before the next round of accumulation workgroups, which keeps an accumulation queued at all times.
-  // ARK355_STREAM_PRIO=0 turns it off (A/B).
-  static const bool prio = [] {
-    const char* e = getenv("ARK355_STREAM_PRIO");
-    return !(e && e[0] == '0');
-  }();
-  int prio_lo = 0, prio_hi = 0;
-#if !defined(ARK_EMUL)
-  if (prio) (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);     // hi is the numerically smaller value
-#endif
-  for (hipStream_t* st : {&sc.sW, &sc.sS, &sc.sR}) {
-    if (*st) continue;
-#if !defined(ARK_EMUL)
-    if (prio && prio_hi != prio_lo) {
-      ARK_CHECK_HIP(hipStreamCreateWithPriority(st, hipStreamDefault, prio_hi));
-      continue;
-    }
-#endif
-    ARK_CHECK_HIP(hipStreamCreate(st));
-  }
-  if (!sc.sA) ARK_CHECK_HIP(hipStreamCreate(&sc.sA));      // default = lowest of the two levels gfx950 exposes
-  // Schedule.  A proof ALONE on the device runs as the five-stream pipeline below (the latency-bound tails of one MSM hide
-  // under the next MSM's accumulation: 26.9 against 31.7 ms for a single 2^20 proof).  With OTHER proofs in flight the same
-  // proof runs on ONE stream: the gaps are filled by the other proofs' kernels anyway, and the pipeline's cross-stream
-  // waits cost more than they buy -- HIP maps its streams onto a few in-order hardware queues, so a kernel that waits for
-  // an event of its own proof blocks the ready kernels of other proofs queued behind it (the 2^18 x 8 timeline shows a
-  // kernel running 99.9 % of the time but an accumulation only 77 %).  Measured, same box (profiles/r03_one_stream_ab.txt):
-  // BLS12-381 2^20 23.81 -> 23.42 ms per proof at four in flight (23.25 at eight) on 0.14 instead of 0.93 host cores,
-  // BN254 2^20 16.1 -> 15.0 ms, 2^18 8.28 -> 7.38 ms at six in flight (7.23 at twelve).  The choice is made per proof from
-  // the number of proofs in flight on the device when it starts; ARK355_SERIAL=1 / 0 forces one stream / the pipeline.
+  // Schedule.  A proof ALONE on the device runs best as the five-stream pipeline below (the latency-bound tails of one MSM
+  // hide under the next MSM's accumulation: 26.9 against 31.7 ms for a single 2^20 proof).  With OTHER proofs in flight the
+  // same proof runs best on ONE stream: the gaps are filled by the other proofs' kernels anyway, and the pipeline's
+  // cross-stream waits cost more than they buy -- HIP maps its streams onto a few in-order hardware queues, so a kernel that
+  // waits for an event of its own proof blocks the ready kernels of other proofs queued behind it (the 2^18 x 8 timeline
+  // shows a kernel running 99.9 % of the time but an accumulation only 77 %).  Measured, same box
+  // (profiles/r03_one_stream_ab.txt): BLS12-381 2^20 23.81 -> 23.42 ms per proof at four in flight on 0.14 instead of 0.93
+  // host cores, BN254 2^20 16.1 -> 15.0 ms, 2^18 8.28 -> 7.38 ms at six in flight.  Those are the STATIC defaults; with
+  // policy SCHED = AUTO (the default) they are only the starting point of a measured choice per class (SchedTuner above),
+  // and SCHED = 0..3 forces one schedule for every proof of the context.
   struct InFlight {
     std::atomic<int>& c;
     int mine;
@@ -453,32 +541,57 @@ static void prove_run(ark355_ctx* ctx, ProverScratch& sc, const PkDev& pk, const
   };
   static std::atomic<int> g_inflight[64];
   InFlight inflight(g_inflight[(unsigned)ctx->device & 63u]);
-  const int serial_force = [] {                      // read per proof: the tests flip it
-    const char* e = getenv("ARK355_SERIAL");
-    return e ? (e[0] == '1' ? 1 : 0) : -1;
-  }();
-  const bool one_stream = serial_force >= 0 ? serial_force == 1 : (inflight.mine >= 2 && !cm);
-  hipStream_t sW = one_stream ? sM : sc.sW, sS = one_stream ? sM : sc.sS, sA = one_stream ? sM : sc.sA,
-              sR = one_stream ? sM : sc.sR;
+  const bool concurrent = inflight.mine >= 2;
+  const uint64_t shape = prove_shape(Curve::ID, pk.N, pk.m);
+  // measured regimes of the pipeline's epilogue (profiles/r03_epilogue_ab.txt): BLS12-381 N = 2^21 / 2^22 / 2^23 win without
+  // the stream synchronises, small proofs and BN254 with them
+  const int static_alone = (pk.N >= (1ull << 20) && sizeof(Fq) >= 48) ? SCHED_PIPELINE : SCHED_PIPELINE_SYNC;
+  const int static_sched = (concurrent && !cm) ? SCHED_ONE_STREAM : static_alone;
+  int sched = pol.sched;
+  bool exploring = false;
+  const uint64_t tune_key = SchedTuner::key(shape, concurrent);
+  if (cm) {
+    // a sharded proof is a collective: every rank must queue the same operations in the same order on the same kind of
+    // stream, so the choice cannot depend on one rank's measurements
+    if (sched < 0 || sched >= SCHED_COUNT) sched = static_sched;
+  } else if (sched < 0 || sched >= SCHED_COUNT) {
+    const bool warm = sc.warm_shape == shape;
+    sched = warm ? SchedTuner::of(ctx->device).pick(tune_key, concurrent, pol.sched_explore, static_sched, &exploring)
+                 : static_sched;
+  }
+  sc.warm_shape = shape;
+  ctx->last_sched = sched;
+  const bool one_stream = sched == SCHED_ONE_STREAM || sched == SCHED_ONE_STREAM_SPIN;
+  const bool spin = pol.wait_spin != 0 || sched == SCHED_ONE_STREAM_SPIN;
+  // The short kernels that feed the accumulations (witness map, sorts) and the latency-bound reductions outrank the
+  // long accumulation launches: when workgroup slots free up, a waiting NTT pass or sort of ANOTHER proof in flight
+  // is dispatched before the next round of accumulation workgroups, which keeps an accumulation queued at all times.
+  // Policy STREAM_PRIO=0 turns it off (A/B).
+  if (!one_stream) sc.ensure_streams(pol.stream_prio != 0);
+  hipStream_t sW = one_stream ? sM : sc.sW, sS = one_stream ? sM : sc.sS, sA = sM, sR = one_stream ? sM : sc.sR;
   const uint64_t m = pk.m, ell = pk.ell;
-  if (cm && cm->world > 1 && !pk.shard_plan_checked.load()) {
+  if (cm && cm->world > 1) {
     // Every rank must have planned the same window size and table stride for its shard: the bucket-level exchange adds
     // bucket arrays of different ranks element by element.  The planners are deterministic functions of the key's
-    // dimensions and the device size, but an environment override on one rank (ARK355_MSM_C, ARK355_TABLE_STRIDE,
-    // ARK355_HBM_BUDGET_MB) would break that silently -- so the ranks compare notes once per key, over the communicator.
+    // dimensions and the device size, but a policy override on one rank (MSM_C, TABLE_STRIDE, HBM_BUDGET_MB) would break
+    // that silently -- so the ranks compare notes over the communicator, on EVERY sharded proof: a per-process "already
+    // checked" flag could differ between ranks (one rank reloaded its shard, or failed before it set the flag), and then
+    // only some ranks would enter this all-gather while the others went on to the ring steps -- mismatched collectives on
+    // one communicator.  16 bytes per rank and one stream synchronise: ~50 us against a proof of tens of milliseconds.
     const uint32_t mine[4] = {pk.a_ext.plan.c, pk.a_ext.plan.wstride, pk.h_query.plan.c, pk.h_query.plan.wstride};
     cm->gather.ensure(sizeof(mine) * (size_t)(cm->world + 1));
     uint8_t* d_mine = cm->gather.as<uint8_t>() + sizeof(mine) * (size_t)cm->world;
-    ARK_CHECK_HIP(hipMemcpyAsync(d_mine, mine, sizeof(mine), hipMemcpyHostToDevice, sM));
+    uint8_t* stg = static_cast<uint8_t*>(sc.stage());
+    memcpy(stg + ProverScratch::STAGE_BYTES - sizeof(mine), mine, sizeof(mine));
+    ARK_CHECK_HIP(hipMemcpyAsync(d_mine, stg + ProverScratch::STAGE_BYTES - sizeof(mine), sizeof(mine), hipMemcpyHostToDevice, sM));
     ARK_CHECK_NCCL(ncclAllGather(d_mine, cm->gather.p, sizeof(mine), ncclUint8, cm->comm, sM));
-    std::vector<uint32_t> all(4 * (size_t)cm->world);
-    ARK_CHECK_HIP(hipMemcpyAsync(all.data(), cm->gather.p, sizeof(mine) * (size_t)cm->world, hipMemcpyDeviceToHost, sM));
+    uint32_t* all = reinterpret_cast<uint32_t*>(sc.pinned(sizeof(mine) * (size_t)cm->world));
+    ARK_CHECK_HIP(hipMemcpyAsync(all, cm->gather.p, sizeof(mine) * (size_t)cm->world, hipMemcpyDeviceToHost, sM));
     ARK_CHECK_HIP(hipStreamSynchronize(sM));
     for (int g = 0; g < cm->world; g++)
       for (int k = 0; k < 4; k++)
         ARK_REQUIRE(all[4 * (size_t)g + k] == mine[k], ARK355_EINVAL,
                     "key shards of different ranks were planned with different window sizes / table strides");
-    pk.shard_plan_checked.store(true);
   }
   enum { E_START, E_Z, E_H, E_SORT0, E_SORT1, E_SORT2, E_ACC_DONE0, E_END = E_ACC_DONE0 + 5, E_COUNT };
   static_assert(E_COUNT + 10 <= ProverScratch::N_EVENTS, "event pool too small");
@@ -522,15 +635,15 @@ static void prove_run(ark355_ctx* ctx, ProverScratch& sc, const PkDev& pk, const
     msm_sort<Fr>(ctx, sc.sortZ, (const uint8_t*)sc.zx.p + pk.z_lo * sizeof(Fr), pk.z_cnt, 1, sS, &pk.a_ext);
     // bucket sets are sized and cleared here, behind the sort they belong to (msm_prepare_phase)
     // (a batch-affine MSM sizes its bucket set later, for the nodes its tree levels leave over)
-    if (!pk.b2_ext.batch_affine) msm_prepare_phase<Fq2>(sc.sortZ, sc.bkB2, sS);
-    if (!pk.a_ext.batch_affine) msm_prepare_phase<Fq>(sc.sortZ, sc.bkA, sS);
-    if (!pk.b1_ext.batch_affine) msm_prepare_phase<Fq>(sc.sortZ, sc.bkB1, sS);
-    if (!pk.l_ext.batch_affine) msm_prepare_phase<Fq>(sc.sortZ, sc.bkL, sS);
+    if (!pk.b2_ext.batch_affine) msm_prepare_phase<Fq2>(pol, sc.sortZ, sc.bkB2, sS);
+    if (!pk.a_ext.batch_affine) msm_prepare_phase<Fq>(pol, sc.sortZ, sc.bkA, sS);
+    if (!pk.b1_ext.batch_affine) msm_prepare_phase<Fq>(pol, sc.sortZ, sc.bkB1, sS);
+    if (!pk.l_ext.batch_affine) msm_prepare_phase<Fq>(pol, sc.sortZ, sc.bkL, sS);
     ARK_CHECK_HIP(hipEventRecord(ev[E_SORT0], sS));
     ARK_CHECK_HIP(hipEventRecord(ev[E_SORT1], sS));     // (L' shares the sort of zx)
     ARK_CHECK_HIP(hipStreamWaitEvent(sS, ev[E_H], 0));
     msm_sort<Fr>(ctx, sc.sortH, (const uint8_t*)d_h + pk.h_lo * sizeof(Fr), pk.h_cnt, 1, sS, &pk.h_query);
-    if (!pk.h_query.batch_affine) msm_prepare_phase<Fq>(sc.sortH, sc.bkH, sS);
+    if (!pk.h_query.batch_affine) msm_prepare_phase<Fq>(pol, sc.sortH, sc.bkH, sS);
     ARK_CHECK_HIP(hipEventRecord(ev[E_SORT2], sS));
 
     // accumulations (A, B1, B2 share the sort of zx) and, per MSM, its reduction on sR
@@ -591,7 +704,6 @@ static void prove_run(ark355_ctx* ctx, ProverScratch& sc, const PkDev& pk, const
     }
 
     if (out) memset(out, 0, sizeof(*out));
-    const char* dev_fin = getenv("ARK355_DEVICE_FINALIZE");
     if (cm) {
       // sharded prove: all-gather of the five XYZZ partial sums (A, B1, L', H in G1, then B2 in G2) straight from HBM
       // on the reduction stream, then the O(world) additions and the O(1) tail on the host -- on every rank
@@ -602,7 +714,7 @@ static void prove_run(ark355_ctx* ctx, ProverScratch& sc, const PkDev& pk, const
       uint8_t* all = static_cast<uint8_t*>(sc.pinned(all_bytes));
       ARK_CHECK_HIP(hipMemcpyAsync(all, cm->gather.p, all_bytes, hipMemcpyDeviceToHost, sR));
       ARK_CHECK_HIP(hipEventRecord(ev[E_END], sR));
-      wait_event_polite(ev[E_END]);
+      wait_event_polite(ev[E_END], spin);
       combine_partials_host<Curve>(all, (uint64_t)cm->world, r_canon, s_canon, out);
     } else if (partials_out) {
       // sharded prove: hand back the five XYZZ partial sums (A, B1, L', H in G1, then B2 in G2)
@@ -610,9 +722,9 @@ static void prove_run(ark355_ctx* ctx, ProverScratch& sc, const PkDev& pk, const
       void* land = sc.pinned(psz);
       ARK_CHECK_HIP(hipMemcpyAsync(land, g1res, psz, hipMemcpyDeviceToHost, sR));
       ARK_CHECK_HIP(hipEventRecord(ev[E_END], sR));
-      wait_event_polite(ev[E_END]);
+      wait_event_polite(ev[E_END], spin);
       memcpy(partials_out, land, psz);
-    } else if (dev_fin && dev_fin[0] == '1') {
+    } else if (pol.device_finalize) {
       ARK_LAUNCH((groth16_finalize_kernel<Curve>), dim3(1), dim3(192), 0, sR, (const XYZZ<Fq>*)g1res,
                  (const XYZZ<Fq2>*)g2res, sc.rs.as<Fr>(), sc.proof.as<unsigned char>());
       ARK_CHECK_LAUNCH();
@@ -620,7 +732,7 @@ static void prove_run(ark355_ctx* ctx, ProverScratch& sc, const PkDev& pk, const
       uint8_t* land = static_cast<uint8_t*>(sc.pinned(fsz));
       ARK_CHECK_HIP(hipMemcpyAsync(land, sc.proof.p, fsz, hipMemcpyDeviceToHost, sR));
       ARK_CHECK_HIP(hipEventRecord(ev[E_END], sR));
-      wait_event_polite(ev[E_END]);
+      wait_event_polite(ev[E_END], spin);
       memcpy(out->a, land, sizeof(Affine<Fq>));
       memcpy(out->b, land + sizeof(Affine<Fq>), sizeof(Affine<Fq2>));
       memcpy(out->c, land + sizeof(Affine<Fq>) + sizeof(Affine<Fq2>), sizeof(Affine<Fq>));
@@ -631,9 +743,8 @@ static void prove_run(ark355_ctx* ctx, ProverScratch& sc, const PkDev& pk, const
       ARK_CHECK_HIP(hipMemcpyAsync(land, g1res, sizeof(h1) + sizeof(h2), hipMemcpyDeviceToHost, sR));
       ARK_CHECK_HIP(hipEventRecord(ev[E_END], sR));
       t_launched = since(t_enter);
-      const uint64_t shape = (pk.N << 8) ^ (pk.m << 1) ^ (uint64_t)Curve::ID;
       bool overslept = false;
-      wait_event_polite(ev[E_END], epi_sleep_ok(pk.N) ? sc.drain_hint(shape) : 0.0, &overslept);
+      wait_event_polite(ev[E_END], spin, epi_sleep_ok(pk.N) ? sc.drain_hint(pol.wait_adapt != 0, shape) : 0.0, &overslept);
       t_synced = since(t_enter);
       sc.drain_record(shape, t_synced - t_launched, overslept);
       memcpy(h1, land, sizeof(h1));
@@ -642,35 +753,25 @@ static void prove_run(ark355_ctx* ctx, ProverScratch& sc, const PkDev& pk, const
       t_tail = since(t_enter);
     }
     // Every stream has drained into sR through the event chain: E_END completes only after the last event of sW (E_H),
-    // sS (E_SORT2) and sA (E_ACC_DONE0 + 4); nothing else is queued on them.  The prover used to call hipStreamSynchronize
-    // on the three streams here.  That is NOT free: HIP streams share a handful of hardware queues, and a synchronise on
-    // an idle stream of this proof waits -- spinning -- for the other proofs' kernels in the same queue: 22 and 82 ms in
-    // two of six traced 2^20 proofs with four in flight (profiles/r03_host_cpu.txt), i.e. 0.3 host cores per proof in
-    // flight and as many milliseconds in which the proving thread cannot start its next proof.  Measured, same box
-    // (profiles/r03_epilogue_ab.txt): without them 2^20 x 4 in flight runs 23.9 instead of 24.7 ms per proof on 0.8 instead
-    // of 1.5 host cores -- but 2^18 x 8 in flight runs 10.8 instead of 8.5 ms (the spinning threads evidently keep the
-    // runtime's dependency handling prompt when eight short proofs are in flight; not understood further).  So: large
-    // proofs check the three events (complete by construction), small ones keep the synchronises.
-    // ARK355_EPILOGUE_SYNC=0|1 forces either behaviour (A/B).
-    static const int epi_force = [] {
-      const char* e = getenv("ARK355_EPILOGUE_SYNC");
-      return e ? (e[0] == '1' ? 1 : 0) : -1;
-    }();
-    // measured regimes: BLS12-381 N = 2^21 / 2^22 / 2^23 win without (23.9 vs 24.7 ms at 2^20 x 4 in flight); BLS12-381 2^18 x 8
-    // in flight (8.5 vs 10.8 ms) and BN254 2^20 x 4 in flight (15.6 vs 16.6 ms) win with them
-    // (one-stream schedule: the only stream has drained when E_END fired)
-    const bool epi_sync = epi_force >= 0 ? epi_force == 1 : (!one_stream && !(pk.N >= (1ull << 20) && sizeof(Fq) >= 48));
-    if (epi_sync) {
-      ARK_CHECK_HIP(hipStreamSynchronize(sA));
+    // sS (E_SORT2) and the accumulation stream (E_ACC_DONE0 + 4); nothing else is queued on them.  The prover used to call
+    // hipStreamSynchronize on the feeder streams here.  That is NOT free: HIP streams share a handful of hardware queues, and
+    // a synchronise on an idle stream of this proof waits -- spinning -- for the other proofs' kernels in the same queue: 22
+    // and 82 ms in two of six traced 2^20 proofs with four in flight (profiles/r03_host_cpu.txt).  Measured, same box
+    // (profiles/r03_epilogue_ab.txt): without them 2^20 x 4 in flight ran 23.9 instead of 24.7 ms per proof on 0.8 instead of
+    // 1.5 host cores -- but 2^18 x 8 in flight 10.8 instead of 8.5 ms.  Both epilogues are therefore SCHEDULES
+    // (SCHED_PIPELINE checks the three events, SCHED_PIPELINE_SYNC synchronises) and the choice between them is measured
+    // per class like the rest; a one-stream proof has nothing to synchronise.
+    if (sched == SCHED_PIPELINE_SYNC) {
       ARK_CHECK_HIP(hipStreamSynchronize(sS));
       ARK_CHECK_HIP(hipStreamSynchronize(sW));
-    } else {
+    } else if (!one_stream) {
       for (hipEvent_t last : {ev[E_ACC_DONE0 + 4], ev[E_SORT2], ev[E_H]}) {
         const hipError_t q = hipEventQuery(last);
-        if (q == hipErrorNotReady) wait_event_polite(last);
+        if (q == hipErrorNotReady) wait_event_polite(last, spin);
         else if (q != hipSuccess) ARK_CHECK_HIP(q);
       }
     }
+    if (exploring) SchedTuner::of(ctx->device).report(tune_key, sched, since(t_enter), pol.sched_explore);
     auto el = [&](hipEvent_t a, hipEvent_t b) {
       float ms = 0;
       (void)hipEventElapsedTime(&ms, a, b);

@@ -271,13 +271,9 @@ ba_tail_entries_kernel(const uint32_t* __restrict__ off, const uint32_t* __restr
   }
 }
 
-static inline uint32_t ba_levels() {
-  uint32_t levels = 5;
-  if (const char* e = getenv("ARK355_BA_LEVELS")) {
-    const int v = atoi(e);
-    if (v >= 1 && v <= (int)BA_MAX_LEVELS) levels = (uint32_t)v;
-  }
-  return levels;
+static inline uint32_t ba_levels(const TunePolicy& pol) {
+  const int v = pol.ba_levels;
+  return (v >= 1 && v <= (int)BA_MAX_LEVELS) ? (uint32_t)v : 5u;
 }
 
 // Accumulation phase of one MSM over an existing sort, batch-affine flavour.  `table`: window table in the canonical
@@ -291,7 +287,7 @@ static const MsmSort& msm_ba_accumulate_phase(ark355_ctx* ctx, const MsmSort& s,
   ARK_REQUIRE(p.precomp && p.key_windows == 1, ARK355_EINVAL, "batch-affine accumulation needs window tables");
   const uint32_t nb = p.total_buckets;
   const uint64_t entries = (uint64_t)p.windows * p.n;
-  const uint32_t levels = ba_levels();
+  const uint32_t levels = ba_levels(ctx->policy);
   // upper bounds of the node counts per level (the exact totals live on the device)
   uint64_t bound[BA_MAX_LEVELS + 1];
   bound[0] = entries;
@@ -365,7 +361,7 @@ static const MsmSort& msm_ba_accumulate_phase(ark355_ctx* ctx, const MsmSort& s,
   }
   // the survivors as a sorted entry list for the XYZZ path
   const uint64_t tail_entries = bound[levels];
-  if (getenv("ARK355_TRACE_HOST"))
+  if (ctx->policy.trace_host)
     fprintf(stderr, "[ark355] batch-affine accumulation: %u levels over <= %llu entries, <= %llu nodes to the XYZZ tail\n", levels,
             (unsigned long long)entries, (unsigned long long)tail_entries);
   tail.plan.n = (tail_entries + p.windows - 1) / p.windows;      // the phases size their segments from windows * n

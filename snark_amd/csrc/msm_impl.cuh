@@ -48,9 +48,6 @@ constexpr uint32_t MSM_THREADS = 256;
 #ifndef ARK_G1_PREFETCH
 #define ARK_G1_PREFETCH 1   // measured neutral on MI355X (7.75 vs 7.79 ms for A+B1); kept for small-n latency
 #endif
-#ifndef ARK_G2_INLINE_DEFAULT
-#define ARK_G2_INLINE_DEFAULT 1
-#endif
 
 struct MsmPlan {
   uint64_t n = 0;
@@ -78,12 +75,10 @@ struct MsmPlan {
 // workgroups = exactly two rounds, but 13 windows (c = 20) / 64 = 832 workgroups still take two rounds -- the second
 // 62 % full -- and the saved additions buy nothing (measured in round 1: -19 % entries, -5 % time).  The length is
 // therefore chosen so that the segments fill a whole number of rounds: nearest round count at ~64 entries per lane,
-// then ceil(entries / (slots x rounds)).  pair_lanes: the G2 kernels use two lanes per segment.  ARK355_MSM_SEG=<len> overrides (A/B, tests).
-static inline uint32_t msm_seg_len(uint64_t entries, bool pair_lanes) {
-  if (const char* e = getenv("ARK355_MSM_SEG")) {
-    const int v = atoi(e);
-    if (v >= 1 && v <= 4096) return (uint32_t)v;
-  }
+// then ceil(entries / (slots x rounds)).  pair_lanes: the G2 kernels use two lanes per segment.  force: TunePolicy::msm_seg
+// (policy MSM_SEG=<len>: A/B, tests).
+static inline uint32_t msm_seg_len(uint64_t entries, bool pair_lanes, int force = 0) {
+  if (force >= 1 && force <= 4096) return (uint32_t)force;
 #if defined(ARK_EMUL)
   const uint64_t cus = 1;
 #else
@@ -107,7 +102,9 @@ static inline uint32_t msm_seg_len(uint64_t entries, bool pair_lanes) {
 
 struct MsmPlan;
 static inline int msm_digit_flags(const MsmPlan& p);
-inline MsmPlan msm_plan(uint64_t n, uint32_t scalar_bits, bool precomp = false, int force_c = 0, uint32_t force_stride = 0) {
+// pref_c: TunePolicy::msm_c -- the window size asked for resident tables (0: this planner's choice)
+inline MsmPlan msm_plan(uint64_t n, uint32_t scalar_bits, bool precomp = false, int force_c = 0, uint32_t force_stride = 0,
+                        int pref_c = 0) {
   MsmPlan p;
   p.n = n;
   p.precomp = precomp;
@@ -139,10 +136,8 @@ inline MsmPlan msm_plan(uint64_t n, uint32_t scalar_bits, bool precomp = false, 
     if (found) break;
   }
   if (precomp && !force_c) {
-    // tuning knob for resident keys (window tables): ARK355_MSM_C=<bits>
-    const char* e = getenv("ARK355_MSM_C");        // read per plan (key load), not cached: tests flip it
-    const int env_c = e ? atoi(e) : 0;
-    if (env_c >= 4 && env_c <= 24 && n >= 1024) c = env_c;
+    // tuning knob for resident keys (window tables): policy MSM_C=<bits>, applied when the key is loaded
+    if (pref_c >= 4 && pref_c <= 24 && n >= 1024) c = pref_c;
   }
   if (force_c) c = force_c;     // an MSM over window tables must use the window size the tables were built for
   p.c = (uint32_t)c;
@@ -1221,20 +1216,15 @@ struct PrecompTable {
   bool batch_affine = false;   // canonical affine rows, accumulated by msm_ba_impl.cuh (ARK355_G1/G2_BATCH_AFFINE=1)
 };
 
-#ifndef ARK_LIMB28_DEFAULT
-#define ARK_LIMB28_DEFAULT 1
-#endif
-// ARK355_LIMB28=0|1 / ARK355_G2_LIMB28=0|1 (both default 1): window tables and bucket accumulation of G1 / G2 in the
+// policy LIMB28=0|1 / G2_LIMB28=0|1 (both default 1): window tables and bucket accumulation of G1 / G2 in the
 // radix-2^28 form (msm28_impl.cuh); 0 keeps the 32-bit kernels (A/B switches, exercised by the tests).
-// ARK355_G2_BATCH_AFFINE=1 / ARK355_G1_BATCH_AFFINE=1: the window table of that group stays in the canonical affine
+// policy G2_BATCH_AFFINE=1 / G1_BATCH_AFFINE=1: the window table of that group stays in the canonical affine
 // form and its bucket accumulation runs as batch-affine tree levels (msm_ba_impl.cuh).  Read when a table is built.
-static inline bool msm_use_batch_affine(bool g2) {
-  const char* e = getenv(g2 ? "ARK355_G2_BATCH_AFFINE" : "ARK355_G1_BATCH_AFFINE");
-  return e && e[0] == '1';
+static inline bool msm_use_batch_affine(const TunePolicy& pol, bool g2) {
+  return (g2 ? pol.g2_batch_affine : pol.g1_batch_affine) != 0;
 }
-static inline bool msm_use_limb28(bool g2) {       // read when a table is built (not cached: tests flip it)
-  const char* e = getenv(g2 ? "ARK355_G2_LIMB28" : "ARK355_LIMB28");
-  return e ? (e[0] == '1') : (ARK_LIMB28_DEFAULT != 0);
+static inline bool msm_use_limb28(const TunePolicy& pol, bool g2) {       // read when a table is built
+  return (g2 ? pol.g2_limb28 : pol.limb28) != 0;
 }
 
 // ---- HBM footprint of window tables -------------------------------------------------------------------------------------
@@ -1253,17 +1243,15 @@ struct TableNeed {          // one base vector of a key
   uint64_t n;               // rows per window block
   uint64_t plan_n;          // length the window size is planned for (shards: the largest shard)
   bool g2;
+  int pref_c = 0;           // window size asked for this vector alone (policy MSM_C_H for h_query); 0: policy MSM_C
 };
 
-// HBM budget for the resident tables of ONE key / base set: ARK355_HBM_BUDGET_MB (tests, A/B) or 80 % of the device
+// HBM budget for the resident tables of ONE key / base set: policy HBM_BUDGET_MB (tests, A/B) or 80 % of the device
 // minus a reserve for the proving contexts' scratch (`scratch_bytes`, the caller's estimate); `use_free`: also stay
 // inside what is free right now (whole keys; the shards of one key plan from the device size alone so that every rank
 // reaches the same stride -- the bucket-level exchange adds bucket arrays of different ranks).
-static inline size_t table_budget_bytes(size_t scratch_bytes, bool use_free) {
-  if (const char* e = getenv("ARK355_HBM_BUDGET_MB")) {
-    const long long v = atoll(e);
-    if (v > 0) return (size_t)v << 20;
-  }
+static inline size_t table_budget_bytes(const TunePolicy& pol, size_t scratch_bytes, bool use_free) {
+  if (pol.hbm_budget_mb > 0) return (size_t)pol.hbm_budget_mb << 20;
 #if defined(ARK_EMUL)
   (void)scratch_bytes;
   (void)use_free;
@@ -1280,19 +1268,18 @@ static inline size_t table_budget_bytes(size_t scratch_bytes, bool use_free) {
 // smallest stride whose tables (all vectors resident + the two-window staging area of the one being built) fit `budget`;
 // 0 when not even the bare base vectors do
 template <class Fq, class Fq2, class Fr>
-static inline uint32_t table_stride_plan(const TableNeed* need, int count, size_t budget, std::string* why) {
-  if (const char* e = getenv("ARK355_TABLE_STRIDE")) {       // tests / A/B: force a stride
-    const int v = atoi(e);
-    if (v >= 1 && v <= 64) return (uint32_t)v;
-  }
+static inline uint32_t table_stride_plan(const TunePolicy& pol, const TableNeed* need, int count, size_t budget, std::string* why) {
+  if (pol.table_stride >= 1 && pol.table_stride <= 64) return (uint32_t)pol.table_stride;       // tests / A/B: force a stride
   uint32_t max_windows = 1;
   for (uint32_t s = 1;; s++) {
     size_t resident = 0, stage = 0;
     for (int i = 0; i < count; i++) {
+      const int pc = need[i].pref_c ? need[i].pref_c : pol.msm_c;
       const MsmPlan p = msm_plan(need[i].n, Fr::Params::BITS, true,
-                                 need[i].plan_n ? (int)msm_plan(need[i].plan_n, Fr::Params::BITS, true).c : 0, s);
+                                 need[i].plan_n ? (int)msm_plan(need[i].plan_n, Fr::Params::BITS, true, 0, 0, pc).c : 0, s, pc);
       if (p.windows > max_windows) max_windows = p.windows;
-      const bool l28 = msm_use_limb28(need[i].g2) && !msm_use_batch_affine(need[i].g2);
+      // (precomp_build drops batch-affine when the stride is > 1)
+      const bool l28 = msm_use_limb28(pol, need[i].g2) && !(msm_use_batch_affine(pol, need[i].g2) && s == 1);
       const size_t row = need[i].g2 ? table_row_bytes<Fq2>(l28) : table_row_bytes<Fq>(l28);
       const size_t aff = need[i].g2 ? sizeof(Affine<Fq2>) : sizeof(Affine<Fq>);
       const size_t xyzz = need[i].g2 ? sizeof(XYZZ<Fq2>) : sizeof(XYZZ<Fq>);
@@ -1313,20 +1300,22 @@ static inline uint32_t table_stride_plan(const TableNeed* need, int count, size_
 // plan_n: the length the window size is chosen for (0 = n).  The shards of one key pass the LARGEST shard length so
 // that every rank uses the same window size -- the bucket-level exchange adds bucket arrays of different ranks.
 // wstride: MsmPlan::wstride (from table_stride_plan).
+// pref_c: window size asked for this table alone (0: policy MSM_C).
 template <class F, class Fr>
-static void precomp_build(PrecompTable& t, const void* d_bases, uint64_t n, hipStream_t stream, uint64_t plan_n = 0,
-                          uint32_t wstride = 1) {
+static void precomp_build(const TunePolicy& pol, PrecompTable& t, const void* d_bases, uint64_t n, hipStream_t stream,
+                          uint64_t plan_n = 0, uint32_t wstride = 1, int pref_c = 0) {
   t.n = n;
+  const int pc = pref_c ? pref_c : pol.msm_c;
   t.plan = msm_plan(n, Fr::Params::BITS, /*precomp=*/true,
-                    plan_n ? (int)msm_plan(plan_n, Fr::Params::BITS, /*precomp=*/true).c : 0, wstride);
+                    plan_n ? (int)msm_plan(plan_n, Fr::Params::BITS, /*precomp=*/true, 0, 0, pc).c : 0, wstride, pc);
   const MsmPlan& p = t.plan;
   const uint32_t TW = p.table_windows;
   ARK_REQUIRE((uint64_t)TW * n < (1ull << 31), ARK355_EINVAL, "window table too large for 31-bit indices");
-  if (getenv("ARK355_TRACE_HOST"))
+  if (pol.trace_host)
     fprintf(stderr, "[ark355] window table: %llu bases, c = %u, %u windows (%u table blocks, %u bucket sets)%s\n",
             (unsigned long long)n, p.c, p.windows, TW, p.key_windows, p.negate_high ? ", scalars above (r - 1) / 2 negated" : "");
-  const bool ba = msm_use_batch_affine(is_fp2<F>::value) && p.wstride == 1;
-  const bool l28 = !ba && msm_use_limb28(is_fp2<F>::value);
+  const bool ba = msm_use_batch_affine(pol, is_fp2<F>::value) && p.wstride == 1;
+  const bool l28 = !ba && msm_use_limb28(pol, is_fp2<F>::value);
   const uint32_t grid = (uint32_t)((n + MSM_THREADS - 1) / MSM_THREADS);
   const uint32_t gridb = (uint32_t)(((n + PRE_K - 1) / PRE_K + MSM_THREADS - 1) / MSM_THREADS);
   const uint32_t shift = p.c * p.wstride;              // consecutive table blocks differ by 2^(c * wstride)
@@ -1425,11 +1414,9 @@ static void msm_sort(ark355_ctx* ctx, MsmSort& s, const void* d_scalars, uint64_
   ARK_CHECK_HIP(hipMemsetAsync(s.counts.p, 0, (size_t)p.total_buckets * 4, stream));
   ARK_CHECK_HIP(hipMemsetAsync(s.cursor.p, 0, (size_t)p.total_buckets * 4, stream));
   const uint32_t bins = (p.total_buckets + SORT_LO - 1) / SORT_LO;
-  // ARK355_SORT=legacy: the one-pass counting sort (A/B switch; also taken when level 1 would not fit LDS)
-  static const bool legacy = [] {
-    const char* e = getenv("ARK355_SORT");
-    return e && e[0] == 'l';
-  }();
+  // policy SORT_LEGACY=1 (env ARK355_SORT=legacy): the one-pass counting sort (A/B switch; also taken when level 1
+  // would not fit LDS)
+  const bool legacy = ctx->policy.sort_legacy != 0;
   if (legacy || bins > SORT_MAX_BINS) {
     const uint32_t grid_n = (uint32_t)((n + MSM_THREADS - 1) / MSM_THREADS);
     ARK_LAUNCH((msm_digits_kernel<Fr>), dim3(grid_n), dim3(MSM_THREADS), 0, stream, (const Fr*)d_scalars, (uint32_t)n,
@@ -1491,12 +1478,12 @@ struct MsmBuckets {
 // fill kernels in front of every accumulation launch sat behind the other proofs' workgroups and opened a gap between
 // consecutive accumulations (31 fills per proof, 2.5 ms of stream time with four proofs in flight).
 template <class F>
-static void msm_prepare_phase(const MsmSort& s, MsmBuckets& b, hipStream_t stream) {
+static void msm_prepare_phase(const TunePolicy& pol, const MsmSort& s, MsmBuckets& b, hipStream_t stream) {
   const MsmPlan& p = s.plan;
   b.prepared = true;
   if (p.n == 0) return;
   const uint64_t entries = (uint64_t)p.windows * p.n;
-  b.seg_len = msm_seg_len(entries, is_fp2<F>::value);
+  b.seg_len = msm_seg_len(entries, is_fp2<F>::value, pol.msm_seg);
   b.segs = (uint32_t)((entries + b.seg_len - 1) / b.seg_len);
   const uint32_t segs = b.segs;
   b.buckets.ensure((size_t)p.total_buckets * sizeof(XYZZ<F>));
@@ -1514,7 +1501,7 @@ static void msm_accumulate_phase(ark355_ctx* ctx, const MsmSort& s, MsmBuckets& 
                                  hipStream_t stream, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr,
                                  bool bases28 = false) {
   const MsmPlan& p = s.plan;
-  if (!b.prepared) msm_prepare_phase<F>(s, b, stream);      // stand-alone MSMs: same stream
+  if (!b.prepared) msm_prepare_phase<F>(ctx->policy, s, b, stream);      // stand-alone MSMs: same stream
   b.prepared = false;
   if (p.n == 0) return;
   const uint32_t segs = b.segs;
@@ -1522,11 +1509,8 @@ static void msm_accumulate_phase(ark355_ctx* ctx, const MsmSort& s, MsmBuckets& 
   if (ev0) ARK_CHECK_HIP(hipEventRecord(ev0, stream));
   // G2 (Fq2): inlining 30 Fq multiplications costs registers (256 VGPR + 256 AGPR, 1 wave/SIMD), the
   // out-of-line flavour keeps acc in scratch across calls; measured on MI355X with the asm multiplier the
-  // inlined one wins (1.04 vs 0.85 Gadd/s).  ARK355_G2_INLINE=0|1 overrides.  G1 always inlines.
-  static const int g2_inline = [] {
-    const char* e = getenv("ARK355_G2_INLINE");
-    return e ? (e[0] == '1') : ARK_G2_INLINE_DEFAULT;
-  }();
+  // inlined one wins (1.04 vs 0.85 Gadd/s).  Policy G2_INLINE=0|1 overrides.  G1 always inlines.
+  const int g2_inline = ctx->policy.g2_inline;
   auto launch = [&](auto ni_tag) {
     constexpr bool NI = decltype(ni_tag)::value;
     ARK_LAUNCH((msm_accumulate_kernel<F, NI>), dim3(grid_s), dim3(MSM_THREADS), 0, stream, d_bases,
@@ -1535,12 +1519,9 @@ static void msm_accumulate_phase(ark355_ctx* ctx, const MsmSort& s, MsmBuckets& 
                b.head_key.as<uint32_t>(), b.tail.as<XYZZ<F>>(), b.tail_key.as<uint32_t>(), b.seg_len);
   };
   if constexpr (is_fp2<F>::value) {
-    // G2: lane-split kernel (two lanes per segment).  ARK355_G2_WHOLE=1 selects the whole-element kernel
-    // (inlined or, with ARK355_G2_INLINE=0, out-of-line) for A/B comparison.
-    static const int g2_whole = [] {
-      const char* e = getenv("ARK355_G2_WHOLE");
-      return e && e[0] == '1';
-    }();
+    // G2: lane-split kernel (two lanes per segment).  Policy G2_WHOLE=1 selects the whole-element kernel
+    // (inlined or, with G2_INLINE=0, out-of-line) for A/B comparison.
+    const int g2_whole = ctx->policy.g2_whole;
     if (bases28) {
       using P = typename F::Base::Params;
       const uint32_t grid_l = (2 * segs + MSM_THREADS - 1) / MSM_THREADS;
@@ -1575,11 +1556,8 @@ static void msm_accumulate_phase(ark355_ctx* ctx, const MsmSort& s, MsmBuckets& 
   if (ev1) ARK_CHECK_HIP(hipEventRecord(ev1, stream));
 }
 
-// ARK355_G2_PAIR_TAILS=0: keep the one-lane-per-bucket tail kernels for G2 (A/B; default: the lane-pair kernels)
-static inline bool msm_g2_pair_tails() {
-  const char* e = getenv("ARK355_G2_PAIR_TAILS");
-  return !(e && e[0] == '0');
-}
+// policy G2_PAIR_TAILS=0: keep the one-lane-per-bucket tail kernels for G2 (A/B; default: the lane-pair kernels)
+static inline bool msm_g2_pair_tails(const ark355_ctx* ctx) { return ctx->policy.g2_pair_tails != 0; }
 
 // Phase 2: straddling-run merge, weighted bucket reduction, window combination; writes/accumulates the XYZZ
 // result into d_out.  Only a handful of workgroups and latency-bound, so the prover runs it on its own stream
@@ -1612,7 +1590,7 @@ static void msm_reduce_phase(ark355_ctx* ctx, const MsmSort& s, MsmBuckets& b, X
     b.heavy_list.ensure((size_t)max_heavy * 4);
     ARK_CHECK_HIP(hipMemsetAsync(b.heavy_count.p, 0, 4, stream));
     if constexpr (is_fp2<F>::value) {
-      if (msm_g2_pair_tails()) {
+      if (msm_g2_pair_tails(ctx)) {
         using P = typename F::Base::Params;
         ARK_LAUNCH((msm_merge_pair_kernel<P>), dim3(2 * grid_b), dim3(MSM_THREADS), 0, stream, p.total_buckets,
                    s.offsets.as<uint32_t>(), s.counts.as<uint32_t>(), b.buckets.as<XYZZ<F>>(), b.head.as<XYZZ<F>>(),
@@ -1634,7 +1612,7 @@ static void msm_reduce_phase(ark355_ctx* ctx, const MsmSort& s, MsmBuckets& b, X
     const uint32_t grid_h = max_heavy < ARK_MSM_HEAVY_GRID ? max_heavy : ARK_MSM_HEAVY_GRID;
     bool heavy_done = false;
     if constexpr (is_fp2<F>::value) {
-      if (msm_g2_pair_tails()) {
+      if (msm_g2_pair_tails(ctx)) {
         using P = typename F::Base::Params;
         ARK_LAUNCH((msm_merge_heavy_pair_kernel<P>), dim3(grid_h), dim3(MSM_THREADS), 0, stream, b.heavy_count.as<uint32_t>(),
                    b.heavy_list.as<uint32_t>(), s.offsets.as<uint32_t>(), s.counts.as<uint32_t>(), b.buckets.as<XYZZ<F>>(),
@@ -1653,8 +1631,8 @@ static void msm_reduce_phase(ark355_ctx* ctx, const MsmSort& s, MsmBuckets& b, X
 #ifndef ARK_MSM_TWO_LEVEL_MIN
 #define ARK_MSM_TWO_LEVEL_MIN (1u << 17)        // bucket count from which the two-level reduction is used (tests: small)
 #endif
-  uint32_t two_level_min = ARK_MSM_TWO_LEVEL_MIN;
-  if (const char* e = getenv("ARK355_MSM_TWO_LEVEL_MIN")) two_level_min = (uint32_t)strtoul(e, nullptr, 10);   // A/B knob
+  const uint32_t two_level_min = ctx->policy.msm_two_level_min >= 0 ? (uint32_t)ctx->policy.msm_two_level_min
+                                                                     : (uint32_t)ARK_MSM_TWO_LEVEL_MIN;       // A/B knob
   if (p.key_windows == 1 && p.total_buckets >= two_level_min) {
     const uint32_t items = (p.total_buckets + MSM_RED_L1 - 1) / MSM_RED_L1;
     b.lvl_t.ensure((size_t)items * sizeof(XYZZ<F>));
@@ -1675,7 +1653,7 @@ static void msm_reduce_phase(ark355_ctx* ctx, const MsmSort& s, MsmBuckets& b, X
   }
   const uint32_t chunks = (p.buckets_per_window + MSM_RED_K - 1) / MSM_RED_K;
   if constexpr (is_fp2<F>::value) {
-    if (msm_g2_pair_tails()) {
+    if (msm_g2_pair_tails(ctx)) {
       using P = typename F::Base::Params;
       const uint32_t blocks_pw = (chunks + MSM_THREADS / 2 - 1) / (MSM_THREADS / 2);       // a lane pair per chunk
       b.partials.ensure((size_t)blocks_pw * p.key_windows * sizeof(XYZZ<F>));

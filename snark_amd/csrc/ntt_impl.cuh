@@ -492,10 +492,9 @@ static const Fr* ntt_seam_table(NttTables* t) {
 
 // w^(s p k) for p < N/(s R), k < R at index (p << r) | k; nullptr when the table would exceed 2^NTT_DIRECT_MAX_LOG entries
 template <class Fr>
-static const Fr* ntt_direct_table(NttTables* t, uint32_t s_log, uint32_t r, bool inverse) {
+static const Fr* ntt_direct_table(const TunePolicy& pol, NttTables* t, uint32_t s_log, uint32_t r, bool inverse) {
   const uint32_t ent_log = t->log_n - s_log;
-  uint32_t max_log = NTT_DIRECT_MAX_LOG;
-  if (const char* e = getenv("ARK355_NTT_DIRECT_MAX")) max_log = (uint32_t)atoi(e);      // tests: force the fallback
+  const uint32_t max_log = pol.ntt_direct_max >= 0 ? (uint32_t)pol.ntt_direct_max : NTT_DIRECT_MAX_LOG;   // tests: force the fallback
   if (ent_log > max_log || ent_log == r) return nullptr;                  // too large / last pass (p == 0 only)
   std::lock_guard<std::mutex> lk(t->mu);
   const uint32_t key = ((inverse ? 1u : 0u) << 16) | (s_log << 8) | r;
@@ -534,12 +533,9 @@ static inline uint32_t ntt_pass_muls(uint32_t r, bool last) {
 // Radices of the passes: as few passes as the largest radix allows; among those, the first and the last pass share a
 // radix whenever possible (the seam kernel needs that) and the split with the fewest multiplications wins -- 2^21 points
 // run as 2^6 x 2^9 x 2^6 (79 multiplications per eight elements and transform) rather than 2^7 x 2^7 x 2^7 (88).
-static inline std::vector<uint32_t> ntt_radices(uint32_t log_n) {
+static inline std::vector<uint32_t> ntt_radices(const TunePolicy& pol, uint32_t log_n) {
   uint32_t rmax = NTT_RMAX_LOG;
-  if (const char* e = getenv("ARK355_NTT_RMAX")) {          // tests: force many passes on small vectors
-    const int v = atoi(e);
-    if (v >= 1 && v <= (int)NTT_RMAX_LOG) rmax = (uint32_t)v;
-  }
+  if (pol.ntt_rmax >= 1 && pol.ntt_rmax <= (int)NTT_RMAX_LOG) rmax = (uint32_t)pol.ntt_rmax;   // tests: many passes on small vectors
   const uint32_t npass = (log_n + rmax - 1) / rmax;
   if (npass <= 1) return {log_n};
   std::vector<uint32_t> best;
@@ -697,7 +693,7 @@ static void* ntt_run(ark355_ctx* ctx, void* data, void* scratch, uint32_t log_n,
     ARK_LAUNCH((ntt_scale_kernel<Fr>), sgrid, dim3(256), 0, stream, (Fr*)data, n, in_lo, in_hi, t->lo_bits, (const Fr*)nullptr);
     ARK_CHECK_LAUNCH();
   }
-  const std::vector<uint32_t> radices = ntt_radices(log_n);
+  const std::vector<uint32_t> radices = ntt_radices(ctx->policy, log_n);
   uint32_t s_log = 0;
   Fr* src = (Fr*)data;
   Fr* dst = (Fr*)scratch;
@@ -710,7 +706,7 @@ static void* ntt_run(ark355_ctx* ctx, void* data, void* scratch, uint32_t log_n,
     a.s_log = s_log;
     a.p_log = ntt_p_log(log_n, r);
     a.tw = ntt_tw_table<Fr>(t, r, inverse);
-    a.direct = ntt_direct_table<Fr>(t, s_log, r, inverse);
+    a.direct = ntt_direct_table<Fr>(ctx->policy, t, s_log, r, inverse);
     a.w_lo = w_lo;
     a.w_hi = w_hi;
     a.lo_bits = t->lo_bits;
@@ -731,10 +727,10 @@ static void* ntt_run(ark355_ctx* ctx, void* data, void* scratch, uint32_t log_n,
 template <class Curve>
 static void* ntt_inverse_then_coset(ark355_ctx* ctx, void* data, void* scratch, uint32_t log_n, hipStream_t stream) {
   using Fr = typename Curve::Fr;
-  const std::vector<uint32_t> radices = log_n >= 3 ? ntt_radices(log_n) : std::vector<uint32_t>();
+  const std::vector<uint32_t> radices = log_n >= 3 ? ntt_radices(ctx->policy, log_n) : std::vector<uint32_t>();
   // the seam kernel exists for first/last radices 2^5 .. 2^9 (every domain of 2^10 points or more with matching ends);
-  // tests lower the bound through ARK355_NTT_RMAX and then use radices < 6: those take the unfused path
-  const bool fuse = log_n >= 3 && radices.front() == radices.back() && radices.front() >= 5 && !getenv("ARK355_NTT_NOFUSE");
+  // tests lower the bound through policy NTT_RMAX and then use radices < 6: those take the unfused path
+  const bool fuse = log_n >= 3 && radices.front() == radices.back() && radices.front() >= 5 && !ctx->policy.ntt_nofuse;
   if (!fuse) {
     void* cur = data;
     void* oth = scratch;
@@ -753,7 +749,7 @@ static void* ntt_inverse_then_coset(ark355_ctx* ctx, void* data, void* scratch, 
     a.s_log = s_log;
     a.p_log = ntt_p_log(log_n, r);
     a.tw = ntt_tw_table<Fr>(t, r, inverse);
-    a.direct = ntt_direct_table<Fr>(t, s_log, r, inverse);
+    a.direct = ntt_direct_table<Fr>(ctx->policy, t, s_log, r, inverse);
     a.w_lo = (inverse ? t->wi_lo : t->w_lo).template as<Fr>();
     a.w_hi = (inverse ? t->wi_hi : t->w_hi).template as<Fr>();
     a.lo_bits = t->lo_bits;

@@ -1,0 +1,169 @@
+// TunePolicy: every runtime switch of the library in ONE struct per context.
+//
+// The environment (ARK355_<NAME>) is read exactly once, when a context is created (ark355_ctx_create); afterwards a
+// context's policy changes only through ark355_ctx_set_policy(ctx, "<NAME>", value).  Nothing on the proving path calls
+// getenv, and two contexts of one process can run different policies (bench.py's in-run A/B does).  Child contexts of
+// ark355_prove_batch inherit the parent's policy at every call.
+//
+// Three groups:
+//   per proof      SCHED, WAIT_SPIN, WAIT_ADAPT, STREAM_PRIO, DEVICE_FINALIZE, TRACE_HOST (+ the legacy spellings SERIAL
+//                  and EPILOGUE_SYNC, which map onto SCHED)
+//   per key load   MSM_C, LIMB28, G2_LIMB28, G1_BATCH_AFFINE, G2_BATCH_AFFINE, BA_LEVELS, TABLE_STRIDE, HBM_BUDGET_MB
+//                  (read when a key / base set is loaded through the context: the tables are built for them)
+//   per call       MSM_SEG, SORT_LEGACY, G2_INLINE, G2_WHOLE, G2_PAIR_TAILS, MSM_TWO_LEVEL_MIN, NTT_RMAX, NTT_DIRECT_MAX,
+//                  NTT_NOFUSE (A/B and test knobs of the kernels' host drivers)
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+namespace ark355 {
+
+// How one proof is laid onto HIP streams and how its thread waits for it (groth16_impl.cuh, prove_run).
+enum Sched : int32_t {
+  SCHED_AUTO = -1,          // measured choice: the first proofs of a (device, shape, alone / in flight) class try the
+                            // candidates below, the class then keeps the fastest (SchedTuner)
+  SCHED_ONE_STREAM = 0,     // every kernel of the proof on the context's stream; the thread polls the last event
+  SCHED_PIPELINE = 1,       // five-stream pipeline; epilogue checks the (complete by construction) last events
+  SCHED_PIPELINE_SYNC = 2,  // five-stream pipeline; epilogue synchronises the three feeder streams (round-2 behaviour)
+  SCHED_ONE_STREAM_SPIN = 3,// one stream; the thread waits inside the HIP runtime (which spins: one host core per proof)
+  SCHED_COUNT = 4
+};
+
+struct TunePolicy {
+  // ---- per proof
+  int32_t sched = SCHED_AUTO;
+  int32_t wait_spin = 0;          // 1: every wait of a proof inside the HIP runtime (hipEventSynchronize)
+  int32_t wait_adapt = 0;         // 1: sleep through half of the shortest recent drain before polling
+  int32_t stream_prio = 1;        // feeder streams (witness map, sort, reduction) at the higher stream priority
+  int32_t device_finalize = 0;    // O(1) proof tail on the device instead of the host
+  int32_t trace_host = 0;         // host wall-clock phases on stderr
+  int32_t sched_explore = 3;      // samples per candidate before SCHED_AUTO latches (0: static default, no exploration)
+  // ---- per key load
+  int32_t msm_c = 0;              // window size of resident tables (0: planner)
+  int32_t msm_c_h = 0;            // window size of the h_query table alone (0: same rule as the others)
+  int32_t limb28 = 1, g2_limb28 = 1;
+  int32_t g1_batch_affine = 0, g2_batch_affine = 0;
+  int32_t ba_levels = 5;
+  int32_t table_stride = 0;       // 0: planner
+  int64_t hbm_budget_mb = 0;      // 0: 80 % of the device
+  // ---- per call
+  int32_t msm_seg = 0;            // entries per accumulation lane (0: msm_seg_len)
+  int32_t sort_legacy = 0;
+  int32_t g2_inline = 1, g2_whole = 0, g2_pair_tails = 1;
+  int64_t msm_two_level_min = -1; // bucket count from which the two-level reduction runs (-1: ARK_MSM_TWO_LEVEL_MIN)
+  int32_t ntt_rmax = 0;           // 0: NTT_RMAX_LOG
+  int32_t ntt_direct_max = -1;    // -1: NTT_DIRECT_MAX_LOG
+  int32_t ntt_nofuse = 0;
+
+  struct Field {
+    const char* name;
+    int kind;                     // 0: int32, 1: int64
+    size_t off;
+  };
+  static const Field* fields(int* count);
+
+  // 0 on success, -1 for an unknown name
+  int set(const char* name, int64_t v);
+  int get(const char* name, int64_t* v) const;
+  static TunePolicy from_env();
+};
+
+#define ARK_POLICY_FIELD32(n, f) {n, 0, offsetof(TunePolicy, f)}
+#define ARK_POLICY_FIELD64(n, f) {n, 1, offsetof(TunePolicy, f)}
+
+inline const TunePolicy::Field* TunePolicy::fields(int* count) {
+  static const Field tab[] = {
+      ARK_POLICY_FIELD32("SCHED", sched),
+      ARK_POLICY_FIELD32("WAIT_SPIN", wait_spin),
+      ARK_POLICY_FIELD32("WAIT_ADAPT", wait_adapt),
+      ARK_POLICY_FIELD32("STREAM_PRIO", stream_prio),
+      ARK_POLICY_FIELD32("DEVICE_FINALIZE", device_finalize),
+      ARK_POLICY_FIELD32("TRACE_HOST", trace_host),
+      ARK_POLICY_FIELD32("SCHED_EXPLORE", sched_explore),
+      ARK_POLICY_FIELD32("MSM_C", msm_c),
+      ARK_POLICY_FIELD32("MSM_C_H", msm_c_h),
+      ARK_POLICY_FIELD32("LIMB28", limb28),
+      ARK_POLICY_FIELD32("G2_LIMB28", g2_limb28),
+      ARK_POLICY_FIELD32("G1_BATCH_AFFINE", g1_batch_affine),
+      ARK_POLICY_FIELD32("G2_BATCH_AFFINE", g2_batch_affine),
+      ARK_POLICY_FIELD32("BA_LEVELS", ba_levels),
+      ARK_POLICY_FIELD32("TABLE_STRIDE", table_stride),
+      ARK_POLICY_FIELD64("HBM_BUDGET_MB", hbm_budget_mb),
+      ARK_POLICY_FIELD32("MSM_SEG", msm_seg),
+      ARK_POLICY_FIELD32("SORT_LEGACY", sort_legacy),
+      ARK_POLICY_FIELD32("G2_INLINE", g2_inline),
+      ARK_POLICY_FIELD32("G2_WHOLE", g2_whole),
+      ARK_POLICY_FIELD32("G2_PAIR_TAILS", g2_pair_tails),
+      ARK_POLICY_FIELD64("MSM_TWO_LEVEL_MIN", msm_two_level_min),
+      ARK_POLICY_FIELD32("NTT_RMAX", ntt_rmax),
+      ARK_POLICY_FIELD32("NTT_DIRECT_MAX", ntt_direct_max),
+      ARK_POLICY_FIELD32("NTT_NOFUSE", ntt_nofuse),
+  };
+  *count = (int)(sizeof(tab) / sizeof(tab[0]));
+  return tab;
+}
+
+inline int TunePolicy::set(const char* name, int64_t v) {
+  if (!name) return -1;
+  // legacy spellings of the schedule
+  if (strcmp(name, "SERIAL") == 0) {
+    sched = v < 0 ? SCHED_AUTO : (v ? SCHED_ONE_STREAM : SCHED_PIPELINE);
+    return 0;
+  }
+  if (strcmp(name, "EPILOGUE_SYNC") == 0) {
+    if (sched == SCHED_PIPELINE || sched == SCHED_PIPELINE_SYNC) sched = v ? SCHED_PIPELINE_SYNC : SCHED_PIPELINE;
+    return 0;
+  }
+  int n = 0;
+  const Field* f = fields(&n);
+  for (int i = 0; i < n; i++) {
+    if (strcmp(name, f[i].name) != 0) continue;
+    char* base = reinterpret_cast<char*>(this) + f[i].off;
+    if (f[i].kind == 0) *reinterpret_cast<int32_t*>(base) = (int32_t)v;
+    else *reinterpret_cast<int64_t*>(base) = v;
+    return 0;
+  }
+  return -1;
+}
+
+inline int TunePolicy::get(const char* name, int64_t* v) const {
+  if (!name || !v) return -1;
+  int n = 0;
+  const Field* f = fields(&n);
+  for (int i = 0; i < n; i++) {
+    if (strcmp(name, f[i].name) != 0) continue;
+    const char* base = reinterpret_cast<const char*>(this) + f[i].off;
+    *v = f[i].kind == 0 ? (int64_t)*reinterpret_cast<const int32_t*>(base) : *reinterpret_cast<const int64_t*>(base);
+    return 0;
+  }
+  return -1;
+}
+
+inline TunePolicy TunePolicy::from_env() {
+  TunePolicy p;
+  int n = 0;
+  const Field* f = fields(&n);
+  char var[64];
+  for (int i = 0; i < n; i++) {
+    snprintf(var, sizeof(var), "ARK355_%s", f[i].name);
+    if (const char* e = getenv(var)) {
+      if (e[0]) p.set(f[i].name, strtoll(e, nullptr, 10));
+    }
+  }
+  // legacy spellings (rounds 1-3): ARK355_SERIAL=1|0, ARK355_EPILOGUE_SYNC=0|1, ARK355_SORT=legacy
+  if (const char* e = getenv("ARK355_SERIAL")) {
+    if (e[0]) p.set("SERIAL", e[0] == '1' ? 1 : 0);
+  }
+  if (const char* e = getenv("ARK355_EPILOGUE_SYNC")) {
+    if (e[0]) p.set("EPILOGUE_SYNC", e[0] == '1' ? 1 : 0);
+  }
+  if (const char* e = getenv("ARK355_SORT")) {
+    if (e[0] == 'l') p.sort_legacy = 1;
+  }
+  return p;
+}
+
+}  // namespace ark355

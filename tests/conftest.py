@@ -53,3 +53,38 @@ def gpu_ctx(gpu_lib):
     ctx = gpu_lib.ctx_create(0)
     yield ctx
     gpu_lib.ctx_destroy(ctx)
+
+
+class _PolicyShim:
+    """monkeypatch.setenv-shaped access to a context's runtime policy (ark355_ctx_set_policy): the library reads the
+    environment only when a context is created, and the test contexts are session-scoped."""
+
+    def __init__(self, lib, ctx):
+        self.lib, self.ctx, self.saved = lib, ctx, []
+
+    def setenv(self, name, value):
+        assert name.startswith("ARK355_")
+        name = name[len("ARK355_"):]
+        if name in ("SERIAL", "EPILOGUE_SYNC"):
+            self.saved.append(("SCHED", self.lib.ctx_get_policy(self.ctx, "SCHED")))
+        else:
+            self.saved.append((name, self.lib.ctx_get_policy(self.ctx, name)))
+        self.lib.ctx_set_policy(self.ctx, name, int(value))
+
+    def restore(self):
+        for name, old in reversed(self.saved):
+            self.lib.ctx_set_policy(self.ctx, name, old)
+
+
+@pytest.fixture
+def emul_policy(emul_lib, emul_ctx):
+    shim = _PolicyShim(emul_lib, emul_ctx)
+    yield shim
+    shim.restore()
+
+
+@pytest.fixture
+def gpu_policy(gpu_lib, gpu_ctx):
+    shim = _PolicyShim(gpu_lib, gpu_ctx)
+    yield shim
+    shim.restore()

@@ -27,12 +27,12 @@ def test_resident_msm_vs_o3_on_the_emulator(emul_lib, emul_ctx, group):
     O.check_resident_msm(emul_lib, emul_ctx, BLS12_381, group, 200, to_dev)
 
 
-def test_large_window_two_level_reduction_and_odd_segments(emul_lib, emul_ctx, monkeypatch):
+def test_large_window_two_level_reduction_and_odd_segments(emul_lib, emul_ctx, emul_policy):
     """Window size 13 over window tables (4096 buckets: the two-level bucket reduction, level 1 with 16 buckets per
     lane) and a segment length that is not a power of two, against oracle/c -- the configuration the GPU reaches with
     ARK355_MSM_C=20 at 2^20 terms."""
-    monkeypatch.setenv("ARK355_MSM_C", "13")
-    monkeypatch.setenv("ARK355_MSM_SEG", "37")
+    emul_policy.setenv("ARK355_MSM_C", "13")
+    emul_policy.setenv("ARK355_MSM_SEG", "37")
 
     def to_dev(b):
         a = np.frombuffer(b, dtype=np.uint8).copy()
@@ -43,14 +43,14 @@ def test_large_window_two_level_reduction_and_odd_segments(emul_lib, emul_ctx, m
 
 
 @pytest.mark.parametrize("c", ["5", "15"])
-def test_window_sizes_that_negate_high_scalars(emul_lib, emul_ctx, monkeypatch, c):
+def test_window_sizes_that_negate_high_scalars(emul_lib, emul_ctx, emul_policy, c):
     """MsmPlan::negate_high: when the window size divides the scalar width (5, 15, 17 for BLS12-381's 255 bits), scalars
     above (r - 1) / 2 are replaced by r - k with flipped digit signs and a whole window disappears (c = 17: 15 instead
     of 16).  Scalars around the threshold against the known discrete log; the three distributions against oracle/c;
     a whole proof."""
     import parity_cases as pc
     from oracle import synthetic as S
-    monkeypatch.setenv("ARK355_MSM_C", c)
+    emul_policy.setenv("ARK355_MSM_C", c)
 
     def to_dev(b):
         a = np.frombuffer(b, dtype=np.uint8).copy()
@@ -76,12 +76,12 @@ def test_large_size_checks_on_the_emulator(emul_lib, emul_ctx):
 
 
 @pytest.mark.parametrize("stride", ["2", "3", "16"])
-def test_strided_window_tables_on_the_emulator(emul_lib, emul_ctx, monkeypatch, stride):
+def test_strided_window_tables_on_the_emulator(emul_lib, emul_ctx, emul_policy, stride):
     """MsmPlan::wstride (the fallback for keys whose full window tables do not fit HBM): tables for every s-th window,
     s bucket sets combined as sum_j 2^(c j) S_j.  s = 2, 3 (does not divide the window count) and 16 >= windows (no
     table beyond the bases themselves); resident MSMs against oracle/c for both groups and whole proofs -- incl.
     ark355_prove_sharded with the bucket-level ring -- against cbase.prove."""
-    monkeypatch.setenv("ARK355_TABLE_STRIDE", stride)
+    emul_policy.setenv("ARK355_TABLE_STRIDE", stride)
 
     def to_dev(b):
         a = np.frombuffer(b, dtype=np.uint8).copy()
@@ -94,7 +94,7 @@ def test_strided_window_tables_on_the_emulator(emul_lib, emul_ctx, monkeypatch, 
                          equation=False)
 
 
-def test_table_budget_picks_a_stride_or_reports_enomem(emul_lib, emul_ctx, monkeypatch):
+def test_table_budget_picks_a_stride_or_reports_enomem(emul_lib, emul_ctx, emul_policy):
     """The planner behind ark355_pk_load: with a budget below the full tables the key still loads with the smallest
     stride that fits (ark355_pk_table_info shows it) and proves the same bytes; with a budget below the bare vectors the
     load fails with ARK355_ENOMEM and a message, not a HIP error."""
@@ -108,7 +108,7 @@ def test_table_budget_picks_a_stride_or_reports_enomem(emul_lib, emul_ctx, monke
     full = emul_lib.pk_table_info(pkh)
     O.free(emul_lib, pkh, rh)
     assert full["table_stride"] == 1 and full["windows"] * full["window_bits"] >= 256
-    monkeypatch.setenv("ARK355_HBM_BUDGET_MB", str(max(1, (full["table_bytes"] // 3) >> 20)))
+    emul_policy.setenv("ARK355_HBM_BUDGET_MB", str(max(1, (full["table_bytes"] // 3) >> 20)))
     pkh, rh = O.load(emul_lib, emul_ctx, C, inst, pk)
     try:
         info = emul_lib.pk_table_info(pkh)
@@ -118,7 +118,7 @@ def test_table_budget_picks_a_stride_or_reports_enomem(emul_lib, emul_ctx, monke
         assert got == cbase.prove(C, n, ell, w, mats, zb, pk, 3, 4)
     finally:
         O.free(emul_lib, pkh, rh)
-    monkeypatch.setenv("ARK355_HBM_BUDGET_MB", "1")
+    emul_policy.setenv("ARK355_HBM_BUDGET_MB", "1")
     big = S.mulchain_csr(C.r, 5000)
     n2, ell2, w2, mats2, z2 = big
     pk2, _ = cbase.setup_raw_c(C, n2, ell2, w2, mats2, O.TD)

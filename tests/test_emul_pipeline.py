@@ -40,12 +40,12 @@ def test_resident_tables_exceptional_additions(emul_lib, emul_ctx, C, group):
 
 
 @pytest.mark.parametrize("env", [{"ARK355_G2_LIMB28": "0"}, {"ARK355_LIMB28": "0"}], ids=["g2-32bit", "g1-32bit"])
-def test_resident_tables_alternate_limb_forms(emul_lib, emul_ctx, monkeypatch, env):
+def test_resident_tables_alternate_limb_forms(emul_lib, emul_ctx, emul_policy, env):
     """The 32-bit lane-split G2 kernel and the 32-bit G1 kernel over window tables (the A/B switches; the defaults
     are the radix-2^28 kernels)."""
     import numpy as np
     for k, v in env.items():
-        monkeypatch.setenv(k, v)
+        emul_policy.setenv(k, v)
 
     def to_dev(b):
         a = np.frombuffer(b, dtype=np.uint8).copy()
@@ -76,19 +76,54 @@ def test_prove_bytes_equal_oracle(emul_lib, emul_ctx, C):
     pc.prove_case(emul_lib, emul_ctx, C, A, B, Cm, z, ell, rs=((0x1234567890abcdef, 0xfedcba0987654321aabbccdd), (0, 5)))
 
 
-@pytest.mark.parametrize("serial", ["1", "0"])
-def test_prove_schedules_give_the_same_bytes(emul_lib, emul_ctx, monkeypatch, serial):
-    """prove_run picks its schedule per proof: one stream when other proofs are in flight on the device, the five-stream
-    pipeline when the proof is alone (ARK355_SERIAL=1 / 0 force either).  Same bytes as the oracle both ways."""
-    monkeypatch.setenv("ARK355_SERIAL", serial)
+@pytest.mark.parametrize("sched", ["SERIAL=1", "SERIAL=0", "SCHED=2", "SCHED=3"])
+def test_prove_schedules_give_the_same_bytes(emul_lib, emul_ctx, emul_policy, sched):
+    """prove_run's schedules (policy SCHED; SERIAL=1 / 0 are the legacy spellings of 0 / 1): one stream, the five-stream
+    pipeline with either epilogue, one stream with the runtime's own wait.  Same bytes as the oracle every way."""
+    name, value = sched.split("=")
+    emul_policy.setenv("ARK355_" + name, value)
     C = BLS12_381
     A, B, Cm, z, ell = S.mulchain_direct(C.r, 21)
     pc.prove_case(emul_lib, emul_ctx, C, A, B, Cm, z, ell, rs=((7, 9),))
+    assert emul_lib.ctx_get_policy(emul_ctx, "SCHED") == {"SERIAL=1": 0, "SERIAL=0": 1, "SCHED=2": 2, "SCHED=3": 3}[sched]
 
 
-def test_prove_device_finalize_kernel_gives_same_bytes(emul_lib, emul_ctx, monkeypatch):
+def test_measured_schedule_choice_explores_then_latches(emul_lib):
+    """Policy SCHED = -1 (default): the first warm proofs of a class run the candidate schedules in turn (SCHED_EXPLORE samples
+    each), every one of them gives the oracle's bytes, and the class then keeps one schedule (ark355_sched_info)."""
+    from oracle import groth16 as G, serialize as Z
+    C = BLS12_381
+    A, B, Cm, z, ell = S.mulchain_direct(C.r, 9)
+    m = len(z)
+    ctx = emul_lib.ctx_create(0)
+    try:
+        emul_lib.sched_reset(ctx)
+        assert emul_lib.ctx_get_policy(ctx, "SCHED") == -1
+        emul_lib.ctx_set_policy(ctx, "SCHED_EXPLORE", 2)
+        sz = emul_lib.sizes(C.curve_id)
+        pk = G.setup(C, A, B, Cm, ell, m, G.Trapdoor(tau=987654321, alpha=5, beta=7, gamma=11, delta=13))
+        rh = pc.r1cs_load_from_rows(emul_lib, ctx, C, A, B, Cm, ell, m - ell)
+        pkh = pc.pk_load_from_oracle(emul_lib, ctx, C, pk, ell, m - ell, 1 << pk.domain_log)
+        zb = pc.z_bytes(C, z)
+        exp = G.prove_closed_form(C, pk, z, ell, 5, 6)
+        seen = []
+        for i in range(1 + 3 * 2 + 2):                    # one cold proof, 3 candidates x 2 samples, 2 latched
+            a, b, c = emul_lib.prove(ctx, pkh, rh, zb, m, Z.fr_canon(C, 5), Z.fr_canon(C, 6), sz)
+            assert G.Proof(Z.g1_from_raw(C, a), Z.g2_from_raw(C, b), Z.g1_from_raw(C, c)) == exp
+            info = emul_lib.sched_info(ctx, pkh, False)
+            seen.append(info["last"])
+        assert info["latched"] in ("pipeline", "pipeline_sync", "one_stream")
+        assert set(seen[1:7]) == {"pipeline", "pipeline_sync", "one_stream"} and seen[-1] == seen[-2] == info["latched"]
+        assert all(n == 2 for n in info["samples"].values()) and len(info["samples"]) == 3
+        emul_lib.dll.ark355_pk_free(pkh)
+        emul_lib.dll.ark355_r1cs_free(rh)
+    finally:
+        emul_lib.ctx_destroy(ctx)
+
+
+def test_prove_device_finalize_kernel_gives_same_bytes(emul_lib, emul_ctx, emul_policy):
     """ARK355_DEVICE_FINALIZE=1 keeps s*A + r*B1 and the normalisations in groth16_finalize_kernel."""
-    monkeypatch.setenv("ARK355_DEVICE_FINALIZE", "1")
+    emul_policy.setenv("ARK355_DEVICE_FINALIZE", "1")
     C = BN254
     A, B, Cm, z, ell = S.mulchain_direct(C.r, 5)
     pc.prove_case(emul_lib, emul_ctx, C, A, B, Cm, z, ell)
@@ -176,11 +211,11 @@ def test_reference_example_circuit_on_the_emulator(emul_lib, emul_ctx):
 
 
 @pytest.mark.parametrize("rmax", ["9", "3", "2"])
-def test_ntt_every_radix_and_pass_count(emul_lib, emul_ctx, rmax, monkeypatch):
+def test_ntt_every_radix_and_pass_count(emul_lib, emul_ctx, rmax, emul_policy):
     """Register-resident radix-8 groups, LDS re-deals, direct inter-pass tables, the fused inverse->coset seam and the
     pointwise fusion, for every pass radix 2^1..2^9 and for 1..5 passes (ARK355_NTT_RMAX shrinks the largest radix so
     that small vectors take many passes), all four transform modes against the oracle; then the witness map."""
-    monkeypatch.setenv("ARK355_NTT_RMAX", rmax)
+    emul_policy.setenv("ARK355_NTT_RMAX", rmax)
     C = BLS12_381
     for log_n in (range(1, 11) if rmax != "9" else (2, 3, 5, 6, 7, 8, 10, 12)):
         pc.ntt_case(emul_lib, emul_ctx, C, log_n, seed=int(rmax))
@@ -220,13 +255,13 @@ def test_batch_verification_vs_oracle_pairing(emul_lib, emul_ctx, C):
 
 @pytest.mark.parametrize("group", [2, 1])
 @pytest.mark.parametrize("levels", ["5", "1", "9"])
-def test_batch_affine_accumulation_edge_cases(emul_lib, emul_ctx, monkeypatch, group, levels):
+def test_batch_affine_accumulation_edge_cases(emul_lib, emul_ctx, emul_policy, group, levels):
     """ARK355_G2_BATCH_AFFINE / ARK355_G1_BATCH_AFFINE (msm_ba_impl.cuh): the first tree levels of every bucket as affine
     additions with shared inversions.  P + P, P + (-P), infinity and runs of equal points inside buckets, for 1, 5 and 9
     tree levels (9 leaves a single node per bucket), against the oracle's naive MSM."""
     import numpy as np
-    monkeypatch.setenv("ARK355_G2_BATCH_AFFINE" if group == 2 else "ARK355_G1_BATCH_AFFINE", "1")
-    monkeypatch.setenv("ARK355_BA_LEVELS", levels)
+    emul_policy.setenv("ARK355_G2_BATCH_AFFINE" if group == 2 else "ARK355_G1_BATCH_AFFINE", "1")
+    emul_policy.setenv("ARK355_BA_LEVELS", levels)
 
     def to_dev(b):
         a = np.frombuffer(b, dtype=np.uint8).copy()
@@ -237,13 +272,13 @@ def test_batch_affine_accumulation_edge_cases(emul_lib, emul_ctx, monkeypatch, g
 
 
 @pytest.mark.parametrize("C", [BLS12_381, BN254], ids=lambda c: c.name)
-def test_prove_with_batch_affine_accumulation(emul_lib, emul_ctx, monkeypatch, C):
+def test_prove_with_batch_affine_accumulation(emul_lib, emul_ctx, emul_policy, C):
     """Whole proofs with the G2 MSM (and, second pass, all five MSMs) on the batch-affine path: same bytes as the oracle."""
     A, B, Cm, z, ell = S.mulchain_direct(C.r, 13)
-    monkeypatch.setenv("ARK355_G2_BATCH_AFFINE", "1")
+    emul_policy.setenv("ARK355_G2_BATCH_AFFINE", "1")
     pc.prove_case(emul_lib, emul_ctx, C, A, B, Cm, z, ell, rs=((0x1234567890abcdef, 0xfedcba0987654321aabbccdd),))
     if C is BLS12_381:
-        monkeypatch.setenv("ARK355_G1_BATCH_AFFINE", "1")
+        emul_policy.setenv("ARK355_G1_BATCH_AFFINE", "1")
         pc.prove_case(emul_lib, emul_ctx, C, A, B, Cm, z, ell, rs=((7, 9),))
 
 

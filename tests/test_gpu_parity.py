@@ -65,13 +65,13 @@ def test_resident_tables_exceptional_additions(gpu_lib, gpu_ctx, C, group, n):
 
 
 @pytest.mark.parametrize("env", [{"ARK355_G2_LIMB28": "0"}, {"ARK355_LIMB28": "0"}], ids=["g2-32bit", "g1-32bit"])
-def test_resident_tables_alternate_limb_forms(gpu_lib, gpu_ctx, monkeypatch, env):
+def test_resident_tables_alternate_limb_forms(gpu_lib, gpu_ctx, gpu_policy, env):
     """The 32-bit lane-split G2 kernel and the 32-bit G1 kernel over window tables (the A/B switches; the defaults
     are the radix-2^28 kernels)."""
     import numpy as np
     import torch
     for k, v in env.items():
-        monkeypatch.setenv(k, v)
+        gpu_policy.setenv(k, v)
 
     def to_dev(b):
         t = torch.from_numpy(np.frombuffer(b, dtype=np.uint8).copy()).cuda()
@@ -221,14 +221,14 @@ def test_batch_verification_vs_oracle_pairing(gpu_lib, gpu_ctx, C):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("group", [2, 1])
-def test_batch_affine_accumulation(gpu_lib, gpu_ctx, monkeypatch, group):
+def test_batch_affine_accumulation(gpu_lib, gpu_ctx, gpu_policy, group):
     """ARK355_G2_BATCH_AFFINE / ARK355_G1_BATCH_AFFINE (msm_ba_impl.cuh): tree levels of affine additions with shared
     inversions in front of the XYZZ path.  Exceptional additions inside buckets on both curves (oracle's naive MSM), then
     a 2^16-term MSM with uniform / all-equal / boolean scalars against the independent C oracle."""
     import numpy as np
     import torch
     import o3_cases as O
-    monkeypatch.setenv("ARK355_G2_BATCH_AFFINE" if group == 2 else "ARK355_G1_BATCH_AFFINE", "1")
+    gpu_policy.setenv("ARK355_G2_BATCH_AFFINE" if group == 2 else "ARK355_G1_BATCH_AFFINE", "1")
 
     def to_dev(b):
         t = torch.from_numpy(np.frombuffer(b, dtype=np.uint8).copy()).cuda()
@@ -237,33 +237,33 @@ def test_batch_affine_accumulation(gpu_lib, gpu_ctx, monkeypatch, group):
     for C in CURVES:
         pc.resident_msm_edge_case(gpu_lib, gpu_ctx, C, group, 200, to_dev)
     for levels in ("2", "5"):
-        monkeypatch.setenv("ARK355_BA_LEVELS", levels)
+        gpu_policy.setenv("ARK355_BA_LEVELS", levels)
         O.check_resident_msm(gpu_lib, gpu_ctx, BLS12_381, group, 1 << 16, to_dev, seed=int(levels))
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("C", CURVES, ids=lambda c: c.name)
-def test_prove_with_batch_affine_g2(gpu_lib, gpu_ctx, monkeypatch, C):
-    monkeypatch.setenv("ARK355_G2_BATCH_AFFINE", "1")
+def test_prove_with_batch_affine_g2(gpu_lib, gpu_ctx, gpu_policy, C):
+    gpu_policy.setenv("ARK355_G2_BATCH_AFFINE", "1")
     A, B, Cm, z, ell = S.mulchain_direct(C.r, 300)
     pc.prove_case(gpu_lib, gpu_ctx, C, A, B, Cm, z, ell, rs=((0x1234567890abcdef, 0xfedcba0987654321aabbccdd), (0, 5)))
 
 
 @pytest.mark.gpu
-def test_prove_with_window_17_negating_high_scalars(gpu_lib, gpu_ctx, monkeypatch):
+def test_prove_with_window_17_negating_high_scalars(gpu_lib, gpu_ctx, gpu_policy):
     """ARK355_MSM_C=17 on a key of >= 1024 terms: MsmPlan::negate_high (scalars above (r - 1) / 2 become r - k with
     flipped digit signs), 15 windows, 2^16 buckets -- the proof must still be the oracle's."""
-    monkeypatch.setenv("ARK355_MSM_C", "17")
+    gpu_policy.setenv("ARK355_MSM_C", "17")
     C = BLS12_381
     A, B, Cm, z, ell = S.mulchain_direct(C.r, 1030)
     pc.prove_case(gpu_lib, gpu_ctx, C, A, B, Cm, z, ell, rs=((C.r - 3, 12345),))
 
 
 @pytest.mark.parametrize("serial", ["1", "0"])
-def test_prove_one_stream_schedule(gpu_lib, gpu_ctx, monkeypatch, serial):
+def test_prove_one_stream_schedule(gpu_lib, gpu_ctx, gpu_policy, serial):
     """The schedule prove_run picks with other proofs in flight (one stream) and the one it picks for a proof alone (five
     streams), forced through ARK355_SERIAL: proof bytes == oracle, pairing equation."""
-    monkeypatch.setenv("ARK355_SERIAL", serial)
+    gpu_policy.setenv("ARK355_SERIAL", serial)
     C = BLS12_381
     A, B, Cm, z, ell = S.mulchain_direct(C.r, 300)
     pc.prove_case(gpu_lib, gpu_ctx, C, A, B, Cm, z, ell, verify=True)

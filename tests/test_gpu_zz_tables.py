@@ -20,15 +20,15 @@ def _to_dev(b):
 
 
 @pytest.mark.parametrize("stride", ["2", "3", "16"])
-def test_strided_window_tables(gpu_lib, gpu_ctx, monkeypatch, stride):
-    monkeypatch.setenv("ARK355_TABLE_STRIDE", stride)
+def test_strided_window_tables(gpu_lib, gpu_ctx, gpu_policy, stride):
+    gpu_policy.setenv("ARK355_TABLE_STRIDE", stride)
     O.check_resident_msm(gpu_lib, gpu_ctx, BLS12_381, 1, 5000, _to_dev, seed=21)      # c = 8: 32 windows
     O.check_resident_msm(gpu_lib, gpu_ctx, BN254, 2, 700, _to_dev, seed=22)           # c = 4: 64 windows
     if stride != "16":
         O.check_instance(gpu_lib, gpu_ctx, BLS12_381, S.mulchain_csr(BLS12_381.r, 3000), [(5, 7)])
 
 
-def test_table_budget_picks_a_stride_or_reports_enomem(gpu_lib, gpu_ctx, monkeypatch):
+def test_table_budget_picks_a_stride_or_reports_enomem(gpu_lib, gpu_ctx, gpu_policy):
     from oracle.c import cbase
     from snark_amd._binding import Ark355Error, ENOMEM
     C = BLS12_381
@@ -39,7 +39,7 @@ def test_table_budget_picks_a_stride_or_reports_enomem(gpu_lib, gpu_ctx, monkeyp
     full = gpu_lib.pk_table_info(pkh)
     O.free(gpu_lib, pkh, rh)
     assert full["table_stride"] == 1
-    monkeypatch.setenv("ARK355_HBM_BUDGET_MB", str(max(1, (full["table_bytes"] // 3) >> 20)))
+    gpu_policy.setenv("ARK355_HBM_BUDGET_MB", str(max(1, (full["table_bytes"] // 3) >> 20)))
     pkh, rh = O.load(gpu_lib, gpu_ctx, C, inst, pk)
     try:
         info = gpu_lib.pk_table_info(pkh)
@@ -49,7 +49,7 @@ def test_table_budget_picks_a_stride_or_reports_enomem(gpu_lib, gpu_ctx, monkeyp
         assert got == cbase.prove(C, n, ell, w, mats, zb, pk, 3, 4)
     finally:
         O.free(gpu_lib, pkh, rh)
-    monkeypatch.setenv("ARK355_HBM_BUDGET_MB", "1")
+    gpu_policy.setenv("ARK355_HBM_BUDGET_MB", "1")
     with pytest.raises(Ark355Error) as e:
         O.load(gpu_lib, gpu_ctx, C, inst, pk)
     assert e.value.code == ENOMEM and "do not fit" in str(e.value)

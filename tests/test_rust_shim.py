@@ -90,7 +90,7 @@ def test_constants_and_structs_agree():
     for k, v in consts.items():
         m = re.search(r"pub const %s: \w+ = (-?\d+);" % k, f)
         assert m and int(m.group(1)) == v, k
-    for struct in ("ark355_pk_desc", "ark355_proof_raw", "ark355_timings"):
+    for struct in ("ark355_pk_desc", "ark355_proof_raw", "ark355_timings", "ark355_sched_report"):
         body = re.search(r"typedef struct \{([^{}]*?)\}\s*%s;" % struct, h, flags=re.S).group(1)
         c_fields = [re.sub(r"\[\d+\]", "", x.strip().split()[-1].lstrip("*")) for x in body.split(";") if x.strip()]
         rbody = re.search(r"pub struct %s \{(.*?)\n\}" % struct, f, flags=re.S).group(1)
