@@ -59,6 +59,9 @@ def parse_args():
     ap.add_argument("--no-check", action="store_true", help="skip the closed-form proof check")
     ap.add_argument("--inflight", type=int, default=4,
                     help="proofs in flight per GPU (independent contexts sharing the resident key; 1 = strictly serial)")
+    ap.add_argument("--no-ab", action="store_true", help="skip the in-run A/B of the schedules (after the timed region)")
+    ap.add_argument("--no-micro", action="store_true", help="skip the stand-alone MSM / NTT readings (after the timed region)")
+    ap.add_argument("--no-telemetry", action="store_true", help="no clock / power sampling")
     args = ap.parse_args()
     if args.dry_run_emul:
         args.inflight = 1                # the emulator is single-threaded
@@ -134,6 +137,88 @@ def pmc_traffic(n, curve):
         return k["fetch_bytes_per_launch"] + k["write_bytes_per_launch"], note
     except Exception:
         return None, None
+
+
+def micro_readings(g, cv, pk, torch, np, dev_sync, rnd):
+    """Stand-alone MSM (ark355_bases_load + ark355_msm_dev) and lone-NTT (ark355_ntt_fr_dev) latencies on this GPU."""
+    import ctypes
+    L, ctx, cid = g.lib, g.ctx, cv.curve_id
+    s1, s2 = g.sizes["g1"], g.sizes["g2"]
+
+    def scalars(n, dist, gen):
+        top = (1 << (cv.r.bit_length() - 1 - 192)) - 1
+        uni = gen.integers(0, 1 << 64, size=(n, 4), dtype=np.uint64, endpoint=False)
+        uni[:, 3] &= np.uint64(top)
+        if dist == "uniform":
+            return uni
+        if dist == "equal":
+            return np.tile(uni[:1], (n, 1))
+        raw = np.zeros((n, 4), dtype="<u8")
+        kind = gen.integers(0, 256, size=n, dtype=np.uint8)
+        raw[:, 0] = kind & 1
+        sel = kind >= 230
+        raw[sel] = uni[sel]
+        return raw
+
+    gen = np.random.default_rng(rnd.getrandbits(63))
+    out = {"definition": "latency of ONE ark355_msm_dev call over resident window tables (digit sort, bucket accumulation, "
+                         "merge / reduction / combination, normalisation, D2H of the point), median of 5; scalars canonical, "
+                         "uniform / all equal / 90 % boolean; bases = the key's own query vectors",
+           "msm": {}}
+
+    def as_u8(b):
+        return np.frombuffer(b, dtype=np.uint8) if not isinstance(b, np.ndarray) else b.view(np.uint8).reshape(-1)
+    a_q, b1_q, b2_q, h_q, l_q = (as_u8(x) for x in (pk.a_query, pk.b_g1_query, pk.b_g2_query, pk.h_query, pk.l_query))
+    n20 = min(len(a_q) // s1, 1 << 20)
+    cases = [("g1", 1, a_q[:n20 * s1], n20, ("uniform", "equal", "boolean")),
+             ("g2", 2, b2_q[:n20 * s2], n20, ("uniform", "equal", "boolean"))]
+    big = np.concatenate([a_q, b1_q, l_q, h_q])
+    n22 = min(len(big) // s1, 1 << 22)
+    if n22 > n20:
+        cases.append(("g1", 1, big[:n22 * s1], n22, ("uniform",)))
+    for name, group, bases, n, dists in cases:
+        psz = s1 if group == 1 else s2
+        h = L.bases_load(ctx, cid, group, np.ascontiguousarray(bases), n)
+        try:
+            for dist in dists:
+                ks = scalars(n, dist, gen)
+                kd = torch.from_numpy(ks.view(np.uint8).reshape(-1).copy()).cuda()
+                dev_sync()
+                L.msm_dev(ctx, h, kd.data_ptr(), n, 0, psz)
+                ts = []
+                for _ in range(5):
+                    ta = time.perf_counter()
+                    L.msm_dev(ctx, h, kd.data_ptr(), n, 0, psz)
+                    ts.append((time.perf_counter() - ta) * 1e3)
+                ms = sorted(ts)[2]
+                out["msm"]["%s_2^%d_%s" % (name, n.bit_length() - 1, dist)] = {
+                    "n": n, "ms": round(ms, 3), "mscalar_mul_per_s": round(n / ms / 1e3, 1),
+                    "accumulate_kernel_ms": round(L.kernel_stats(ctx)["accumulate_ms"], 3)}
+                del kd
+        finally:
+            L.dll.ark355_bases_free(h)
+    # lone forward NTT, 2^21 points, data and scratch resident (ark355_ntt_fr_dev on the context's stream)
+    log_n = 21
+    nb = (1 << log_n) * 32
+    data = torch.from_numpy(gen.integers(0, 1 << 62, size=(1 << log_n) * 4, dtype=np.uint64).view(np.uint8).copy()).cuda()
+    scr = torch.empty(nb, dtype=torch.uint8, device=data.device)
+    dev_sync()
+    fn = L.dll.ark355_ntt_fr_dev
+
+    def ntt_once():
+        rc = fn(ctx, cid, ctypes.c_void_p(data.data_ptr()), ctypes.c_void_p(scr.data_ptr()), log_n, 0, 0, None)
+        assert rc == 0, rc
+    ntt_once()
+    dev_sync()
+    reps = 20
+    ta = time.perf_counter()
+    for _ in range(reps):
+        ntt_once()
+    dev_sync()
+    ms = (time.perf_counter() - ta) / reps * 1e3
+    out["ntt"] = {"log_n": log_n, "ms": round(ms, 4), "elements_per_s": (1 << log_n) / (ms * 1e-3),
+                  "definition": "forward radix-2 NTT of 2^21 Fr elements resident in HBM, %d back-to-back calls" % reps}
+    return out
 
 
 _T0 = time.perf_counter()
@@ -289,6 +374,55 @@ def main():
             t.join()
         return results
 
+    # ---- untimed preparation that belongs to the library's own start-up ------------------------------------------
+    # telemetry (tools/gpu_telemetry.py): static facts now, clocks / power / throttling sampled across the run
+    telemetry = {"note": "tools/gpu_telemetry.py; sampled by a child process every 25 ms"}
+    sampler = None
+    if rank == 0 and not emul and not args.no_telemetry:
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import gpu_telemetry as GT
+            bus = None
+            try:
+                pr = torch.cuda.get_device_properties(local_rank)
+                bus = "%04x:%02x:%02x" % (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, pr.pci_device_id)
+                telemetry["device"] = {"name": pr.name, "cus": pr.multi_processor_count, "hbm_bytes": pr.total_memory,
+                                       "torch": torch.__version__, "hip": torch.version.hip}
+            except Exception as e:                            # noqa: BLE001
+                telemetry["device"] = {"error": str(e)[:120]}
+            telemetry["static"] = GT.snapshot(bus)
+            sampler = GT.Sampler(bus, period_ms=25)
+            telemetry["host_before"] = GT.host_counters()
+        except Exception as e:                                # noqa: BLE001
+            telemetry["error"] = "%s: %s" % (type(e).__name__, str(e)[:160])
+    # which of the proving streams share an in-order hardware queue of the runtime (idle device; see ark355_diag_streams)
+    stream_map = None
+    if not emul and rank == 0:
+        try:
+            mat = g.lib.diag_streams(ctxs)
+            names = ["ctx%d" % i for i in range(len(ctxs))] + ["ctx0.sW", "ctx0.sS", "ctx0.sR"]
+            pairs = [[names[i], names[j]] for i in range(len(names)) for j in range(i + 1, len(names))
+                     if mat[i][j] == 1 or mat[j][i] == 1]
+            stream_map = {"streams": names, "serialised_pairs": pairs,
+                          "note": "pairs of streams on which a kernel waited for a spinning kernel of the other: they "
+                                  "share a hardware queue (GPU_MAX_HW_QUEUES) and cannot overlap"}
+        except Exception as e:                                # noqa: BLE001
+            stream_map = {"error": str(e)[:160]}
+    # schedule calibration: with policy SCHED = AUTO the library tries its candidate schedules on the first warm proofs of
+    # a class and keeps the fastest; let it finish BEFORE the contract's warm-up so that the timed region runs one schedule
+    calib = None
+    if not shard and pkh is not None and not emul:
+        t_c = time.perf_counter()
+        rounds = 0
+        while rounds < 6:
+            run(2, None, per_worker=True)
+            rounds += 1
+            info = g.lib.sched_info(g.ctx, pkh, len(ctxs) > 1)
+            if info["latched"] != "auto" or g.lib.ctx_get_policy(g.ctx, "SCHED") >= 0:
+                break
+        calib = {"proofs": rounds * 2 * len(ctxs), "seconds": round(time.perf_counter() - t_c, 3),
+                 "in_flight" if len(ctxs) > 1 else "alone": g.lib.sched_info(g.ctx, pkh, len(ctxs) > 1)}
+        stage("schedule calibration done: %s" % json.dumps(calib))
     run(max(1, -(-args.warmup // len(ctxs))) if args.warmup else 0, None, per_worker=True)
     stage("warm-up done")
     # The harness keeps the assignment as a list of 2^20 Python ints (for the closed-form check) next to other large
@@ -305,12 +439,18 @@ def main():
     thr0 = thread_cpu_times()
     worker_cpu[0] = 0.0
     cpu0 = time.process_time()
+    wall0 = time.time()
     t0 = time.perf_counter()
     results = run(args.steps, rec)
     dev_sync()
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
+    wall1 = time.time()
+    if sampler is not None:
+        time.sleep(0.06)                         # let the sampler's last reading of the region land
+        telemetry["timed_region"] = sampler.window(wall0, wall1)
+        telemetry["host_after_timed_region"] = GT.host_counters()
     host_cpu_s = time.process_time() - cpu0          # CPU time of all threads of this rank over the timed region
     thr1 = thread_cpu_times()
     stage("timed region done: %.2f ms per step" % (dt / args.steps * 1e3))
@@ -327,9 +467,65 @@ def main():
     acc_ms_sum, acc_launches, acc_points = rec
     last = results[-1]
     tim = g.lib.timings(g.ctx)
-    # Outside the timed region: three proofs on ONE context, nothing else in flight -- the uncontended launch duration of
-    # the dominant kernel (with several proofs in flight its launches share the chip with the other proofs' kernels)
+    sched_used = None if shard or pkh is None else g.lib.sched_info(g.ctx, pkh, len(ctxs) > 1)
+    # In-run A/B of the schedules (outside the timed region; the headline above is the library default): the timed region
+    # repeated under each forced schedule, two interleaved passes, same process, same box, same minute.
+    ab = None
+    if not shard and not args.no_ab and rank == 0 and world == 1 and not emul:
+        names = {0: "one_stream", 1: "pipeline", 2: "pipeline_sync", 3: "one_stream_spin"}
+        ab = {"steps": args.steps, "inflight": len(ctxs), "ms_per_step": {v: [] for v in names.values()},
+              "note": "the timed region repeated under each forced schedule (policy SCHED), interleaved; headline = library default"}
+        wall_ab0 = time.time()
+        for _pass in range(2):
+            for code, nm in names.items():
+                for c in ctxs:
+                    g.lib.ctx_set_policy(c, "SCHED", code)
+                dev_sync()
+                ta = time.perf_counter()
+                res = run(args.steps, None)
+                dev_sync()
+                ab["ms_per_step"][nm].append(round((time.perf_counter() - ta) / args.steps * 1e3, 3))
+                results.extend(res)
+        for c in ctxs:
+            g.lib.ctx_set_policy(c, "SCHED", -1)
+        if sampler is not None:
+            telemetry["ab_block"] = sampler.window(wall_ab0, time.time())
+        stage("schedule A/B done: %s" % json.dumps(ab["ms_per_step"]))
+    # One proof at a time on ONE stream, nothing else on the device: every kernel runs alone, so the event-bracketed phases
+    # are ISOLATED kernel times -- the box-independent check of the kernels themselves ("kernels equal, overlap slower" shows
+    # at a glance), and the clean source of the secondary metrics (MSM scalar-mul/s, NTT elements/s).
+    isolated = None
+    if not shard and not emul and rank == 0:
+        g.lib.ctx_set_policy(g.ctx, "SCHED", 0)
+        acc, tms = [], []
+        for _ in range(3):
+            prove_on(g.ctx, rnd.randrange(cv.r), rnd.randrange(cv.r))
+            acc.append(g.lib.kernel_stats(g.ctx)["accumulate_ms"])
+            tms.append(g.lib.timings(g.ctx))
+        g.lib.ctx_set_policy(g.ctx, "SCHED", -1)
+        dev_sync()
+        tmed = {k: sorted(t[k] for t in tms)[1] for k in tms[0]}
+        N_ = r1.domain_size
+        isolated = {"definition": "one proof alone on one stream (policy SCHED = 0): every kernel runs by itself; median of 3",
+                    "accumulate_ms_per_proof": sorted(acc)[1],
+                    "accumulate_g2_launch_ms": tmed["msm_b_g2_ms"], "accumulate_h_launch_ms": tmed["msm_h_ms"],
+                    "witness_map_ms": tmed["witness_map_ms"], "total_ms": tmed["total_ms"],
+                    "msm_g1_mscalar_mul_per_s": (N_ - 1) / (tmed["msm_h_ms"] * 1e-3) / 1e6 if tmed["msm_h_ms"] > 0 else None,
+                    "msm_g2_mscalar_mul_per_s": (r1.m + 4) / (tmed["msm_b_g2_ms"] * 1e-3) / 1e6 if tmed["msm_b_g2_ms"] > 0 else None,
+                    "ntt_elements_per_s_witness_map": 7 * N_ / (tmed["witness_map_ms"] * 1e-3) if tmed["witness_map_ms"] > 0 else None,
+                    "note": "MSM rates: bucket accumulation + its merge / reduction / combination of the H (G1, N-1 terms) and "
+                            "B2 (G2, m+4 terms) MSMs of a proof, sort excluded; NTT rate: 7 transforms of N points per witness "
+                            "map, SpMV and the pointwise step included in the time"}
+        stage("isolated single-stream reading done")
+    # Outside the timed region: single proofs on ONE context, nothing else in flight -- first until the library's measured
+    # schedule choice for the "alone" class has latched, then three for the uncontended launch duration of the dominant
+    # kernel (with several proofs in flight its launches share the chip with the other proofs' kernels)
     solo = None
+    if not shard and pkh is not None and not emul:
+        for _ in range(16):
+            if g.lib.sched_info(g.ctx, pkh, False)["latched"] != "auto":
+                break
+            prove_on(g.ctx, rnd.randrange(cv.r), rnd.randrange(cv.r))
     if not shard and len(ctxs) > 1:
         solo_rec = [0.0, 0, 0]
         for _ in range(3):
@@ -382,6 +578,16 @@ def main():
         latency["constraints_per_s_single_proof_host_pinned_z"] = n / (latency["host_pinned_z_ms"] * 1e-3)
         g.lib.dll.ark355_host_free(ptr)
         stage("latency / host-z readings done")
+    # Stand-alone readings of BASELINE's secondary metrics (outside the timed region, rank 0): ark355_msm_dev over resident
+    # window tables (latency of one call: digit sort, accumulation, bucket reduction, normalisation, D2H of the result) for
+    # three scalar distributions, and a lone forward NTT on device-resident data.  Bases: the key's own query vectors.
+    micro = None
+    if rank == 0 and world == 1 and not shard and not emul and not args.no_micro:
+        try:
+            micro = micro_readings(g, cv, pk, torch, np, dev_sync, rnd)
+        except Exception as e:                                # noqa: BLE001
+            micro = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
+        stage("stand-alone MSM / NTT readings done")
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=xdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -461,19 +667,35 @@ def main():
             "host_cpu_threads": host_cpu_threads,      # cores per thread name over the timed region (top 8)
             # the metric as SURVEY.md 8d defines it (host z -> host proof, single proofs) beside the throughput headline
             "latency": latency,
-            "phases_ms": tim,
+            # which schedule the library's measured choice settled on for this run, and what it saw while choosing
+            "schedule": {"in_timed_region": sched_used, "calibration": calib,
+                         "alone": None if shard or pkh is None else g.lib.sched_info(g.ctx, pkh, False)},
+            "schedule_ab": ab,
+            "isolated": isolated,
+            "micro": micro,
+            "stream_map": stream_map,
+            "telemetry": telemetry,
+            # elapsed times of OVERLAPPING stream segments of the last single proof (the pipeline runs them concurrently:
+            # they do not add up and are not kernel times -- `isolated` has those)
+            "phases_overlapping_stream_segments_ms": tim,
             "prove_alg_bytes": prove_alg_bytes,
             "prove_hbm_frac": prove_alg_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS,
-            # BASELINE's second metric, read inside the prover (H: N-1 G1 terms; B2: m+4 G2 terms of this rank's shard)
-            "msm_g1_mscalar_mul_per_s": (N - 1) / (world if shard else 1) / (tim["msm_h_ms"] * 1e-3) / 1e6 if tim["msm_h_ms"] > 0 else None,
-            "msm_g2_mscalar_mul_per_s": (m + 4) / (world if shard else 1) / (tim["msm_b_g2_ms"] * 1e-3) / 1e6 if tim["msm_b_g2_ms"] > 0 else None,
+            # BASELINE's second metric: ISOLATED readings (one proof alone on one stream; `isolated`), not the overlapping
+            # stream segments rounds 1-3 derived them from; stand-alone ark355_msm_dev calls are under `micro`
+            "msm_g1_mscalar_mul_per_s": isolated["msm_g1_mscalar_mul_per_s"] if isolated else None,
+            "msm_g2_mscalar_mul_per_s": isolated["msm_g2_mscalar_mul_per_s"] if isolated else None,
+            "ntt_elements_per_s": isolated["ntt_elements_per_s_witness_map"] if isolated else None,
             "prep_s": prep_s,
             # how the resident key sits in HBM (window size, windows, table stride, bytes of its five window tables)
             "key_tables": g.lib.pk_table_info(pkh if pkh is not None else sg.load_pk_shard(pk)),
         }
         if not args.no_cpu_baseline and world == 1 and not emul:
             out["cpu_baseline"] = cpu_baseline(args.curve)
+        if sampler is not None:
+            telemetry["host_at_end"] = GT.host_counters()
         print(json.dumps(out), flush=True)
+    if sampler is not None:
+        sampler.stop()
     for c in ctxs[1:]:
         g.lib.ctx_destroy(c)
     if sg is not None:

@@ -91,6 +91,12 @@ typedef struct {
 } ark355_sched_report;
 int32_t ark355_sched_info(const ark355_ctx* ctx, const ark355_pk* pk, int32_t in_flight, ark355_sched_report* out);
 int32_t ark355_sched_reset(const ark355_ctx* ctx);
+/* Diagnostic: which of the library's HIP streams share an in-order hardware queue of the runtime (streams on one queue
+ * serialise whatever their events say).  Probes, on an IDLE device, the own streams of `count` (<= 16) contexts followed
+ * by the three feeder streams of ctxs[0]'s pipeline: serialised is an (count + 3) x (count + 3) row-major matrix,
+ * [i][j] = 1 when a kernel on stream j waited for a spinning kernel on stream i, 0 when it overtook it, -1 when the build
+ * cannot measure it.  bench.py prints it; nothing on the proving path depends on it. */
+int32_t ark355_diag_streams(ark355_ctx** ctxs, uint32_t count, int8_t* serialised);
 
 /* Page-locked host memory for assignments / key vectors handed to the entry points below: H2D copies from pinned
  * memory run at PCIe rate (~55 GB/s) and truly asynchronously; pageable memory is staged by the runtime at a fraction

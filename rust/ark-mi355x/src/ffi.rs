@@ -115,6 +115,7 @@ extern "C" {
     pub fn ark355_ctx_get_policy(ctx: *mut ark355_ctx, name: *const c_char, value: *mut i64) -> i32;
     pub fn ark355_sched_info(ctx: *const ark355_ctx, pk: *const ark355_pk, in_flight: i32, out: *mut ark355_sched_report) -> i32;
     pub fn ark355_sched_reset(ctx: *const ark355_ctx) -> i32;
+    pub fn ark355_diag_streams(ctxs: *mut *mut ark355_ctx, count: u32, serialised: *mut i8) -> i32;
 
     pub fn ark355_host_alloc(bytes: u64, out: *mut *mut c_void) -> i32;
     pub fn ark355_host_free(p: *mut c_void);

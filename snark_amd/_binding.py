@@ -48,7 +48,7 @@ SYMBOLS = [
     "ark355_pk_table_info",
     "ark355_points_decode", "ark355_points_encode", "ark355_proof_to_bytes", "ark355_proof_from_bytes",
     "ark355_setup_scalars", "ark355_verify_batch",
-    "ark355_ctx_set_policy", "ark355_ctx_get_policy", "ark355_sched_info", "ark355_sched_reset",
+    "ark355_ctx_set_policy", "ark355_ctx_get_policy", "ark355_sched_info", "ark355_sched_reset", "ark355_diag_streams",
 ]
 
 SCHED_NAMES = {-1: "auto", 0: "one_stream", 1: "pipeline", 2: "pipeline_sync", 3: "one_stream_spin"}
@@ -174,6 +174,7 @@ class Lib:
         d.ark355_ctx_get_policy.argtypes = [vp, C.c_char_p, P(i64)]
         d.ark355_sched_info.argtypes = [vp, vp, i32, P(SchedReport)]
         d.ark355_sched_reset.argtypes = [vp]
+        d.ark355_diag_streams.argtypes = [vp, u32, vp]
         d.ark355_get_timings.argtypes = [vp, P(Timings)]
         d.ark355_get_kernel_stats.argtypes = [vp, P(C.c_float), P(u64), P(u64)]
         for name in SYMBOLS:
@@ -212,6 +213,14 @@ class Lib:
         return {"latched": SCHED_NAMES.get(r.latched, str(r.latched)), "last": SCHED_NAMES.get(r.last, str(r.last)),
                 "samples": {SCHED_NAMES[i]: int(r.samples[i]) for i in range(4) if r.samples[i]},
                 "mean_ms": {SCHED_NAMES[i]: round(float(r.mean_ms[i]), 3) for i in range(4) if r.samples[i]}}
+
+    def diag_streams(self, ctxs):
+        """ark355_diag_streams: rows of the serialisation matrix over [ctx streams..., sW, sS, sR of ctxs[0]]"""
+        n = len(ctxs) + 3
+        arr = (C.c_void_p * len(ctxs))(*ctxs)
+        out = (C.c_int8 * (n * n))()
+        self.check(ctxs[0], self.dll.ark355_diag_streams(arr, len(ctxs), out))
+        return [[int(out[i * n + j]) for j in range(n)] for i in range(n)]
 
     def sched_reset(self, ctx):
         self.check(ctx, self.dll.ark355_sched_reset(ctx))

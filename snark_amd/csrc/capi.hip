@@ -5,6 +5,7 @@
 #include <new>
 #include <thread>
 #include "api_impl.cuh"
+#include "diag_impl.cuh"
 
 namespace ark355 {
 extern template struct Api<BlsCurve>;
@@ -188,6 +189,25 @@ int32_t ark355_sched_info(const ark355_ctx* ctx, const ark355_pk* pk, int32_t in
     }
   }
   return ARK355_OK;
+}
+int32_t ark355_diag_streams(ark355_ctx** ctxs, uint32_t count, int8_t* serialised) {
+  if (!ctxs || !serialised || count == 0 || count > 16) return ARK355_EINVAL;
+  for (uint32_t i = 0; i < count; i++)
+    if (!ctxs[i]) return ARK355_EINVAL;
+  // streams probed: every context's own stream, then the three feeder streams of ctxs[0] (created if need be)
+  return guarded(ctxs[0], [&] {
+    CtxExtra& ex = extra(ctxs[0]);
+    ex.prover.ensure_streams(ctxs[0]->policy.stream_prio != 0);
+    std::vector<hipStream_t> st;
+    for (uint32_t i = 0; i < count; i++) st.push_back(ctxs[i]->stream);
+    st.push_back(ex.prover.sW);
+    st.push_back(ex.prover.sS);
+    st.push_back(ex.prover.sR);
+    const size_t n = st.size();
+    for (size_t i = 0; i < n; i++)
+      for (size_t j = 0; j < n; j++)
+        serialised[i * n + j] = (int8_t)(i == j ? 1 : diag_streams_serialised(st[i], st[j]));
+  });
 }
 int32_t ark355_sched_reset(const ark355_ctx* ctx) {
   if (!ctx) return ARK355_EINVAL;

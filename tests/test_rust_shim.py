@@ -11,7 +11,7 @@ FFI = os.path.join(ROOT, "rust", "ark-mi355x", "src", "ffi.rs")
 
 C2RUST = {
     "int32_t": "i32", "uint32_t": "u32", "int64_t": "i64", "uint64_t": "u64", "float": "f32", "void": "()",
-    "uint8_t": "u8", "char": "c_char",
+    "uint8_t": "u8", "int8_t": "i8", "char": "c_char",
 }
 
 
