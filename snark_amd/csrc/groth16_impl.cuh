@@ -635,15 +635,15 @@ static void prove_run(ark355_ctx* ctx, ProverScratch& sc, const PkDev& pk, const
     msm_sort<Fr>(ctx, sc.sortZ, (const uint8_t*)sc.zx.p + pk.z_lo * sizeof(Fr), pk.z_cnt, 1, sS, &pk.a_ext);
     // bucket sets are sized and cleared here, behind the sort they belong to (msm_prepare_phase)
     // (a batch-affine MSM sizes its bucket set later, for the nodes its tree levels leave over)
-    if (!pk.b2_ext.batch_affine) msm_prepare_phase<Fq2>(pol, sc.sortZ, sc.bkB2, sS);
-    if (!pk.a_ext.batch_affine) msm_prepare_phase<Fq>(pol, sc.sortZ, sc.bkA, sS);
-    if (!pk.b1_ext.batch_affine) msm_prepare_phase<Fq>(pol, sc.sortZ, sc.bkB1, sS);
-    if (!pk.l_ext.batch_affine) msm_prepare_phase<Fq>(pol, sc.sortZ, sc.bkL, sS);
+    if (!pk.b2_ext.batch_affine) msm_prepare_phase<Fq2>(pol, sc.sortZ, sc.bkB2, sS, pk.b2_ext.limb28);
+    if (!pk.a_ext.batch_affine) msm_prepare_phase<Fq>(pol, sc.sortZ, sc.bkA, sS, pk.a_ext.limb28);
+    if (!pk.b1_ext.batch_affine) msm_prepare_phase<Fq>(pol, sc.sortZ, sc.bkB1, sS, pk.b1_ext.limb28);
+    if (!pk.l_ext.batch_affine) msm_prepare_phase<Fq>(pol, sc.sortZ, sc.bkL, sS, pk.l_ext.limb28);
     ARK_CHECK_HIP(hipEventRecord(ev[E_SORT0], sS));
     ARK_CHECK_HIP(hipEventRecord(ev[E_SORT1], sS));     // (L' shares the sort of zx)
     ARK_CHECK_HIP(hipStreamWaitEvent(sS, ev[E_H], 0));
     msm_sort<Fr>(ctx, sc.sortH, (const uint8_t*)d_h + pk.h_lo * sizeof(Fr), pk.h_cnt, 1, sS, &pk.h_query);
-    if (!pk.h_query.batch_affine) msm_prepare_phase<Fq>(pol, sc.sortH, sc.bkH, sS);
+    if (!pk.h_query.batch_affine) msm_prepare_phase<Fq>(pol, sc.sortH, sc.bkH, sS, pk.h_query.limb28);
     ARK_CHECK_HIP(hipEventRecord(ev[E_SORT2], sS));
 
     // accumulations (A, B1, B2 share the sort of zx) and, per MSM, its reduction on sR

@@ -27,6 +27,61 @@ struct Acc28 {
   Fp28<P> x, y, zz, zzz;
 };
 
+// ARK_LAZY_FLUSH: the accumulation kernels store a finished run as it stands -- the lazily reduced 28-bit limbs of the
+// accumulator, 4 x N words (G1) or this lane's 4 x N of 8 x N (G2) -- into a raw slot array [buckets | head | tail],
+// and msm_unlazy28_kernel converts every slot to the canonical 32-bit XYZZ form once, in front of the merge.  The
+// conversion (carry propagation, three conditional subtractions, repacking, one Montgomery step: ~500 instructions per
+// coordinate) used to sit in the flush, where ONE lane of a wave closing a run made all 64 wait for it: 12 % of the
+// iterations at 512 entries per bucket.  0 keeps the conversion in the flush (A/B).
+#ifndef ARK_LAZY_FLUSH
+#define ARK_LAZY_FLUSH 0
+#endif
+#define ARK_KEY_NONE 0xFFFFFFFFu
+
+// What the accumulation kernels write a run into: raw limbs when ARK_LAZY_FLUSH, the canonical point otherwise.
+#if ARK_LAZY_FLUSH
+template <class P, int COORDS>
+struct alignas(8) Msm28SlotRaw {
+  uint32_t w[COORDS * Fp28<P>::N];
+};
+template <class P, int COORDS>
+using Msm28Slot = Msm28SlotRaw<P, COORDS>;
+#else
+template <class P, int COORDS>
+using Msm28Slot = typename std::conditional<COORDS == 4, XYZZ<Fp<P>>, XYZZ<Fp2<P>>>::type;
+#endif
+
+// one lane per (slot, coordinate); COORDS = 4 (XYZZ over Fq) or 8 (over Fq2: x.c0, x.c1, y.c0, ...).  An empty run was
+// stored as zeros, which convert to the all-zero XYZZ = infinity; head / tail slots without a key were never written.
+template <class P, int COORDS>
+__global__ void __launch_bounds__(256)
+msm_unlazy28_kernel(const uint32_t* __restrict__ raw, uint32_t nb, uint32_t segs, const uint32_t* __restrict__ head_key,
+                    const uint32_t* __restrict__ tail_key, Fp<P>* __restrict__ buckets, Fp<P>* __restrict__ head,
+                    Fp<P>* __restrict__ tail) {
+  using F = Fp28<P>;
+  const uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t slot = idx / COORDS;
+  const uint32_t c = (uint32_t)(idx % COORDS);
+  if (slot >= (uint64_t)nb + 2ull * segs) return;
+  Fp<P>* dst;
+  if (slot < nb) {
+    dst = buckets + slot * COORDS + c;
+  } else if (slot < (uint64_t)nb + segs) {
+    const uint64_t sg = slot - nb;
+    if (head_key[sg] == ARK_KEY_NONE) return;
+    dst = head + sg * COORDS + c;
+  } else {
+    const uint64_t sg = slot - nb - segs;
+    if (tail_key[sg] == ARK_KEY_NONE) return;
+    dst = tail + sg * COORDS + c;
+  }
+  const uint32_t* src = raw + (slot * COORDS + c) * F::N;
+  F v;
+#pragma unroll
+  for (int i = 0; i < F::N; i++) v.l[i] = src[i];
+  *dst = F::to_fp_lt8(v);
+}
+
 template <class P>
 __global__ void __launch_bounds__(256)
 table_to28_kernel(const Affine<Fp<P>>* __restrict__ src, Affine28<P>* __restrict__ dst, uint64_t rows) {
@@ -131,13 +186,16 @@ ARK_D void madd28(Acc28<P>& acc, bool& empty, const Fp28<P>& px, const Fp28<P>& 
 }
 
 // Same contract as msm_accumulate_kernel<Fp<P>, false>; `bases` holds Affine28 rows.
+#ifndef ARK_ACC_PREFETCH_KEY
+#define ARK_ACC_PREFETCH_KEY 0   // the bucket key of the next entry travels with its row index, one iteration ahead
+#endif
 template <class P>
 __global__ void __launch_bounds__(MSM_THREADS)
 msm_accumulate28_kernel(const Affine28<P>* __restrict__ bases, const uint32_t* __restrict__ sorted_keys,
                         const uint32_t* __restrict__ sorted_vals, const uint32_t* __restrict__ total_ptr,
                         const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ counts,
-                        XYZZ<Fp<P>>* __restrict__ buckets, XYZZ<Fp<P>>* __restrict__ head,
-                        uint32_t* __restrict__ head_key, XYZZ<Fp<P>>* __restrict__ tail,
+                        Msm28Slot<P, 4>* __restrict__ buckets, Msm28Slot<P, 4>* __restrict__ head,
+                        uint32_t* __restrict__ head_key, Msm28Slot<P, 4>* __restrict__ tail,
                         uint32_t* __restrict__ tail_key, uint32_t seg_len) {
   using F = Fp28<P>;
   using Fq = Fp<P>;
@@ -158,6 +216,31 @@ msm_accumulate28_kernel(const Affine28<P>* __restrict__ bases, const uint32_t* _
   acc.zz = F::zero();
   acc.zzz = F::zero();
   // always_inline: a closure that is inlined late keeps every captured variable (the accumulator!) in scratch memory
+#if ARK_LAZY_FLUSH
+  auto flush = [&](uint32_t key, uint32_t run_end) __attribute__((always_inline)) {
+    const uint32_t o = offsets[key], cnt = counts[key];
+    const bool complete = (run_start == o) && (run_end == o + cnt);
+    // three explicit branches, not a select among the captured pointers (see msm_accumulate_g2l28_kernel)
+    auto store = [&](uint32_t* d) __attribute__((always_inline)) {
+#pragma unroll
+      for (int i = 0; i < F::N; i++) {
+        d[i] = empty ? 0u : acc.x.l[i];
+        d[F::N + i] = empty ? 0u : acc.y.l[i];
+        d[2 * F::N + i] = empty ? 0u : acc.zz.l[i];
+        d[3 * F::N + i] = empty ? 0u : acc.zzz.l[i];
+      }
+    };
+    if (complete) {
+      store(buckets[key].w);
+    } else if (first_run) {
+      store(head[seg].w);
+      head_key[seg] = key;
+    } else {
+      store(tail[seg].w);
+      tail_key[seg] = key;
+    }
+  };
+#else
   auto flush = [&](uint32_t key, uint32_t run_end) __attribute__((always_inline)) {
     XYZZ<Fq> out = XYZZ<Fq>::inf();
     if (!empty) {
@@ -169,16 +252,24 @@ msm_accumulate28_kernel(const Affine28<P>* __restrict__ bases, const uint32_t* _
     msm_flush_run<Fq>(key, out, first_run, run_start, run_end, seg, offsets, counts, buckets, head, head_key, tail,
                       tail_key);
   };
+#endif
   // software prefetch of the next row into explicit 16-byte registers (see msm_accumulate_kernel)
   uint4 nx[Q];
   uint32_t v_next = sorted_vals[start];
+#if ARK_ACC_PREFETCH_KEY
+  uint32_t key_next = cur_key;
+#endif
   {
     const uint4* src = reinterpret_cast<const uint4*>(bases + (v_next & ARK_TBL_MASK));
 #pragma unroll
     for (int k = 0; k < Q; k++) nx[k] = src[k];
   }
   for (uint32_t e = start; e < end; e++) {
+#if ARK_ACC_PREFETCH_KEY
+    const uint32_t key = key_next;
+#else
     const uint32_t key = sorted_keys[e];
+#endif
     const uint32_t v = v_next;
     F px, py;
     {
@@ -198,6 +289,9 @@ msm_accumulate28_kernel(const Affine28<P>* __restrict__ bases, const uint32_t* _
     }
     const uint32_t en = (e + 1 < end) ? e + 1 : e;       // clamp: the last iteration re-reads its own entry
     v_next = sorted_vals[en];
+#if ARK_ACC_PREFETCH_KEY
+    key_next = sorted_keys[en];
+#endif
     {
       const uint4* src = reinterpret_cast<const uint4*>(bases + (v_next & ARK_TBL_MASK));
 #pragma unroll
@@ -339,8 +433,12 @@ ARK_HD_NOINLINE typename Fp28<P>::Vec dbl28_g2_coord_ni(Fp28<P> x, Fp28<P> y, in
 // acc += (px, +-py) over Fq2, one component per lane.  Same formula and value classes as madd28; Pd, R and
 // T = Q - X3 are normalised before they enter a multi-product pass, which keeps every column below
 // 14 (2^56 + 2^57 + 2^57 + 2^58) + 14 2^56 < 2^63 (the emulator build traps on any column overflow).
+// The addition comes in two halves so that the accumulation loop can issue the gather of the NEXT table row between
+// them: after the first half px / py are dead, and the row's latency hides under the eight products of the second.
+// madd28_g2_head returns false when the entry is already dealt with (bucket opened, doubling, cancellation).
 template <class P>
-ARK_D void madd28_g2(Acc28<P>& acc, bool& empty, const Fp28<P>& px, const Fp28<P>& py, bool negate) {
+ARK_D bool madd28_g2_head(Acc28<P>& acc, bool& empty, const Fp28<P>& px, const Fp28<P>& py, bool negate,
+                          Fp28<P>& Pd, Fp28<P>& R) {
   using F = Fp28<P>;
   using L = Pair28<P>;
   const F pys = L::sel(negate, F::template neg<2, 1>(py), py);
@@ -351,12 +449,12 @@ ARK_D void madd28_g2(Acc28<P>& acc, bool& empty, const Fp28<P>& px, const Fp28<P
     acc.zz = one;
     acc.zzz = one;
     empty = false;
-    return;
+    return false;
   }
   const F U2 = L::template mul<2, 1>(px, acc.zz);
   const F S2 = L::template mul<3, 3>(pys, acc.zzz);          // pys limbs <= 2^29 - 1
-  const F Pd = F::norm(F::template sub<8, 1>(U2, acc.x));
-  const F R = F::norm(F::template sub<3, 1>(S2, acc.y));
+  Pd = F::norm(F::template sub<8, 1>(U2, acc.x));
+  R = F::norm(F::template sub<3, 1>(S2, acc.y));
   if (L::both(Pd.multiple_hint() < 10u)) {
     if (L::both(F::is_zero_mod_p_inl(Pd))) {
       if (L::both(F::is_zero_mod_p_inl(R))) {
@@ -369,9 +467,15 @@ ARK_D void madd28_g2(Acc28<P>& acc, bool& empty, const Fp28<P>& px, const Fp28<P
       } else {
         empty = true;
       }
-      return;
+      return false;
     }
   }
+  return true;
+}
+template <class P>
+ARK_D void madd28_g2_tail(Acc28<P>& acc, const Fp28<P>& Pd, const Fp28<P>& R) {
+  using F = Fp28<P>;
+  using L = Pair28<P>;
   const F PP = L::template sqr<11>(Pd);
   const F PPP = L::template mul<11, 1>(Pd, PP);
   const F Q = L::template mul<8, 1>(acc.x, PP);
@@ -392,7 +496,16 @@ ARK_D void madd28_g2(Acc28<P>& acc, bool& empty, const Fp28<P>& px, const Fp28<P
 #endif
   acc.x = X3;
 }
+template <class P>
+ARK_D void madd28_g2(Acc28<P>& acc, bool& empty, const Fp28<P>& px, const Fp28<P>& py, bool negate) {
+  Fp28<P> Pd, R;
+  if (madd28_g2_head<P>(acc, empty, px, py, negate, Pd, R)) madd28_g2_tail<P>(acc, Pd, R);
+}
 
+#ifndef ARK_G2L28_PREFETCH
+#define ARK_G2L28_PREFETCH 0  // 0: load key, row index and row at the top of every iteration; 1: key and index one
+                              // iteration ahead; 2: also the row, gathered between the two halves of the addition
+#endif
 #ifndef ARK_G2L28_WAVES
 #define ARK_G2L28_WAVES 2     // waves per SIMD the register budget is sized for; 3 (168 VGPRs, ~90 spills per
                               // addition) was measured: 10.5 vs 9.2 ms per 2^20-term MSM
@@ -402,8 +515,8 @@ __global__ void __launch_bounds__(MSM_THREADS, ARK_G2L28_WAVES)
 msm_accumulate_g2l28_kernel(const Affine28G2<P>* __restrict__ bases, const uint32_t* __restrict__ sorted_keys,
                             const uint32_t* __restrict__ sorted_vals, const uint32_t* __restrict__ total_ptr,
                             const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ counts,
-                            XYZZ<Fp2<P>>* __restrict__ buckets, XYZZ<Fp2<P>>* __restrict__ head,
-                            uint32_t* __restrict__ head_key, XYZZ<Fp2<P>>* __restrict__ tail,
+                            Msm28Slot<P, 8>* __restrict__ buckets, Msm28Slot<P, 8>* __restrict__ head,
+                            uint32_t* __restrict__ head_key, Msm28Slot<P, 8>* __restrict__ tail,
                             uint32_t* __restrict__ tail_key, uint32_t seg_len) {
   using F = Fp28<P>;
   using Fq = Fp<P>;
@@ -426,6 +539,35 @@ msm_accumulate_g2l28_kernel(const Affine28G2<P>* __restrict__ bases, const uint3
   acc.zz = F::zero();
   acc.zzz = F::zero();
   // always_inline: a closure that is inlined late keeps every captured variable (the accumulator!) in scratch memory
+#if ARK_LAZY_FLUSH
+  auto flush = [&](uint32_t key, uint32_t run_end) __attribute__((always_inline)) {
+    const uint32_t o = offsets[key], cnt = counts[key];
+    const bool complete = (run_start == o) && (run_end == o + cnt);
+    // this lane's halves of the four Fq2 coordinates as they stand: coordinate k, component par -> words
+    // [(2k + par) N, (2k + par + 1) N) of the slot (the order of the Fq values inside XYZZ<Fp2>).
+    // Three explicit branches, NOT a select among the captured pointers: hipcc turns such a select into an indexed
+    // load from the closure object, which then cannot be scalarised -- and every captured variable, the accumulator
+    // included, lives in scratch memory for the whole loop (28 x 16-byte scratch accesses per mixed addition)
+    auto store = [&](uint32_t* d) __attribute__((always_inline)) {
+#pragma unroll
+      for (int i = 0; i < F::N; i++) {
+        d[(0 + par) * F::N + i] = empty ? 0u : acc.x.l[i];
+        d[(2 + par) * F::N + i] = empty ? 0u : acc.y.l[i];
+        d[(4 + par) * F::N + i] = empty ? 0u : acc.zz.l[i];
+        d[(6 + par) * F::N + i] = empty ? 0u : acc.zzz.l[i];
+      }
+    };
+    if (complete) {
+      store(buckets[key].w);
+    } else if (first_run) {
+      store(head[seg].w);
+      if (par == 0) head_key[seg] = key;
+    } else {
+      store(tail[seg].w);
+      if (par == 0) tail_key[seg] = key;
+    }
+  };
+#else
   auto flush = [&](uint32_t key, uint32_t run_end) __attribute__((always_inline)) {
     // this lane's halves of the four Fq2 coordinates, canonical 32-bit form
     XYZZ<Fq> mine = XYZZ<Fq>::inf();
@@ -457,6 +599,77 @@ msm_accumulate_g2l28_kernel(const Affine28G2<P>* __restrict__ bases, const uint3
       if (par == 0) tail_key[seg] = key;
     }
   };
+#endif
+#if ARK_G2L28_PREFETCH
+  // entry e + 1's key and row index are loaded during entry e (both are needed before anything else can start);
+  // with ARK_G2L28_PREFETCH == 2 the row itself is gathered between the two halves of the addition
+  uint32_t v_next = sorted_vals[start], key_next = cur_key;
+#if ARK_G2L28_PREFETCH == 2
+  uint4 nx[Q];
+  {
+    const uint4* src = reinterpret_cast<const uint4*>(&bases[v_next & ARK_TBL_MASK].half[par]);
+#pragma unroll
+    for (int k = 0; k < Q; k++) nx[k] = src[k];
+  }
+#endif
+  for (uint32_t e = start; e < end; e++) {
+    const uint32_t key = key_next;
+    const uint32_t v = v_next;
+    F px, py;
+    {
+      uint32_t d[4 * Q];
+#if ARK_G2L28_PREFETCH == 2
+#pragma unroll
+      for (int k = 0; k < Q; k++) {
+        d[4 * k + 0] = nx[k].x;
+        d[4 * k + 1] = nx[k].y;
+        d[4 * k + 2] = nx[k].z;
+        d[4 * k + 3] = nx[k].w;
+      }
+#else
+      const uint4* src = reinterpret_cast<const uint4*>(&bases[v & ARK_TBL_MASK].half[par]);
+#pragma unroll
+      for (int k = 0; k < Q; k++) {
+        const uint4 t = src[k];
+        d[4 * k + 0] = t.x;
+        d[4 * k + 1] = t.y;
+        d[4 * k + 2] = t.z;
+        d[4 * k + 3] = t.w;
+      }
+#endif
+#pragma unroll
+      for (int k = 0; k < F::N; k++) {
+        px.l[k] = d[k];
+        py.l[k] = d[F::N + k];
+      }
+    }
+    const uint32_t en = (e + 1 < end) ? e + 1 : e;       // clamp: the last iteration re-reads its own entry
+    v_next = sorted_vals[en];
+    key_next = sorted_keys[en];
+    if (key != cur_key) {
+      flush(cur_key, e);
+      cur_key = key;
+      run_start = e;
+      first_run = false;
+      empty = true;
+    }
+    uint32_t any = 0;
+#pragma unroll
+    for (int k = 0; k < F::N; k++) any |= px.l[k] | py.l[k];
+    F Pd, R;
+    bool more = false;
+    if ((any | ark_pair_xchg(any)) != 0)                 // else: base at infinity (pair-wide)
+      more = madd28_g2_head<P>(acc, empty, px, py, (v >> 31) != 0, Pd, R);
+#if ARK_G2L28_PREFETCH == 2
+    {
+      const uint4* src = reinterpret_cast<const uint4*>(&bases[v_next & ARK_TBL_MASK].half[par]);
+#pragma unroll
+      for (int k = 0; k < Q; k++) nx[k] = src[k];
+    }
+#endif
+    if (more) madd28_g2_tail<P>(acc, Pd, R);
+  }
+#else
   for (uint32_t e = start; e < end; e++) {
     const uint32_t key = sorted_keys[e];
     const uint32_t v = sorted_vals[e];
@@ -491,6 +704,7 @@ msm_accumulate_g2l28_kernel(const Affine28G2<P>* __restrict__ bases, const uint3
     if ((any | ark_pair_xchg(any)) == 0) continue;       // base at infinity (pair-wide)
     madd28_g2<P>(acc, empty, px, py, (v >> 31) != 0);
   }
+#endif
   flush(cur_key, end);
 }
 

@@ -1468,8 +1468,21 @@ static void msm_sort(ark355_ctx* ctx, MsmSort& s, const void* d_scalars, uint64_
 // Scratch for the bucket phase of one group type.
 struct MsmBuckets {
   DevBuf buckets, head, tail, head_key, tail_key, partials, heavy_count, heavy_list, lvl_t, lvl_w;
+  DevBuf raw28;                         // [buckets | head | tail] slots of raw 28-bit limbs (ARK_LAZY_FLUSH, msm28_impl.cuh)
   uint32_t seg_len = 32, segs = 0;      // of the last accumulation over this bucket set (G1 and G2 differ)
   bool prepared = false;                // msm_prepare_phase ran for the coming accumulation
+  bool lazy28 = false;                  // that accumulation leaves its runs in raw28; msm_reduce_phase converts them
+};
+
+template <class F>
+struct msm_slot28 {                     // Params and coordinate count of the raw slots of an XYZZ<F> bucket set
+  using P = typename F::Params;
+  static constexpr int COORDS = 4;
+};
+template <class Q>
+struct msm_slot28<Fp2<Q>> {
+  using P = Q;
+  static constexpr int COORDS = 8;
 };
 
 // Phase 1 of the bucket method over an existing sort: bucket accumulation (the chip-filling kernel).
@@ -1477,10 +1490,12 @@ struct MsmBuckets {
 // stream right behind the sort, so that the accumulation stream carries nothing but accumulation kernels: three small
 // fill kernels in front of every accumulation launch sat behind the other proofs' workgroups and opened a gap between
 // consecutive accumulations (31 fills per proof, 2.5 ms of stream time with four proofs in flight).
+// lazy28: the accumulation will run on a radix-2^28 window table.
 template <class F>
-static void msm_prepare_phase(const TunePolicy& pol, const MsmSort& s, MsmBuckets& b, hipStream_t stream) {
+static void msm_prepare_phase(const TunePolicy& pol, const MsmSort& s, MsmBuckets& b, hipStream_t stream, bool lazy28 = false) {
   const MsmPlan& p = s.plan;
   b.prepared = true;
+  b.lazy28 = lazy28 && ARK_LAZY_FLUSH;
   if (p.n == 0) return;
   const uint64_t entries = (uint64_t)p.windows * p.n;
   b.seg_len = msm_seg_len(entries, is_fp2<F>::value, pol.msm_seg);
@@ -1491,9 +1506,29 @@ static void msm_prepare_phase(const TunePolicy& pol, const MsmSort& s, MsmBucket
   b.tail.ensure((size_t)segs * sizeof(XYZZ<F>));
   b.head_key.ensure((size_t)segs * 4);
   b.tail_key.ensure((size_t)segs * 4);
-  ARK_CHECK_HIP(hipMemsetAsync(b.buckets.p, 0, (size_t)p.total_buckets * sizeof(XYZZ<F>), stream));
+  if (b.lazy28) {
+    // the raw bucket slots are cleared instead: every canonical bucket is written by msm_unlazy28_kernel
+    using S = msm_slot28<F>;
+    const size_t slot = (size_t)S::COORDS * Fp28<typename S::P>::N * 4;
+    b.raw28.ensure(((size_t)p.total_buckets + 2 * (size_t)segs) * slot);
+    ARK_CHECK_HIP(hipMemsetAsync(b.raw28.p, 0, (size_t)p.total_buckets * slot, stream));
+  } else {
+    ARK_CHECK_HIP(hipMemsetAsync(b.buckets.p, 0, (size_t)p.total_buckets * sizeof(XYZZ<F>), stream));
+  }
   ARK_CHECK_HIP(hipMemsetAsync(b.head_key.p, 0xFF, (size_t)segs * 4, stream));
   ARK_CHECK_HIP(hipMemsetAsync(b.tail_key.p, 0xFF, (size_t)segs * 4, stream));
+}
+
+// destination arrays of the 28-bit accumulation kernels: which = 0 buckets, 1 head, 2 tail
+template <class P, int COORDS>
+static Msm28Slot<P, COORDS>* msm_slots28(MsmBuckets& b, uint32_t total_buckets, int which) {
+#if ARK_LAZY_FLUSH
+  Msm28Slot<P, COORDS>* base = b.raw28.as<Msm28Slot<P, COORDS>>();
+  return which == 0 ? base : (which == 1 ? base + total_buckets : base + total_buckets + b.segs);
+#else
+  (void)total_buckets;
+  return (which == 0 ? b.buckets : (which == 1 ? b.head : b.tail)).as<Msm28Slot<P, COORDS>>();
+#endif
 }
 
 template <class F>
@@ -1501,8 +1536,9 @@ static void msm_accumulate_phase(ark355_ctx* ctx, const MsmSort& s, MsmBuckets& 
                                  hipStream_t stream, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr,
                                  bool bases28 = false) {
   const MsmPlan& p = s.plan;
-  if (!b.prepared) msm_prepare_phase<F>(ctx->policy, s, b, stream);      // stand-alone MSMs: same stream
+  if (!b.prepared) msm_prepare_phase<F>(ctx->policy, s, b, stream, bases28);      // stand-alone MSMs: same stream
   b.prepared = false;
+  ARK_REQUIRE(b.lazy28 == (bases28 && ARK_LAZY_FLUSH), ARK355_EINVAL, "bucket set prepared for the other table format");
   if (p.n == 0) return;
   const uint32_t segs = b.segs;
   const uint32_t grid_s = (segs + MSM_THREADS - 1) / MSM_THREADS;
@@ -1528,8 +1564,8 @@ static void msm_accumulate_phase(ark355_ctx* ctx, const MsmSort& s, MsmBuckets& 
       ARK_LAUNCH((msm_accumulate_g2l28_kernel<P>), dim3(grid_l), dim3(MSM_THREADS), 0, stream,
                  reinterpret_cast<const Affine28G2<P>*>(d_bases), s.sorted_keys.as<uint32_t>(),
                  s.sorted_vals.as<uint32_t>(), s.total.as<uint32_t>(), s.offsets.as<uint32_t>(),
-                 s.counts.as<uint32_t>(), b.buckets.as<XYZZ<F>>(), b.head.as<XYZZ<F>>(), b.head_key.as<uint32_t>(),
-                 b.tail.as<XYZZ<F>>(), b.tail_key.as<uint32_t>(), b.seg_len);
+                 s.counts.as<uint32_t>(), msm_slots28<P, 8>(b, p.total_buckets, 0), msm_slots28<P, 8>(b, p.total_buckets, 1),
+                 b.head_key.as<uint32_t>(), msm_slots28<P, 8>(b, p.total_buckets, 2), b.tail_key.as<uint32_t>(), b.seg_len);
     } else if (!g2_whole) {
       using P = typename F::Base::Params;
       const uint32_t grid_l = (2 * segs + MSM_THREADS - 1) / MSM_THREADS;
@@ -1547,8 +1583,8 @@ static void msm_accumulate_phase(ark355_ctx* ctx, const MsmSort& s, MsmBuckets& 
     ARK_LAUNCH((msm_accumulate28_kernel<P>), dim3(grid_s), dim3(MSM_THREADS), 0, stream,
                reinterpret_cast<const Affine28<P>*>(d_bases), s.sorted_keys.as<uint32_t>(),
                s.sorted_vals.as<uint32_t>(), s.total.as<uint32_t>(), s.offsets.as<uint32_t>(),
-               s.counts.as<uint32_t>(), b.buckets.as<XYZZ<F>>(), b.head.as<XYZZ<F>>(), b.head_key.as<uint32_t>(),
-               b.tail.as<XYZZ<F>>(), b.tail_key.as<uint32_t>(), b.seg_len);
+               s.counts.as<uint32_t>(), msm_slots28<P, 4>(b, p.total_buckets, 0), msm_slots28<P, 4>(b, p.total_buckets, 1),
+               b.head_key.as<uint32_t>(), msm_slots28<P, 4>(b, p.total_buckets, 2), b.tail_key.as<uint32_t>(), b.seg_len);
   } else {
     launch(std::false_type{});
   }
@@ -1581,6 +1617,16 @@ static void msm_reduce_phase(ark355_ctx* ctx, const MsmSort& s, MsmBuckets& b, X
   } else {
     const uint32_t segs = b.segs;
     const uint32_t grid_b = (p.total_buckets + MSM_THREADS - 1) / MSM_THREADS;
+    if (b.lazy28) {
+      using S = msm_slot28<F>;
+      using Fq = Fp<typename S::P>;
+      const uint64_t lanes = ((uint64_t)p.total_buckets + 2ull * segs) * S::COORDS;
+      ARK_LAUNCH((msm_unlazy28_kernel<typename S::P, S::COORDS>), dim3((uint32_t)((lanes + 255) / 256)), dim3(256), 0,
+                 stream, b.raw28.as<uint32_t>(), p.total_buckets, segs, b.head_key.as<uint32_t>(),
+                 b.tail_key.as<uint32_t>(), b.buckets.as<Fq>(), b.head.as<Fq>(), b.tail.as<Fq>());
+      ARK_CHECK_LAUNCH();
+      b.lazy28 = false;
+    }
     // at most entries / (MSM_HEAVY_SPAN * segment length) buckets can be heavy
     const uint32_t max_heavy = segs / MSM_HEAVY_SPAN + 1;
     // "heavy" is relative: twice the average span of a bucket once that exceeds the fixed threshold

@@ -24,21 +24,23 @@ def newest_src():
     return t
 
 
-def build(force=False):
-    if not force and os.path.exists(OUT) and os.path.getmtime(OUT) >= newest_src():
-        return OUT
+def build(force=False, extra_flags=(), tag=""):
+    """tag / extra_flags: a variant build (e.g. -DARK_LAZY_FLUSH=1) next to the default one: libark355_emul_<tag>.so"""
+    out = OUT if not tag else OUT.replace(".so", "_%s.so" % tag)
+    if not force and os.path.exists(out) and os.path.getmtime(out) >= newest_src():
+        return out
     objs = []
-    flags = ["-O2", "-std=c++17", "-fPIC", "-DARK_EMUL", "-DARK_MSM_HEAVY_SPAN=2", "-DARK_MSM_HEAVY_GRID=3u", "-DARK_MSM_TWO_LEVEL_MIN=64u", "-I", HERE, "-I", CSRC, "-w"]
+    flags = list(extra_flags) + ["-O2", "-std=c++17", "-fPIC", "-DARK_EMUL", "-DARK_MSM_HEAVY_SPAN=2", "-DARK_MSM_HEAVY_GRID=3u", "-DARK_MSM_TWO_LEVEL_MIN=64u", "-I", HERE, "-I", CSRC, "-w"]
 
     def cc(src):
-        obj = os.path.join(HERE, os.path.basename(src) + ".emul.o")
+        obj = os.path.join(HERE, os.path.basename(src) + (".%s" % tag if tag else "") + ".emul.o")
         subprocess.check_call(["g++", "-x", "c++", *flags, "-c", src, "-o", obj])
         return obj
 
     with ThreadPoolExecutor(4) as ex:
         objs = list(ex.map(cc, SRCS))
-    subprocess.check_call(["g++", "-shared", "-Wl,-Bsymbolic", "-o", OUT, *objs, "-lpthread", "-lrt"])
-    return OUT
+    subprocess.check_call(["g++", "-shared", "-Wl,-Bsymbolic", "-o", out, *objs, "-lpthread", "-lrt"])
+    return out
 
 
 if __name__ == "__main__":
