@@ -399,6 +399,13 @@ def main():
     stream_map = None
     if not emul and rank == 0:
         try:
+            # GPU-side cost of a dispatch in an in-order stream on THIS box (ark355_diag_dispatch): the fingerprint that
+            # separates the boxes of the pool -- a few us on most, 50-90 us on some, where everything but the long
+            # accumulation kernels runs 2-3x slower
+            telemetry["dispatch_gap_before"] = g.lib.diag_dispatch(g.ctx)
+        except Exception as e:                                # noqa: BLE001
+            telemetry["dispatch_gap_before"] = {"error": str(e)[:160]}
+        try:
             mat = g.lib.diag_streams(ctxs)
             names = ["ctx%d" % i for i in range(len(ctxs))] + ["ctx0.sW", "ctx0.sS", "ctx0.sR"]
             pairs = [[names[i], names[j]] for i in range(len(names)) for j in range(i + 1, len(names))
@@ -693,6 +700,11 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args.curve)
         if sampler is not None:
             telemetry["host_at_end"] = GT.host_counters()
+        if not emul:
+            try:
+                telemetry["dispatch_gap_after"] = g.lib.diag_dispatch(g.ctx)
+            except Exception as e:                            # noqa: BLE001
+                telemetry["dispatch_gap_after"] = {"error": str(e)[:160]}
         print(json.dumps(out), flush=True)
     if sampler is not None:
         sampler.stop()

@@ -25,8 +25,8 @@
 #include <thread>
 #include <vector>
 
-#include "../../include/ark355.h"
-#include "../csrc/curve.cuh"
+#include "../include/ark355.h"
+#include "../snark_amd/csrc/curve.cuh"
 #include "relations.hpp"
 
 namespace ark355 {

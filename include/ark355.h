@@ -97,6 +97,11 @@ int32_t ark355_sched_reset(const ark355_ctx* ctx);
  * [i][j] = 1 when a kernel on stream j waited for a spinning kernel on stream i, 0 when it overtook it, -1 when the build
  * cannot measure it.  bench.py prints it; nothing on the proving path depends on it. */
 int32_t ark355_diag_streams(ark355_ctx** ctxs, uint32_t count, int8_t* serialised);
+/* Diagnostic: GPU-side cost of one dispatch in an in-order stream on this box: `launches` kernels that each spin for
+ * `spin_us`, back to back; *gap_us = elapsed / launches - spin_us (a few us on most boxes, 50-90 us on some: see
+ * DESIGN.md section 10).  *lanes (may be NULL) = the number of streams on pairwise different hardware queues the library
+ * found for one-stream proofs on this device (probed once, at the first ark355_ctx_create). */
+int32_t ark355_diag_dispatch(ark355_ctx* ctx, uint32_t launches, uint32_t spin_us, float* gap_us, uint32_t* lanes);
 
 /* Page-locked host memory for assignments / key vectors handed to the entry points below: H2D copies from pinned
  * memory run at PCIe rate (~55 GB/s) and truly asynchronously; pageable memory is staged by the runtime at a fraction

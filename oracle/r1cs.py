@@ -398,15 +398,6 @@ def circuit2(cs: ConstraintSystem, a, b, c):
     cs.enforce_r1cs_constraint(lambda: LC(p) + VAR_ONE, lambda: LC(p) + e, lambda: LC(p) + e)
 
 
-def circuit2_golden():
-    """gr1cs/tests/circuit2.rs:19-43."""
-    return {"R1CS": [
-        [[(1, 1)], [(1, 1)], [(1, 0)]],
-        [[(2, 2)], [(1, 1), (1, 2)], [(2, 1), (2, 2)]],
-        [[(1, 3)], [(1, 1), (1, 2)], [(2, 1), (2, 2)]],
-    ]}
-
-
 def circuit1(cs: ConstraintSystem, x, w):
     """gr1cs/tests/circuit1.rs:64-165; x = [x1..x5], w = [w1..w8]."""
     p = cs.p
@@ -433,16 +424,6 @@ def _chain(p, vs):
     for v in vs:
         lc = lc + v
     return lc
-
-
-def circuit1_golden():
-    """gr1cs/tests/circuit1.rs:28-61."""
-    return {
-        "R1CS": [[], [], []],
-        "poly-predicate-A": [[[(1, 1)]], [[(1, 2)]], [[(1, 3)]], [[(1, 9)]]],
-        "poly-predicate-B": [[[(1, 4)], [(1, 10)]], [[(1, 6)], [(1, 11)]], [[(1, 10)], [(1, 13)]]],
-        "poly-predicate-C": [[[(1, 7)], [(1, 9), (1, 10)]], [[(1, 8)], [(1, 13)]], [[(1, 11)], [(1, 5)]]],
-    }
 
 
 def dummy_circuit(cs: ConstraintSystem, a, b, num_variables, num_constraints):

@@ -126,32 +126,65 @@ impl Drop for Resident {
 }
 
 type Key = [u8; 32];
-fn registry() -> &'static Mutex<HashMap<Key, Arc<Resident>>> {
-    static R: OnceLock<Mutex<HashMap<Key, Arc<Resident>>>> = OnceLock::new();
-    R.get_or_init(|| Mutex::new(HashMap::new()))
+
+/// Resident keys of this process, most recently used last.  BOUNDED: a key's window tables are ~25x its size (15 GB at
+/// n = 2^20), so an unbounded map turns "one `pk.clone()` per request" into an out-of-memory condition.  When a load would
+/// exceed `max_resident_keys()` the least recently used entry is dropped from the registry; its HBM is released as soon
+/// as the last proof holding its `Arc` finishes.
+struct Registry {
+    entries: Vec<(Key, Arc<Resident>)>,
+}
+impl Registry {
+    fn get(&mut self, k: &Key) -> Option<Arc<Resident>> {
+        let i = self.entries.iter().position(|(key, _)| key == k)?;
+        let e = self.entries.remove(i);
+        let r = e.1.clone();
+        self.entries.push(e);
+        Some(r)
+    }
+    fn insert(&mut self, k: Key, r: Arc<Resident>) {
+        self.entries.retain(|(key, _)| key != &k);
+        while self.entries.len() >= max_resident_keys() {
+            self.entries.remove(0);
+        }
+        self.entries.push((k, r));
+    }
+    fn remove(&mut self, k: &Key) {
+        self.entries.retain(|(key, _)| key != k);
+    }
+}
+/// `ARK_MI355X_MAX_RESIDENT_KEYS` (default 4; at least 1).
+pub fn max_resident_keys() -> usize {
+    static N: OnceLock<usize> = OnceLock::new();
+    *N.get_or_init(|| std::env::var("ARK_MI355X_MAX_RESIDENT_KEYS").ok().and_then(|v| v.parse().ok()).filter(|n| *n >= 1).unwrap_or(4))
+}
+fn registry() -> &'static Mutex<Registry> {
+    static R: OnceLock<Mutex<Registry>> = OnceLock::new();
+    R.get_or_init(|| Mutex::new(Registry { entries: Vec::new() }))
 }
 
-/// Fingerprint of a proving key.  Covers the verifying key, the two prover-only points, the query lengths AND the
-/// query vectors themselves: 256 evenly spaced elements (plus the last one) of each of the five vectors, and the address
-/// of `a_query`'s buffer.  The verifying key alone is not enough: two circuits of the same shape set up from the same
-/// deterministic seed (the usual `test_rng` pattern) that differ only in witness constraints share vk, beta_g1, delta_g1
-/// and every length, and a lookup keyed on those would prove with the other circuit's key and matrices.  Hashing all
-/// ~600 MB of a 2^20 key on every `prove` is not an option, hence samples + buffer identity: a different key object
-/// misses (and is uploaded), the same object hits.
+/// Fingerprint of a proving key, by CONTENT only.  Covers the verifying key, the two prover-only points, the query lengths
+/// AND the query vectors themselves: 1024 evenly spaced elements (plus the last one) of each of the five vectors.  The
+/// verifying key alone is not enough: two circuits of the same shape set up from the same deterministic seed (the usual
+/// `test_rng` pattern) that differ only in witness constraints share vk, beta_g1, delta_g1 and every length, and a lookup
+/// keyed on those would prove with the other circuit's key and matrices -- but their QAP polynomials differ, and with
+/// them (almost) every element of the query vectors, so the samples separate them.  Hashing all ~600 MB of a 2^20 key on
+/// every `prove` is not an option.  The address of the key's buffers is deliberately NOT part of the fingerprint (round 3
+/// mixed it in): a clone or a move of the same key must hit the cache instead of uploading another 15 GB of tables, and a
+/// freed key whose buffer is reused by a same-shape key must not alias.
 pub fn fingerprint<E: Mi355xCurve>(pk: &ProvingKey<E>) -> Key {
     let mut bytes = Vec::new();
     pk.vk.serialize_compressed(&mut bytes).expect("vk serialization");
     pk.beta_g1.serialize_compressed(&mut bytes).expect("point serialization");
     pk.delta_g1.serialize_compressed(&mut bytes).expect("point serialization");
-    for n in [pk.a_query.len(), pk.b_g1_query.len(), pk.b_g2_query.len(), pk.h_query.len(), pk.l_query.len(), E::CURVE_ID as usize,
-              pk.a_query.as_ptr() as usize] {
+    for n in [pk.a_query.len(), pk.b_g1_query.len(), pk.b_g2_query.len(), pk.h_query.len(), pk.l_query.len(), E::CURVE_ID as usize] {
         bytes.extend_from_slice(&(n as u64).to_le_bytes());
     }
     fn sample<T: CanonicalSerialize>(v: &[T], bytes: &mut Vec<u8>) {
         if v.is_empty() {
             return;
         }
-        let step = core::cmp::max(1, v.len() / 256);
+        let step = core::cmp::max(1, v.len() / 1024);
         let mut i = 0;
         while i < v.len() {
             v[i].serialize_uncompressed(&mut *bytes).expect("point serialization");
@@ -178,7 +211,7 @@ pub fn fingerprint<E: Mi355xCurve>(pk: &ProvingKey<E>) -> Key {
 }
 
 pub fn lookup<E: Mi355xCurve>(pk: &ProvingKey<E>) -> Option<Arc<Resident>> {
-    registry().lock().unwrap().get(&fingerprint(pk)).cloned()
+    registry().lock().unwrap().get(&fingerprint(pk))
 }
 
 /// Release the HBM of a key (window tables: ~15 GB at n = 2^20) once no proof uses it any more.

@@ -2,7 +2,7 @@
 //! threads -- each with its own `ark355_ctx`, i.e. its own streams and gigabytes of scratch that are allocated once --
 //! and proves assignments handed to it in page-locked buffers (`ark355_host_alloc`), while the caller's synthesis
 //! threads keep producing the next ones.  Same arrangement as `Groth16::prove_pipelined` of the C++ mirror
-//! (snark_amd/host/snark.hpp), which measured 38 M constraints/s end to end at 2^20 constraints against 43 M/s for
+//! (host_mirror/snark.hpp), which measured 38 M constraints/s end to end at 2^20 constraints against 43 M/s for
 //! assignments synthesised up front.
 //!
 //! The reference's parallel unit is one OS thread per constraint system (`ConstraintSystemRef` is `Rc<RefCell<..>>`,

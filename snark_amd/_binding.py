@@ -48,7 +48,7 @@ SYMBOLS = [
     "ark355_pk_table_info",
     "ark355_points_decode", "ark355_points_encode", "ark355_proof_to_bytes", "ark355_proof_from_bytes",
     "ark355_setup_scalars", "ark355_verify_batch",
-    "ark355_ctx_set_policy", "ark355_ctx_get_policy", "ark355_sched_info", "ark355_sched_reset", "ark355_diag_streams",
+    "ark355_ctx_set_policy", "ark355_ctx_get_policy", "ark355_sched_info", "ark355_sched_reset", "ark355_diag_streams", "ark355_diag_dispatch",
 ]
 
 SCHED_NAMES = {-1: "auto", 0: "one_stream", 1: "pipeline", 2: "pipeline_sync", 3: "one_stream_spin"}
@@ -175,6 +175,7 @@ class Lib:
         d.ark355_sched_info.argtypes = [vp, vp, i32, P(SchedReport)]
         d.ark355_sched_reset.argtypes = [vp]
         d.ark355_diag_streams.argtypes = [vp, u32, vp]
+        d.ark355_diag_dispatch.argtypes = [vp, u32, u32, P(C.c_float), P(u32)]
         d.ark355_get_timings.argtypes = [vp, P(Timings)]
         d.ark355_get_kernel_stats.argtypes = [vp, P(C.c_float), P(u64), P(u64)]
         for name in SYMBOLS:
@@ -221,6 +222,11 @@ class Lib:
         out = (C.c_int8 * (n * n))()
         self.check(ctxs[0], self.dll.ark355_diag_streams(arr, len(ctxs), out))
         return [[int(out[i * n + j]) for j in range(n)] for i in range(n)]
+
+    def diag_dispatch(self, ctx, launches=200, spin_us=20):
+        gap, lanes = C.c_float(0), C.c_uint32(0)
+        self.check(ctx, self.dll.ark355_diag_dispatch(ctx, launches, spin_us, C.byref(gap), C.byref(lanes)))
+        return {"gap_us": round(float(gap.value), 2), "launches": launches, "spin_us": spin_us, "lanes": int(lanes.value)}
 
     def sched_reset(self, ctx):
         self.check(ctx, self.dll.ark355_sched_reset(ctx))

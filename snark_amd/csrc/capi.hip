@@ -5,7 +5,6 @@
 #include <new>
 #include <thread>
 #include "api_impl.cuh"
-#include "diag_impl.cuh"
 
 namespace ark355 {
 extern template struct Api<BlsCurve>;
@@ -110,6 +109,16 @@ int32_t ark355_ctx_create(int32_t device_id, ark355_ctx** out) {
     delete ctx;
     return ARK355_EHIP;
   }
+  // streams for one-stream proofs, probed (once per device, now: the device is idle) to sit on different hardware queues
+  try {
+    uint32_t want = 4;
+    if (const char* e = getenv("GPU_MAX_HW_QUEUES")) {
+      const int v = atoi(e);
+      if (v >= 1 && v <= 16) want = (uint32_t)v;
+    }
+    LanePool::of(device_id).build(want);
+  } catch (...) {
+  }
   *out = ctx;
   return ARK355_OK;
 }
@@ -207,6 +216,13 @@ int32_t ark355_diag_streams(ark355_ctx** ctxs, uint32_t count, int8_t* serialise
     for (size_t i = 0; i < n; i++)
       for (size_t j = 0; j < n; j++)
         serialised[i * n + j] = (int8_t)(i == j ? 1 : diag_streams_serialised(st[i], st[j]));
+  });
+}
+int32_t ark355_diag_dispatch(ark355_ctx* ctx, uint32_t launches, uint32_t spin_us, float* gap_us, uint32_t* lanes) {
+  if (!ctx || !gap_us || launches == 0 || launches > 100000 || spin_us > 100000) return ARK355_EINVAL;
+  return guarded(ctx, [&] {
+    *gap_us = diag_dispatch_gap_us(ctx->stream, launches, spin_us);
+    if (lanes) *lanes = (uint32_t)LanePool::of(ctx->device).size();
   });
 }
 int32_t ark355_sched_reset(const ark355_ctx* ctx) {

@@ -55,4 +55,94 @@ static inline int diag_streams_serialised(hipStream_t a, hipStream_t b, uint32_t
 #endif
 }
 
+
+// GPU-side cost of one dispatch in an in-order stream: `launches` kernels that each spin for `spin_us`, back to back on
+// `st`; (elapsed between the first and the last event) / launches - spin_us.  A few microseconds on most boxes of the
+// pool this was developed on, 50-90 us on some (round 4: the same library proves 30 % slower there, with every kernel as
+// fast as elsewhere) -- the one-number fingerprint bench.py prints so that a slow BOX can be told from a slow TREE.
+static inline float diag_dispatch_gap_us(hipStream_t st, uint32_t launches = 200, uint32_t spin_us = 20) {
+#if defined(ARK_EMUL)
+  (void)st; (void)launches; (void)spin_us;
+  return -1.f;
+#else
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  ARK_CHECK_HIP(hipEventCreate(&e0));
+  ARK_CHECK_HIP(hipEventCreate(&e1));
+  float ms = 0.f;
+  try {
+    for (int warm = 0; warm < 2; warm++) {
+      ARK_CHECK_HIP(hipEventRecord(e0, st));
+      for (uint32_t i = 0; i < launches; i++) {
+        ARK_LAUNCH(diag_spin_kernel, dim3(1), dim3(64), 0, st, (uint64_t)spin_us * 100ull);
+        ARK_CHECK_LAUNCH();
+      }
+      ARK_CHECK_HIP(hipEventRecord(e1, st));
+      ARK_CHECK_HIP(hipEventSynchronize(e1));
+      ARK_CHECK_HIP(hipEventElapsedTime(&ms, e0, e1));
+    }
+  } catch (...) {
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    throw;
+  }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  return ms * 1000.f / (float)launches - (float)spin_us;
+#endif
+}
+
+// Streams for one-stream proofs ("lanes"), one set per device: created back to back at the first request and then
+// PROBED so that the set handed out sits on pairwise different hardware queues (diag_streams_serialised).  Round 4 found
+// two of bench.py's four context streams on one queue on a fresh box -- two of the four proofs "in flight" took turns --
+// because the runtime assigns queues by creation order across everything the process creates (torch's streams, the null
+// stream, ...).  Contexts take lanes round-robin; more contexts than lanes share (that is what a hardware queue would
+// make them do anyway).
+struct LanePool {
+  std::mutex mu;
+  std::vector<hipStream_t> lanes;        // pairwise on different hardware queues (as far as that could be established)
+  std::vector<hipStream_t> parked;       // created, found to collide, kept alive so that the queue stays "taken"
+  uint32_t next = 0;
+  bool built = false;
+  static LanePool& of(int device) {
+    static LanePool p[64];
+    return p[(unsigned)device & 63u];
+  }
+  // call with the device idle (ark355_ctx_create of the first context)
+  void build(uint32_t want = 4, uint32_t max_create = 12) {
+    std::lock_guard<std::mutex> lk(mu);
+    if (built) return;
+    built = true;
+#if defined(ARK_EMUL)
+    (void)want; (void)max_create;
+#else
+    for (uint32_t made = 0; made < max_create && lanes.size() < want; made++) {
+      hipStream_t st = nullptr;
+      if (hipStreamCreate(&st) != hipSuccess) break;
+      bool clash = false;
+      try {
+        for (hipStream_t other : lanes) {
+          if (diag_streams_serialised(other, st, 400) == 1 || diag_streams_serialised(st, other, 400) == 1) {
+            clash = true;
+            break;
+          }
+        }
+      } catch (...) {
+        clash = false;       // the probe failed: take the stream as it is
+      }
+      (clash ? parked : lanes).push_back(st);
+    }
+#endif
+  }
+  // nullptr: no pool on this build / device (the caller falls back to the context's own stream)
+  hipStream_t acquire() {
+    std::lock_guard<std::mutex> lk(mu);
+    if (lanes.empty()) return nullptr;
+    return lanes[next++ % lanes.size()];
+  }
+  size_t size() {
+    std::lock_guard<std::mutex> lk(mu);
+    return lanes.size();
+  }
+};
+
 }  // namespace ark355

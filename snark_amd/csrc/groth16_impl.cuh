@@ -27,6 +27,7 @@
 #include "msm_impl.cuh"
 #include "witness_impl.cuh"
 #include "comm_impl.cuh"
+#include "diag_impl.cuh"
 #include <thread>
 
 namespace ark355 {
@@ -218,6 +219,8 @@ struct ProverScratch {
   // all three feeder streams of one context share ONE in-order hardware queue (a reduction kernel waiting for its
   // accumulation then blocks the NTT passes queued behind it): the box-to-box spread of the pipelined schedule.
   hipStream_t sW = nullptr, sS = nullptr, sR = nullptr;
+  hipStream_t lane = nullptr;       // this context's stream for one-stream proofs (LanePool: pairwise different hardware queues)
+  bool lane_asked = false;
   uint64_t warm_shape = 0;          // shape of the last proof on this context (its scratch and tables exist)
   void ensure_streams(bool prio) {
     if (sW) return;
@@ -568,6 +571,14 @@ static void prove_run(ark355_ctx* ctx, ProverScratch& sc, const PkDev& pk, const
   // is dispatched before the next round of accumulation workgroups, which keeps an accumulation queued at all times.
   // Policy STREAM_PRIO=0 turns it off (A/B).
   if (!one_stream) sc.ensure_streams(pol.stream_prio != 0);
+  if (one_stream) {
+    // one-stream proofs run on a "lane": a stream of the device's pool, probed at start-up to sit on its own hardware queue
+    if (!sc.lane_asked) {
+      sc.lane = LanePool::of(ctx->device).acquire();
+      sc.lane_asked = true;
+    }
+    if (sc.lane) sM = sc.lane;
+  }
   hipStream_t sW = one_stream ? sM : sc.sW, sS = one_stream ? sM : sc.sS, sA = sM, sR = one_stream ? sM : sc.sR;
   const uint64_t m = pk.m, ell = pk.ell;
   if (cm && cm->world > 1) {

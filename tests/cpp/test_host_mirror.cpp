@@ -10,7 +10,7 @@
 #include <chrono>
 #include <string>
 
-#include "../../snark_amd/host/snark.hpp"
+#include "../../host_mirror/snark.hpp"
 
 using namespace ark_relations;
 using namespace ark_relations::gr1cs;

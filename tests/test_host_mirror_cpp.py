@@ -16,7 +16,7 @@ def exe():
     from snark_amd import build
     build.build(verbose=False)
     src = os.path.join(CPP_DIR, "test_host_mirror.cpp")
-    deps = [src] + [os.path.join(ROOT, "snark_amd", "host", f) for f in ("relations.hpp", "snark.hpp")]
+    deps = [src] + [os.path.join(ROOT, "host_mirror", f) for f in ("relations.hpp", "snark.hpp")]
     # rebuild whenever the sources differ from what the binary was built from (content hash, not mtime: a stale binary
     # from another checkout must never run in place of the current sources)
     import hashlib

@@ -1,9 +1,20 @@
 """The oracle's restatement of ark_relations::gr1cs against the reference's OWN golden vectors
 (the only KATs the reference holds for this path: SURVEY.md 8c)."""
+import json
+import os
+
 from oracle import r1cs as R, synthetic as S
 from oracle.fields import BLS12_381
 
 P = BLS12_381.r
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def golden(name):
+    """tests/golden/*.json (written by tests/golden/make_r1cs_golden.py from the reference's test sources):
+    {label: [matrix]} with rows of (coefficient, column) pairs"""
+    raw = json.load(open(os.path.join(GOLDEN, name)))
+    return {label: [[[(c, col) for c, col in row] for row in mat] for mat in mats] for label, mats in raw.items()}
 
 
 def test_circuit2_matrices_golden():
@@ -11,14 +22,14 @@ def test_circuit2_matrices_golden():
     cs = R.ConstraintSystem(P)
     R.circuit2(cs, 1, 1, 2)
     cs.finalize()
-    assert cs.to_matrices() == R.circuit2_golden()
+    assert cs.to_matrices() == golden("circuit2_matrices.json")
 
 
 def test_circuit1_matrices_golden():
     # tests/mod.rs:78-103 vs circuit1.rs:28-61 (before finalize)
     cs = R.ConstraintSystem(P)
     R.circuit1(cs, [0] * 5, [0] * 8)
-    assert cs.to_matrices() == R.circuit1_golden()
+    assert cs.to_matrices() == golden("circuit1_matrices.json")
 
 
 def test_circuit1_sat_and_non_sat():
