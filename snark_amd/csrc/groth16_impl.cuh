@@ -641,20 +641,28 @@ static void prove_run(ark355_ctx* ctx, ProverScratch& sc, const PkDev& pk, const
     void* d_h = witness_map_run<Curve>(ctx, r1, sc.zx.p, sc.ws, sW);
     ARK_CHECK_HIP(hipEventRecord(ev[E_H], sW));
 
-    // sorts
+    // sorts.  Everything the two sorts and the five bucket sets need cleared is planned first and cleared by ONE fill
+    // dispatch (FillBatch, msm_impl.cuh) at the head of the sort stream: the scratch belongs to this context and the
+    // previous proof on it has drained.
+    {
+      FillBatch fb(sS);
+      msm_sort_plan<Fr>(ctx, sc.sortZ, pk.z_cnt, sS, &pk.a_ext, &fb);
+      // bucket sets are sized and cleared here as well (msm_prepare_phase)
+      // (a batch-affine MSM sizes its bucket set later, for the nodes its tree levels leave over)
+      if (!pk.b2_ext.batch_affine) msm_prepare_phase<Fq2>(pol, sc.sortZ, sc.bkB2, sS, pk.b2_ext.limb28, &fb);
+      if (!pk.a_ext.batch_affine) msm_prepare_phase<Fq>(pol, sc.sortZ, sc.bkA, sS, pk.a_ext.limb28, &fb);
+      if (!pk.b1_ext.batch_affine) msm_prepare_phase<Fq>(pol, sc.sortZ, sc.bkB1, sS, pk.b1_ext.limb28, &fb);
+      if (!pk.l_ext.batch_affine) msm_prepare_phase<Fq>(pol, sc.sortZ, sc.bkL, sS, pk.l_ext.limb28, &fb);
+      msm_sort_plan<Fr>(ctx, sc.sortH, pk.h_cnt, sS, &pk.h_query, &fb);
+      if (!pk.h_query.batch_affine) msm_prepare_phase<Fq>(pol, sc.sortH, sc.bkH, sS, pk.h_query.limb28, &fb);
+      fb.flush();
+    }
     ARK_CHECK_HIP(hipStreamWaitEvent(sS, ev[E_Z], 0));
-    msm_sort<Fr>(ctx, sc.sortZ, (const uint8_t*)sc.zx.p + pk.z_lo * sizeof(Fr), pk.z_cnt, 1, sS, &pk.a_ext);
-    // bucket sets are sized and cleared here, behind the sort they belong to (msm_prepare_phase)
-    // (a batch-affine MSM sizes its bucket set later, for the nodes its tree levels leave over)
-    if (!pk.b2_ext.batch_affine) msm_prepare_phase<Fq2>(pol, sc.sortZ, sc.bkB2, sS, pk.b2_ext.limb28);
-    if (!pk.a_ext.batch_affine) msm_prepare_phase<Fq>(pol, sc.sortZ, sc.bkA, sS, pk.a_ext.limb28);
-    if (!pk.b1_ext.batch_affine) msm_prepare_phase<Fq>(pol, sc.sortZ, sc.bkB1, sS, pk.b1_ext.limb28);
-    if (!pk.l_ext.batch_affine) msm_prepare_phase<Fq>(pol, sc.sortZ, sc.bkL, sS, pk.l_ext.limb28);
+    msm_sort_run<Fr>(ctx, sc.sortZ, (const uint8_t*)sc.zx.p + pk.z_lo * sizeof(Fr), pk.z_cnt, 1, sS, &pk.a_ext);
     ARK_CHECK_HIP(hipEventRecord(ev[E_SORT0], sS));
     ARK_CHECK_HIP(hipEventRecord(ev[E_SORT1], sS));     // (L' shares the sort of zx)
     ARK_CHECK_HIP(hipStreamWaitEvent(sS, ev[E_H], 0));
-    msm_sort<Fr>(ctx, sc.sortH, (const uint8_t*)d_h + pk.h_lo * sizeof(Fr), pk.h_cnt, 1, sS, &pk.h_query);
-    if (!pk.h_query.batch_affine) msm_prepare_phase<Fq>(pol, sc.sortH, sc.bkH, sS, pk.h_query.limb28);
+    msm_sort_run<Fr>(ctx, sc.sortH, (const uint8_t*)d_h + pk.h_lo * sizeof(Fr), pk.h_cnt, 1, sS, &pk.h_query);
     ARK_CHECK_HIP(hipEventRecord(ev[E_SORT2], sS));
 
     // accumulations (A, B1, B2 share the sort of zx) and, per MSM, its reduction on sR

@@ -1378,6 +1378,73 @@ static void precomp_build(const TunePolicy& pol, PrecompTable& t, const void* d_
   ARK_CHECK_HIP(hipStreamSynchronize(stream));     // staging buffers are freed on return
 }
 
+// ---- one fill dispatch per proof ----------------------------------------------------------------------------------------
+// A proof used to queue 31 hipMemsetAsync calls (sort counters, bucket sets, head / tail keys, heavy-bucket counters): 31
+// dispatches of ~5 us of work each.  Kernel time was never the issue -- the DISPATCHES are: on some boxes of the pool an
+// in-order queue pays 50-90 us per dispatch (ark355_diag_dispatch), i.e. 2-3 ms per proof for clearing 50 MB.  A FillBatch
+// collects the ranges while the proof's scratch is planned and clears them with ONE kernel.
+struct FillRange {
+  void* p;
+  uint32_t n16;       // whole 16-byte units
+  uint32_t rem;       // 0..3 trailing 32-bit words
+  uint32_t value;     // the byte value replicated into a word
+  uint32_t pad;
+};
+constexpr uint32_t FILL_MAX = 28;
+struct FillList {
+  FillRange r[FILL_MAX];
+  uint32_t count;
+};
+static __global__ void __launch_bounds__(256) multi_fill_kernel(FillList L) {
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint32_t k = 0; k < L.count; k++) {
+    const FillRange r = L.r[k];
+    const uint4 v = make_uint4(r.value, r.value, r.value, r.value);
+    uint4* d = reinterpret_cast<uint4*>(r.p);
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < r.n16; i += stride) d[i] = v;
+    if (blockIdx.x == 0 && threadIdx.x < r.rem) reinterpret_cast<uint32_t*>(r.p)[4ull * r.n16 + threadIdx.x] = r.value;
+  }
+}
+struct FillBatch {
+  FillList list;
+  hipStream_t stream;
+  explicit FillBatch(hipStream_t st) : stream(st) { list.count = 0; }
+  // bytes must be a multiple of 4 and p 16-byte aligned (hipMalloc'ed scratch); anything else is cleared the old way
+  void add(void* p, size_t bytes, uint8_t byte_value) {
+    if (bytes == 0) return;
+    if ((bytes & 3) || (reinterpret_cast<uintptr_t>(p) & 15) || (bytes >> 4) > 0xFFFFFFFFull) {
+      ARK_CHECK_HIP(hipMemsetAsync(p, byte_value, bytes, stream));
+      return;
+    }
+    if (list.count == FILL_MAX) flush();
+    FillRange& r = list.r[list.count++];
+    r.p = p;
+    r.n16 = (uint32_t)(bytes >> 4);
+    r.rem = (uint32_t)((bytes & 15) >> 2);
+    r.value = 0x01010101u * byte_value;
+    r.pad = 0;
+  }
+  void flush() {
+    if (list.count == 0) return;
+    uint64_t units = 0;
+    for (uint32_t k = 0; k < list.count; k++) units += list.r[k].n16;
+#if defined(ARK_EMUL)
+    const uint32_t grid = 1;               // the emulator runs lanes one after another
+#else
+    uint64_t g = (units + 256ull * 8 - 1) / (256ull * 8);
+    const uint32_t grid = (uint32_t)(g < 1 ? 1 : (g > 4096 ? 4096 : g));
+#endif
+    ARK_LAUNCH(multi_fill_kernel, dim3(grid), dim3(256), 0, stream, list);
+    ARK_CHECK_LAUNCH();
+    list.count = 0;
+  }
+};
+// clear through the batch when there is one, directly otherwise
+static inline void fill_bytes(FillBatch* fb, void* p, uint8_t v, size_t bytes, hipStream_t stream) {
+  if (fb) fb->add(p, bytes, v);
+  else ARK_CHECK_HIP(hipMemsetAsync(p, v, bytes, stream));
+}
+
 // ---- host driver ---------------------------------------------------------------------------------------------
 // Scratch for one MSM "sort" (shared by several accumulations over the same scalars).
 struct MsmSort {
@@ -1385,15 +1452,17 @@ struct MsmSort {
   DevBuf keys, vals, counts, offsets, cursor, sorted_keys, sorted_vals, total, hist, hist_scanned;
 };
 
+// Plan one sort (window size, buffer sizes) and clear its counters -- through `fb` when the caller batches the fills of
+// a whole proof (prove_run), on `stream` otherwise.  msm_sort_run queues the kernels.
 template <class Fr>
-static void msm_sort(ark355_ctx* ctx, MsmSort& s, const void* d_scalars, uint64_t n, int mont, hipStream_t stream,
-                     const PrecompTable* tab = nullptr) {
+static void msm_sort_plan(ark355_ctx* ctx, MsmSort& s, uint64_t n, hipStream_t stream, const PrecompTable* tab = nullptr,
+                          FillBatch* fb = nullptr) {
+  (void)ctx;
   ARK_REQUIRE(n < (1ull << 31), ARK355_EINVAL, "MSM size must be < 2^31");
   const bool precomp = tab != nullptr;
   if (tab) ARK_REQUIRE(n <= tab->n, ARK355_EINVAL, "more scalars than table rows");
   // with window tables the window size is the one the tables were built for
   s.plan = msm_plan(n, Fr::Params::BITS, precomp, tab ? (int)tab->plan.c : 0, tab ? tab->plan.wstride : 0);
-  const uint32_t stride = tab ? (uint32_t)tab->n : 0;
   const MsmPlan& p = s.plan;
   const uint64_t entries = (uint64_t)p.windows * n;
   ARK_REQUIRE(entries < (1ull << 31), ARK355_EINVAL, "MSM entry count must be < 2^31");
@@ -1406,13 +1475,23 @@ static void msm_sort(ark355_ctx* ctx, MsmSort& s, const void* d_scalars, uint64_
   s.cursor.ensure((size_t)p.total_buckets * 4);
   s.total.ensure(16);
   if (n == 0) {
-    ARK_CHECK_HIP(hipMemsetAsync(s.total.p, 0, 4, stream));
-    ARK_CHECK_HIP(hipMemsetAsync(s.counts.p, 0, (size_t)p.total_buckets * 4, stream));
-    ARK_CHECK_HIP(hipMemsetAsync(s.offsets.p, 0, (size_t)p.total_buckets * 4, stream));
+    fill_bytes(fb, s.total.p, 0, 4, stream);
+    fill_bytes(fb, s.counts.p, 0, (size_t)p.total_buckets * 4, stream);
+    fill_bytes(fb, s.offsets.p, 0, (size_t)p.total_buckets * 4, stream);
     return;
   }
-  ARK_CHECK_HIP(hipMemsetAsync(s.counts.p, 0, (size_t)p.total_buckets * 4, stream));
-  ARK_CHECK_HIP(hipMemsetAsync(s.cursor.p, 0, (size_t)p.total_buckets * 4, stream));
+  fill_bytes(fb, s.counts.p, 0, (size_t)p.total_buckets * 4, stream);
+  fill_bytes(fb, s.cursor.p, 0, (size_t)p.total_buckets * 4, stream);
+}
+
+template <class Fr>
+static void msm_sort_run(ark355_ctx* ctx, MsmSort& s, const void* d_scalars, uint64_t n, int mont, hipStream_t stream,
+                         const PrecompTable* tab = nullptr) {
+  const MsmPlan& p = s.plan;
+  ARK_REQUIRE(p.n == n, ARK355_EINVAL, "sort was planned for another length");
+  if (n == 0) return;
+  const uint32_t stride = tab ? (uint32_t)tab->n : 0;
+  const uint64_t entries = (uint64_t)p.windows * n;
   const uint32_t bins = (p.total_buckets + SORT_LO - 1) / SORT_LO;
   // policy SORT_LEGACY=1 (env ARK355_SORT=legacy): the one-pass counting sort (A/B switch; also taken when level 1
   // would not fit LDS)
@@ -1465,6 +1544,13 @@ static void msm_sort(ark355_ctx* ctx, MsmSort& s, const void* d_scalars, uint64_
   ARK_CHECK_LAUNCH();
 }
 
+template <class Fr>
+static void msm_sort(ark355_ctx* ctx, MsmSort& s, const void* d_scalars, uint64_t n, int mont, hipStream_t stream,
+                     const PrecompTable* tab = nullptr) {
+  msm_sort_plan<Fr>(ctx, s, n, stream, tab);
+  msm_sort_run<Fr>(ctx, s, d_scalars, n, mont, stream, tab);
+}
+
 // Scratch for the bucket phase of one group type.
 struct MsmBuckets {
   DevBuf buckets, head, tail, head_key, tail_key, partials, heavy_count, heavy_list, lvl_t, lvl_w;
@@ -1472,6 +1558,7 @@ struct MsmBuckets {
   uint32_t seg_len = 32, segs = 0;      // of the last accumulation over this bucket set (G1 and G2 differ)
   bool prepared = false;                // msm_prepare_phase ran for the coming accumulation
   bool lazy28 = false;                  // that accumulation leaves its runs in raw28; msm_reduce_phase converts them
+  bool heavy_cleared = false;           // msm_prepare_phase already cleared heavy_count for the coming merge
 };
 
 template <class F>
@@ -1492,9 +1579,11 @@ struct msm_slot28<Fp2<Q>> {
 // consecutive accumulations (31 fills per proof, 2.5 ms of stream time with four proofs in flight).
 // lazy28: the accumulation will run on a radix-2^28 window table.
 template <class F>
-static void msm_prepare_phase(const TunePolicy& pol, const MsmSort& s, MsmBuckets& b, hipStream_t stream, bool lazy28 = false) {
+static void msm_prepare_phase(const TunePolicy& pol, const MsmSort& s, MsmBuckets& b, hipStream_t stream, bool lazy28 = false,
+                              FillBatch* fb = nullptr) {
   const MsmPlan& p = s.plan;
   b.prepared = true;
+  b.heavy_cleared = false;
   b.lazy28 = lazy28 && ARK_LAZY_FLUSH;
   if (p.n == 0) return;
   const uint64_t entries = (uint64_t)p.windows * p.n;
@@ -1511,12 +1600,16 @@ static void msm_prepare_phase(const TunePolicy& pol, const MsmSort& s, MsmBucket
     using S = msm_slot28<F>;
     const size_t slot = (size_t)S::COORDS * Fp28<typename S::P>::N * 4;
     b.raw28.ensure(((size_t)p.total_buckets + 2 * (size_t)segs) * slot);
-    ARK_CHECK_HIP(hipMemsetAsync(b.raw28.p, 0, (size_t)p.total_buckets * slot, stream));
+    fill_bytes(fb, b.raw28.p, 0, (size_t)p.total_buckets * slot, stream);
   } else {
-    ARK_CHECK_HIP(hipMemsetAsync(b.buckets.p, 0, (size_t)p.total_buckets * sizeof(XYZZ<F>), stream));
+    fill_bytes(fb, b.buckets.p, 0, (size_t)p.total_buckets * sizeof(XYZZ<F>), stream);
   }
-  ARK_CHECK_HIP(hipMemsetAsync(b.head_key.p, 0xFF, (size_t)segs * 4, stream));
-  ARK_CHECK_HIP(hipMemsetAsync(b.tail_key.p, 0xFF, (size_t)segs * 4, stream));
+  fill_bytes(fb, b.head_key.p, 0xFF, (size_t)segs * 4, stream);
+  fill_bytes(fb, b.tail_key.p, 0xFF, (size_t)segs * 4, stream);
+  // the heavy-bucket counter of the merge that follows the accumulation (msm_reduce_phase clears it itself otherwise)
+  b.heavy_count.ensure(16);
+  fill_bytes(fb, b.heavy_count.p, 0, 4, stream);
+  b.heavy_cleared = true;
 }
 
 // destination arrays of the 28-bit accumulation kernels: which = 0 buckets, 1 head, 2 tail
@@ -1634,7 +1727,8 @@ static void msm_reduce_phase(ark355_ctx* ctx, const MsmSort& s, MsmBuckets& b, X
     const uint32_t heavy_span = (2 * avg_span > MSM_HEAVY_SPAN) ? 2 * avg_span : MSM_HEAVY_SPAN;
     b.heavy_count.ensure(16);
     b.heavy_list.ensure((size_t)max_heavy * 4);
-    ARK_CHECK_HIP(hipMemsetAsync(b.heavy_count.p, 0, 4, stream));
+    if (!b.heavy_cleared) ARK_CHECK_HIP(hipMemsetAsync(b.heavy_count.p, 0, 4, stream));
+    b.heavy_cleared = false;
     if constexpr (is_fp2<F>::value) {
       if (msm_g2_pair_tails(ctx)) {
         using P = typename F::Base::Params;
