@@ -87,19 +87,31 @@ static inline void wait_event_polite(hipEvent_t ev, bool spin, double expect_ms 
 // Rounds 1-3 picked the schedule from thresholds fitted on two or three boxes (one stream when other proofs are in
 // flight, the pipeline for a proof alone; epilogue synchronises for everything but large BLS12-381 proofs) -- and the
 // round-3 driver box ran 30-40 % slower than any box those thresholds were fitted on, in exactly the phases where
-// streams overlap.  So the library measures instead: per (device, proof shape, alone | in flight) class the first warm
-// proofs run the candidate schedules in turn (policy SCHED_EXPLORE samples each, default 3), their wall time inside
-// prove_run is recorded, and the class then keeps the fastest.  With k proofs in flight and threads that start the next
-// proof as soon as one returns, throughput = k / mean latency, so the proof's own wall time is the right objective in
-// both classes.  A context's first proof of a shape (allocations, table builds) is neither explored nor recorded.  The
-// spinning wait is only taken when it beats the best polite candidate by 10 %: it costs a host core per proof in flight.
+// streams overlap.  So the library measures, per (device, proof shape, alone | in flight) class:
+//   * a proof ALONE: the first warm proofs run the candidate schedules in turn (policy SCHED_EXPLORE samples each,
+//     default 3) and the class keeps the one with the smallest mean wall time inside prove_run -- nothing else runs, so a
+//     proof's own latency is the objective;
+//   * proofs IN FLIGHT: latency of one proof is the WRONG objective while the candidates are mixed (round-4 run A: a
+//     pipeline proof, whose feeder streams have the higher priority, finished sooner at the expense of the one-stream
+//     proofs running beside it; the tuner latched the schedule that the bench's own throughput A/B then showed to be 4 %
+//     slower).  The class therefore explores in PHASES: every proof started during a phase runs the phase's candidate, the
+//     first SKIP completions of a phase are ignored (proofs of the previous phase are still draining), and the phase's
+//     score is the time per completion over the next 4 * SCHED_EXPLORE + 4 completions -- throughput, measured the way
+//     bench.py measures it.  The static default (one stream) is only abandoned for a candidate that beats it by 3 %.
+// A context's first proof of a shape (allocations, table builds) is neither explored nor recorded.  The spinning wait is
+// no candidate of the automatic choice (it costs a host core per proof in flight); policy SCHED = 3 forces it.
 struct SchedTuner {
+  using Clock = std::chrono::steady_clock;
+  static constexpr uint32_t PHASE_SKIP = 8;
   struct Entry {
     int latched = -1;
     uint32_t started[SCHED_COUNT] = {}, done[SCHED_COUNT] = {};
-    double sum_ms[SCHED_COUNT] = {};
+    double sum_ms[SCHED_COUNT] = {};      // alone: summed wall time; in flight: span of the phase's scored completions
     uint32_t ncand = 0;
     int cand[SCHED_COUNT] = {};
+    // in-flight classes
+    uint32_t phase = 0, phase_done = 0;
+    Clock::time_point t_mark;
   };
   std::mutex mu;
   std::map<uint64_t, Entry> entries;
@@ -108,6 +120,7 @@ struct SchedTuner {
     return t[(unsigned)device & 63u];
   }
   static uint64_t key(uint64_t shape, bool concurrent) { return (shape << 1) | (concurrent ? 1u : 0u); }
+  static uint32_t phase_len(int explore_n) { return 4u * (uint32_t)explore_n + 4u; }
   // the schedule for a proof of class `k`; *explore = this proof is a sample and must be reported
   int pick(uint64_t k, bool concurrent, int explore_n, int fallback, bool* explore) {
     *explore = false;
@@ -117,12 +130,18 @@ struct SchedTuner {
     if (e.latched >= 0) return e.latched;
     if (e.ncand == 0) {
       if (concurrent) {
-        const int c[] = {SCHED_ONE_STREAM, SCHED_PIPELINE, SCHED_PIPELINE_SYNC, SCHED_ONE_STREAM_SPIN};
+        const int c[] = {SCHED_ONE_STREAM, SCHED_PIPELINE, SCHED_PIPELINE_SYNC};
         for (int v : c) e.cand[e.ncand++] = v;
       } else {
         const int c[] = {SCHED_PIPELINE, SCHED_PIPELINE_SYNC, SCHED_ONE_STREAM};
         for (int v : c) e.cand[e.ncand++] = v;
       }
+    }
+    if (concurrent) {
+      const int v = e.cand[e.phase < e.ncand ? e.phase : 0];
+      e.started[v]++;
+      *explore = true;
+      return v;
     }
     int best = -1;
     for (uint32_t i = 0; i < e.ncand; i++) {
@@ -135,30 +154,51 @@ struct SchedTuner {
     *explore = true;
     return best;
   }
-  void report(uint64_t k, int variant, double ms, int explore_n) {
+  void report(uint64_t k, bool concurrent, int variant, double ms, int explore_n, int fallback) {
     std::lock_guard<std::mutex> lk(mu);
     Entry& e = entries[k];
-    if (e.latched >= 0 || variant < 0 || variant >= SCHED_COUNT) return;
+    if (e.latched >= 0 || variant < 0 || variant >= SCHED_COUNT || e.ncand == 0) return;
+    if (concurrent) {
+      if (e.phase >= e.ncand || variant != e.cand[e.phase]) return;       // a straggler of an earlier phase
+      const uint32_t len = phase_len(explore_n);
+      e.phase_done++;
+      if (e.phase_done == PHASE_SKIP) e.t_mark = Clock::now();
+      if (e.phase_done < PHASE_SKIP + len) return;
+      e.sum_ms[variant] = std::chrono::duration<double, std::milli>(Clock::now() - e.t_mark).count();
+      e.done[variant] = len;
+      e.phase++;
+      e.phase_done = 0;
+      if (e.phase < e.ncand) return;
+      int best = -1;
+      for (uint32_t i = 0; i < e.ncand; i++)
+        if (best < 0 || e.sum_ms[e.cand[i]] < e.sum_ms[best]) best = e.cand[i];
+      // the static default stays unless a candidate is clearly better
+      if (fallback >= 0 && fallback < SCHED_COUNT && e.done[fallback] && e.sum_ms[best] > 0.97 * e.sum_ms[fallback]) best = fallback;
+      e.latched = best;
+      return;
+    }
     e.done[variant]++;
     e.sum_ms[variant] += ms;
-    int best = -1, best_polite = -1;
+    int best = -1;
     for (uint32_t i = 0; i < e.ncand; i++) {
       const int v = e.cand[i];
       if (e.done[v] < (uint32_t)explore_n) return;
-      const double mean = e.sum_ms[v] / e.done[v];
-      if (best < 0 || mean < e.sum_ms[best] / e.done[best]) best = v;
-      if (v != SCHED_ONE_STREAM_SPIN && (best_polite < 0 || mean < e.sum_ms[best_polite] / e.done[best_polite])) best_polite = v;
+      if (best < 0 || e.sum_ms[v] / e.done[v] < e.sum_ms[best] / e.done[best]) best = v;
     }
-    if (best == SCHED_ONE_STREAM_SPIN && best_polite >= 0 &&
-        e.sum_ms[best] / e.done[best] > 0.9 * e.sum_ms[best_polite] / e.done[best_polite])
-      best = best_polite;
     e.latched = best;
+  }
+  // an "alone" sample during which another proof started on the device says nothing about the schedule: take it back
+  void unstart(uint64_t k, int variant) {
+    std::lock_guard<std::mutex> lk(mu);
+    Entry& e = entries[k];
+    if (e.latched < 0 && variant >= 0 && variant < SCHED_COUNT && e.started[variant] > e.done[variant]) e.started[variant]--;
   }
   // forget what was measured (ark355_sched_reset: tests, benches that change the load pattern)
   void reset() {
     std::lock_guard<std::mutex> lk(mu);
     entries.clear();
   }
+  // mean_ms: alone = mean wall time of a proof; in flight = time per completed proof over the scored part of the phase
   bool info(uint64_t k, int* latched, double mean_ms[SCHED_COUNT], uint32_t samples[SCHED_COUNT]) {
     std::lock_guard<std::mutex> lk(mu);
     auto it = entries.find(k);
@@ -684,6 +724,11 @@ static void prove_run(ark355_ctx* ctx, ProverScratch& sc, const PkDev& pk, const
         {E_SORT2, &sc.sortH, &sc.bkH, false, &pk.h_query, 3, &sc.baH},
     };
     uint64_t pts = 0;
+    // One-stream proofs: the five accumulations first, then the G2 tails and the tails of the four G1 MSMs as ONE launch
+    // per step (msm_reduce_phase_batch) -- 8 tail dispatches instead of 20, and the four latency-bound G1 chains side by
+    // side instead of one after the other.  (The pipeline hides each MSM's tails under the next accumulation instead.)
+    const bool batch_tails = one_stream && !cm && pol.batch_tails != 0 && !pk.a_ext.batch_affine && !pk.b1_ext.batch_affine &&
+                             !pk.b2_ext.batch_affine && !pk.l_ext.batch_affine && !pk.h_query.batch_affine;
     for (int j = 0; j < 5; j++) {
       const Job& jb = jobs[j];
       ARK_CHECK_HIP(hipStreamWaitEvent(sA, ev[jb.sort_ev], 0));
@@ -703,6 +748,8 @@ static void prove_run(ark355_ctx* ctx, ProverScratch& sc, const PkDev& pk, const
                                  jb.tab->limb28);
       }
       ARK_CHECK_HIP(hipEventRecord(ev[E_ACC_DONE0 + j], sA));
+      pts += (uint64_t)jb.sort->plan.windows * jb.sort->plan.n;
+      if (batch_tails) continue;
       ARK_CHECK_HIP(hipStreamWaitEvent(sR, ev[E_ACC_DONE0 + j], 0));
       if (cm && shard_mode == ARK355_SHARD_BUCKET_RING) {
         // bucket-level exchange: the ranks run their MSMs in the same order, so the ring steps pair up
@@ -719,7 +766,16 @@ static void prove_run(ark355_ctx* ctx, ProverScratch& sc, const PkDev& pk, const
       } else {
         msm_reduce_phase<Fq>(ctx, *red_sort, *jb.bk, g1res + jb.res, 0, sR);
       }
-      pts += (uint64_t)jb.sort->plan.windows * jb.sort->plan.n;
+    }
+    if (batch_tails) {
+      msm_reduce_phase<Fq2>(ctx, sc.sortZ, sc.bkB2, g2res, 0, sR);
+      const MsmSort* sorts[4] = {&sc.sortZ, &sc.sortZ, &sc.sortZ, &sc.sortH};
+      MsmBuckets* bks[4] = {&sc.bkA, &sc.bkB1, &sc.bkL, &sc.bkH};
+      XYZZ<Fq>* outs[4] = {g1res + 0, g1res + 1, g1res + 2, g1res + 3};
+      const bool batched = msm_reduce_phase_batch<Fq>(ctx, 4, sorts, bks, outs, sR);
+      if (!batched)
+        for (int i = 0; i < 4; i++) msm_reduce_phase<Fq>(ctx, *sorts[i], *bks[i], outs[i], 0, sR);
+      if (trace_host) fprintf(stderr, "[ark355] G1 tails: %s\n", batched ? "one launch per step for the four MSMs" : "per MSM");
     }
 
     if (out) memset(out, 0, sizeof(*out));
@@ -790,7 +846,10 @@ static void prove_run(ark355_ctx* ctx, ProverScratch& sc, const PkDev& pk, const
         else if (q != hipSuccess) ARK_CHECK_HIP(q);
       }
     }
-    if (exploring) SchedTuner::of(ctx->device).report(tune_key, sched, since(t_enter), pol.sched_explore);
+    if (exploring) {
+      if (!concurrent && inflight.c.load() > 1) SchedTuner::of(ctx->device).unstart(tune_key, sched);
+      else SchedTuner::of(ctx->device).report(tune_key, concurrent, sched, since(t_enter), pol.sched_explore, static_sched);
+    }
     auto el = [&](hipEvent_t a, hipEvent_t b) {
       float ms = 0;
       (void)hipEventElapsedTime(&ms, a, b);

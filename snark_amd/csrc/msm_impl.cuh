@@ -1144,6 +1144,162 @@ msm_combine_kernel(const XYZZ<F>* __restrict__ partials, uint32_t per_window, ui
   }
 }
 
+// ---- the G1 tails of SEVERAL MSMs, one launch per step (merge, heavy merge, reduction, combination) ------------------------
+// The tails are latency-bound (a few dozen dependent group operations on 32-128 workgroups): four of them side by side take
+// the time of one.  A one-stream proof runs its five accumulations first and then the tails of A, B1, L' and H together
+// (blockIdx.z = MSM): 16 dispatches and ~4 ms of stream time per 2^20 proof become 4 dispatches and ~1.4 ms.  Same lane-level
+// arithmetic as the single kernels above (the bodies are the same statements), so the bucket sums are bit-identical.
+constexpr int TAIL_BATCH_MAX = 4;
+template <class F>
+struct TailJob {
+  const uint32_t* offsets;
+  const uint32_t* counts;
+  XYZZ<F>* buckets;
+  const XYZZ<F>* head;
+  const uint32_t* head_key;
+  const XYZZ<F>* tail;
+  const uint32_t* tail_key;
+  uint32_t* heavy_count;
+  uint32_t* heavy_list;
+  XYZZ<F>* partials;
+  XYZZ<F>* out;
+  uint32_t seg_len, heavy_span;
+  int32_t accumulate;
+  uint32_t pad;
+};
+template <class F>
+struct TailBatch {
+  TailJob<F> j[TAIL_BATCH_MAX];
+};
+
+template <class F>
+__global__ void __launch_bounds__(MSM_THREADS, MSM_TAIL_WAVES)
+msm_merge_batch_kernel(TailBatch<F> tb, uint32_t total_buckets) {
+  const TailJob<F>& J = tb.j[blockIdx.z];
+  const uint32_t key = blockIdx.x * blockDim.x + threadIdx.x;
+  if (key >= total_buckets) return;
+  const uint32_t cnt = J.counts[key];
+  if (cnt == 0) return;
+  const uint32_t o = J.offsets[key];
+  const uint32_t t0 = o / J.seg_len, t1 = (o + cnt - 1) / J.seg_len;
+  if (t0 == t1) return;
+  if (t1 - t0 > J.heavy_span) {
+    J.heavy_list[atomicAdd(J.heavy_count, 1u)] = key;
+    return;
+  }
+  XYZZ<F> sum = XYZZ<F>::inf();
+  for (uint32_t t = t0; t <= t1; t++) {
+    if (J.head_key[t] == key) sum = xyzz_add(sum, J.head[t]);
+    if (J.tail_key[t] == key) sum = xyzz_add(sum, J.tail[t]);
+  }
+  J.buckets[key] = sum;
+}
+
+template <class F>
+__global__ void __launch_bounds__(MSM_THREADS, MSM_TAIL_WAVES)
+msm_merge_heavy_batch_kernel(TailBatch<F> tb) {
+  __shared__ uint32_t wave_out[(MSM_THREADS / 64) * (sizeof(XYZZ<F>) / 4)];
+  constexpr int WORDS = sizeof(XYZZ<F>) / 4;
+  const TailJob<F>& J = tb.j[blockIdx.z];
+  const uint32_t nheavy = *J.heavy_count;
+  for (uint32_t h = blockIdx.x; h < nheavy; h += gridDim.x) {
+    const uint32_t key = J.heavy_list[h];
+    const uint32_t o = J.offsets[key], cnt = J.counts[key];
+    const uint32_t t0 = o / J.seg_len, t1 = (o + cnt - 1) / J.seg_len;
+    XYZZ<F> sum = XYZZ<F>::inf();
+    for (uint32_t t = t0 + threadIdx.x; t <= t1; t += blockDim.x) {
+      if (J.head_key[t] == key) sum = xyzz_add(sum, J.head[t]);
+      if (J.tail_key[t] == key) sum = xyzz_add(sum, J.tail[t]);
+    }
+    sum = wave_reduce_sum(sum);
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) {
+      const uint32_t* src = reinterpret_cast<const uint32_t*>(&sum);
+      for (int i = 0; i < WORDS; i++) wave_out[wave * WORDS + i] = src[i];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      XYZZ<F> tot = XYZZ<F>::inf();
+      for (uint32_t v = 0; v < blockDim.x / 64; v++) {
+        XYZZ<F> t;
+        uint32_t* dst = reinterpret_cast<uint32_t*>(&t);
+        for (int i = 0; i < WORDS; i++) dst[i] = wave_out[v * WORDS + i];
+        tot = xyzz_add(tot, t);
+      }
+      J.buckets[key] = tot;
+    }
+    __syncthreads();
+  }
+}
+
+// grid (blocks per window, windows, MSMs)
+template <class F>
+__global__ void __launch_bounds__(MSM_THREADS, MSM_TAIL_WAVES)
+msm_reduce_batch_kernel(TailBatch<F> tb, uint32_t buckets_per_window) {
+  __shared__ uint32_t wave_out[(MSM_THREADS / 64) * (sizeof(XYZZ<F>) / 4)];
+  const TailJob<F>& J = tb.j[blockIdx.z];
+  const uint32_t w = blockIdx.y;
+  const uint32_t chunk = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t first = chunk * MSM_RED_K;
+  XYZZ<F> contrib = XYZZ<F>::inf();
+  if (first < buckets_per_window) {
+    const uint32_t last = (first + MSM_RED_K < buckets_per_window) ? first + MSM_RED_K : buckets_per_window;
+    const XYZZ<F>* wb = J.buckets + (uint64_t)w * buckets_per_window;
+    XYZZ<F> running = XYZZ<F>::inf();
+    XYZZ<F> acc = XYZZ<F>::inf();
+    for (uint32_t b = last; b-- > first;) {
+      running = xyzz_add(running, wb[b]);
+      acc = xyzz_add(acc, running);
+    }
+    if (first != 0 && !running.is_inf()) {
+      uint32_t k = first;
+      acc = xyzz_add(acc, xyzz_mul_scalar(running, &k, 1));
+    }
+    contrib = acc;
+  }
+  contrib = wave_reduce_sum(contrib);
+  constexpr int WORDS = sizeof(XYZZ<F>) / 4;
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) {
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(&contrib);
+    for (int i = 0; i < WORDS; i++) wave_out[wave * WORDS + i] = src[i];
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    XYZZ<F> sum = XYZZ<F>::inf();
+    for (uint32_t v = 0; v < blockDim.x / 64; v++) {
+      XYZZ<F> t;
+      uint32_t* dst = reinterpret_cast<uint32_t*>(&t);
+      for (int i = 0; i < WORDS; i++) dst[i] = wave_out[v * WORDS + i];
+      sum = xyzz_add(sum, t);
+    }
+    J.partials[w * gridDim.x + blockIdx.x] = sum;
+  }
+}
+
+// one wave per MSM (blockIdx.x = MSM)
+template <class F>
+__global__ void __launch_bounds__(64)
+msm_combine_batch_kernel(TailBatch<F> tb, uint32_t per_window, uint32_t windows, uint32_t c) {
+  const TailJob<F>& J = tb.j[blockIdx.x];
+  const uint32_t w = threadIdx.x;
+  XYZZ<F> v = XYZZ<F>::inf();
+  if (windows == 1) {
+    for (uint32_t i = w; i < per_window; i += 64) v = xyzz_add(v, J.partials[i]);
+  } else if (w < windows) {
+    for (uint32_t i = 0; i < per_window; i++) v = xyzz_add(v, J.partials[w * per_window + i]);
+    if (!v.is_inf()) {
+      const uint32_t dbl = c * w;
+      for (uint32_t i = 0; i < dbl; i++) v = xyzz_dbl(v);
+    }
+  }
+  v = wave_reduce_sum(v);
+  if (threadIdx.x == 0) {
+    if (J.accumulate) v = xyzz_add(v, *J.out);
+    *J.out = v;
+  }
+}
+
 // XYZZ -> affine for `count` points (one lane each)
 template <class F>
 __global__ void __launch_bounds__(64)
@@ -1821,6 +1977,74 @@ static void msm_reduce_phase(ark355_ctx* ctx, const MsmSort& s, MsmBuckets& b, X
   ARK_LAUNCH((msm_combine_kernel<F>), dim3(1), dim3(64), 0, stream, b.partials.as<XYZZ<F>>(), blocks_per_window,
              p.key_windows, p.c, d_out, accumulate);
   ARK_CHECK_LAUNCH();
+}
+
+// Phase 2 of `count` (<= TAIL_BATCH_MAX) G1 MSMs whose accumulations have been queued on `stream`, as one launch per
+// step.  Returns false -- nothing queued -- when the MSMs cannot share launches (different bucket layouts, an empty one,
+// the lazy-flush build, the two-level reduction of very large bucket sets): the caller then runs msm_reduce_phase per MSM.
+template <class F>
+static bool msm_reduce_phase_batch(ark355_ctx* ctx, int count, const MsmSort* const* sorts, MsmBuckets* const* bks,
+                                   XYZZ<F>* const* outs, hipStream_t stream) {
+  static_assert(!is_fp2<F>::value, "the G2 tails run on lane pairs (msm_*_pair_kernel)");
+  if (count < 2 || count > TAIL_BATCH_MAX) return false;
+  const MsmPlan& p0 = sorts[0]->plan;
+  const uint32_t two_level_min = ctx->policy.msm_two_level_min >= 0 ? (uint32_t)ctx->policy.msm_two_level_min
+                                                                     : (uint32_t)ARK_MSM_TWO_LEVEL_MIN;
+  if (p0.key_windows == 1 && p0.total_buckets >= two_level_min) return false;
+  if (p0.key_windows > 64) return false;
+  for (int i = 0; i < count; i++) {
+    const MsmPlan& p = sorts[i]->plan;
+    if (p.n == 0 || bks[i]->lazy28) return false;
+    if (p.total_buckets != p0.total_buckets || p.buckets_per_window != p0.buckets_per_window || p.key_windows != p0.key_windows ||
+        p.c != p0.c)
+      return false;
+  }
+  const uint32_t grid_b = (p0.total_buckets + MSM_THREADS - 1) / MSM_THREADS;
+  const uint32_t chunks = (p0.buckets_per_window + MSM_RED_K - 1) / MSM_RED_K;
+  const uint32_t blocks_per_window = (chunks + MSM_THREADS - 1) / MSM_THREADS;
+  TailBatch<F> tb;
+  memset(&tb, 0, sizeof(tb));
+  uint32_t max_heavy_all = 1;
+  for (int i = 0; i < count; i++) {
+    const MsmSort& s = *sorts[i];
+    MsmBuckets& b = *bks[i];
+    const uint32_t segs = b.segs;
+    const uint32_t max_heavy = segs / MSM_HEAVY_SPAN + 1;
+    const uint32_t avg_span = (uint32_t)(((uint64_t)segs + p0.total_buckets - 1) / p0.total_buckets);
+    const uint32_t heavy_span = (2 * avg_span > MSM_HEAVY_SPAN) ? 2 * avg_span : MSM_HEAVY_SPAN;
+    if (max_heavy > max_heavy_all) max_heavy_all = max_heavy;
+    b.heavy_count.ensure(16);
+    b.heavy_list.ensure((size_t)max_heavy * 4);
+    b.partials.ensure((size_t)blocks_per_window * p0.key_windows * sizeof(XYZZ<F>));
+    if (!b.heavy_cleared) ARK_CHECK_HIP(hipMemsetAsync(b.heavy_count.p, 0, 4, stream));
+    b.heavy_cleared = false;
+    TailJob<F>& J = tb.j[i];
+    J.offsets = s.offsets.as<uint32_t>();
+    J.counts = s.counts.as<uint32_t>();
+    J.buckets = b.buckets.as<XYZZ<F>>();
+    J.head = b.head.as<XYZZ<F>>();
+    J.head_key = b.head_key.as<uint32_t>();
+    J.tail = b.tail.as<XYZZ<F>>();
+    J.tail_key = b.tail_key.as<uint32_t>();
+    J.heavy_count = b.heavy_count.as<uint32_t>();
+    J.heavy_list = b.heavy_list.as<uint32_t>();
+    J.partials = b.partials.as<XYZZ<F>>();
+    J.out = outs[i];
+    J.seg_len = b.seg_len;
+    J.heavy_span = heavy_span;
+    J.accumulate = 0;
+  }
+  ARK_LAUNCH((msm_merge_batch_kernel<F>), dim3(grid_b, 1, (uint32_t)count), dim3(MSM_THREADS), 0, stream, tb, p0.total_buckets);
+  ARK_CHECK_LAUNCH();
+  const uint32_t grid_h = max_heavy_all < ARK_MSM_HEAVY_GRID ? max_heavy_all : ARK_MSM_HEAVY_GRID;
+  ARK_LAUNCH((msm_merge_heavy_batch_kernel<F>), dim3(grid_h, 1, (uint32_t)count), dim3(MSM_THREADS), 0, stream, tb);
+  ARK_CHECK_LAUNCH();
+  ARK_LAUNCH((msm_reduce_batch_kernel<F>), dim3(blocks_per_window, p0.key_windows, (uint32_t)count), dim3(MSM_THREADS), 0, stream,
+             tb, p0.buckets_per_window);
+  ARK_CHECK_LAUNCH();
+  ARK_LAUNCH((msm_combine_batch_kernel<F>), dim3((uint32_t)count), dim3(64), 0, stream, tb, blocks_per_window, p0.key_windows, p0.c);
+  ARK_CHECK_LAUNCH();
+  return true;
 }
 
 // Both phases on one stream.

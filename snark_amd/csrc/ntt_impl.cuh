@@ -226,6 +226,9 @@ struct NttPassArgs {
   const void* w_lo;      // hi/lo tables of w (composition when no direct table)
   const void* w_hi;
   uint32_t lo_bits;
+  // several vectors of one shape in ONE launch (the witness map's a, b, c): vector y = blockIdx.y reads in + y * batch_stride
+  // and writes out + y * batch_stride (elements); 0 for a single vector
+  uint64_t batch_stride;
 };
 
 template <class Fr>
@@ -239,7 +242,7 @@ template <class Fr>
 ARK_D void ntt_load_inputs(NttLane<Fr>& v, const NttPassArgs& a, const uint32_t (&pos)[8], uint64_t pq0, uint32_t cols_log,
                            bool active) {
   if (!active) return;
-  const Fr* in = reinterpret_cast<const Fr*>(a.in);
+  const Fr* in = reinterpret_cast<const Fr*>(a.in) + (uint64_t)blockIdx.y * a.batch_stride;
 #pragma unroll
   for (int i = 0; i < 8; i++) {
     const uint32_t c = pos[i] & ((1u << a.p_log) - 1u), t = pos[i] >> a.p_log;
@@ -274,7 +277,7 @@ template <class Fr, int R_LOG>
 ARK_D void ntt_store_outputs(NttLane<Fr>& v, const NttPassArgs& a, const uint32_t (&kout)[8], const uint32_t (&cout)[8],
                              uint64_t pq0, bool active) {
   if (!active) return;
-  Fr* out = reinterpret_cast<Fr*>(a.out);
+  Fr* out = reinterpret_cast<Fr*>(a.out) + (uint64_t)blockIdx.y * a.batch_stride;
   const uint64_t s_mask = (1ull << a.s_log) - 1ull;
   if (a.direct) {
 #pragma unroll
@@ -568,17 +571,17 @@ static inline std::vector<uint32_t> ntt_radices(const TunePolicy& pol, uint32_t 
 }
 
 template <class Fr, int R_LOG>
-static void ntt_launch_pass(const NttPassArgs& a, hipStream_t stream) {
+static void ntt_launch_pass(const NttPassArgs& a, hipStream_t stream, uint32_t batch = 1) {
   const uint32_t grid = 1u << (a.log_n - R_LOG - a.p_log);
   const size_t smem = ((size_t)16 << (R_LOG + a.p_log)) + (size_t)32 * ((1u << R_LOG) >> 1) + 32;
-  ARK_LAUNCH((ntt_pass_kernel<Fr, R_LOG>), dim3(grid), dim3(NTT_THREADS), smem, stream, a);
+  ARK_LAUNCH((ntt_pass_kernel<Fr, R_LOG>), dim3(grid, batch), dim3(NTT_THREADS), smem, stream, a);
   ARK_CHECK_LAUNCH();
 }
 template <class Fr, int R_LOG>
-static void ntt_launch_seam(const NttPassArgs& a, const NttPassArgs& b, const Fr* seam, hipStream_t stream) {
+static void ntt_launch_seam(const NttPassArgs& a, const NttPassArgs& b, const Fr* seam, hipStream_t stream, uint32_t batch = 1) {
   const uint32_t grid = 1u << (a.log_n - R_LOG - a.p_log);
   const size_t smem = ((size_t)16 << (R_LOG + a.p_log)) + (size_t)64 * ((1u << R_LOG) >> 1) + 64;
-  ARK_LAUNCH((ntt_seam_kernel<Fr, R_LOG>), dim3(grid), dim3(NTT_THREADS), smem, stream, a, b, seam);
+  ARK_LAUNCH((ntt_seam_kernel<Fr, R_LOG>), dim3(grid, batch), dim3(NTT_THREADS), smem, stream, a, b, seam);
   ARK_CHECK_LAUNCH();
 }
 
@@ -655,12 +658,15 @@ ntt_twiddle_kernel(Fr* __restrict__ y, uint64_t n, uint32_t s_log, uint32_t r, c
 }
 
 template <class Fr>
-static void ntt_twiddle_fallback(const NttPassArgs& a, uint32_t r, hipStream_t stream) {
+static void ntt_twiddle_fallback(const NttPassArgs& a, uint32_t r, hipStream_t stream, uint32_t batch = 1) {
   if (a.direct || a.s_log + r == a.log_n) return;
   const uint64_t n = 1ull << a.log_n;
-  ARK_LAUNCH((ntt_twiddle_kernel<Fr>), dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, stream, reinterpret_cast<Fr*>(a.out), n,
-             a.s_log, r, reinterpret_cast<const Fr*>(a.w_lo), reinterpret_cast<const Fr*>(a.w_hi), a.lo_bits);
-  ARK_CHECK_LAUNCH();
+  for (uint32_t y = 0; y < batch; y++) {
+    ARK_LAUNCH((ntt_twiddle_kernel<Fr>), dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, stream,
+               reinterpret_cast<Fr*>(a.out) + (uint64_t)y * a.batch_stride, n, a.s_log, r, reinterpret_cast<const Fr*>(a.w_lo),
+               reinterpret_cast<const Fr*>(a.w_hi), a.lo_bits);
+    ARK_CHECK_LAUNCH();
+  }
 }
 
 // NTT of 2^log_n elements.  `data` holds the input; `scratch` is a same-size buffer.  Returns the buffer that holds
@@ -724,19 +730,28 @@ static void* ntt_run(ark355_ctx* ctx, void* data, void* scratch, uint32_t log_n,
 
 // inverse NTT followed by coset NTT of the same vector (witness map: evaluations on H -> evaluations on g H), with the
 // seam fused when the first and the last pass share a radix.  Same contract as ntt_run.
+// batch > 1: `batch` vectors of the same length, vector y at data + y * batch_stride with its ping-pong partner at
+// scratch + y * batch_stride (elements), every pass ONE launch over all of them (the witness map's a, b, c: 15 dispatches
+// become 5, and a pass fills the chip three times as long); the result of vector y sits at (return value) + y * batch_stride.
 template <class Curve>
-static void* ntt_inverse_then_coset(ark355_ctx* ctx, void* data, void* scratch, uint32_t log_n, hipStream_t stream) {
+static void* ntt_inverse_then_coset(ark355_ctx* ctx, void* data, void* scratch, uint32_t log_n, hipStream_t stream,
+                                    uint32_t batch = 1, uint64_t batch_stride = 0) {
   using Fr = typename Curve::Fr;
   const std::vector<uint32_t> radices = log_n >= 3 ? ntt_radices(ctx->policy, log_n) : std::vector<uint32_t>();
   // the seam kernel exists for first/last radices 2^5 .. 2^9 (every domain of 2^10 points or more with matching ends);
   // tests lower the bound through policy NTT_RMAX and then use radices < 6: those take the unfused path
   const bool fuse = log_n >= 3 && radices.front() == radices.back() && radices.front() >= 5 && !ctx->policy.ntt_nofuse;
   if (!fuse) {
-    void* cur = data;
-    void* oth = scratch;
-    void* res = ntt_run<Curve>(ctx, cur, oth, log_n, /*inverse=*/true, /*coset=*/false, stream);
-    if (res != cur) { oth = cur; cur = res; }
-    return ntt_run<Curve>(ctx, cur, oth, log_n, /*inverse=*/false, /*coset=*/true, stream);
+    void* first = nullptr;
+    for (uint32_t y = 0; y < batch; y++) {       // (every vector takes the same ping-pong path)
+      void* cur = (Fr*)data + (uint64_t)y * batch_stride;
+      void* oth = (Fr*)scratch + (uint64_t)y * batch_stride;
+      void* res = ntt_run<Curve>(ctx, cur, oth, log_n, /*inverse=*/true, /*coset=*/false, stream);
+      if (res != cur) { oth = cur; cur = res; }
+      res = ntt_run<Curve>(ctx, cur, oth, log_n, /*inverse=*/false, /*coset=*/true, stream);
+      if (y == 0) first = res;
+    }
+    return first;
   }
   NttTables* t = get_ntt_tables<Curve>(ctx, log_n);
   const size_t np = radices.size();
@@ -753,6 +768,7 @@ static void* ntt_inverse_then_coset(ark355_ctx* ctx, void* data, void* scratch, 
     a.w_lo = (inverse ? t->wi_lo : t->w_lo).template as<Fr>();
     a.w_hi = (inverse ? t->wi_hi : t->w_hi).template as<Fr>();
     a.lo_bits = t->lo_bits;
+    a.batch_stride = batch > 1 ? batch_stride : 0;
     return a;
   };
   // inverse transform, all passes but the last
@@ -761,8 +777,8 @@ static void* ntt_inverse_then_coset(ark355_ctx* ctx, void* data, void* scratch, 
     NttPassArgs a = make(true, pass, s_log);
     a.in = src;
     a.out = dst;
-    ARK_NTT_DISPATCH(radices[pass], (ntt_launch_pass<Fr, RL>(a, stream)));
-    ntt_twiddle_fallback<Fr>(a, radices[pass], stream);
+    ARK_NTT_DISPATCH(radices[pass], (ntt_launch_pass<Fr, RL>(a, stream, batch)));
+    ntt_twiddle_fallback<Fr>(a, radices[pass], stream, batch);
     s_log += radices[pass];
     Fr* tmp = src; src = dst; dst = tmp;
   }
@@ -774,14 +790,14 @@ static void* ntt_inverse_then_coset(ark355_ctx* ctx, void* data, void* scratch, 
     b.out = dst;
     const Fr* seam = ntt_seam_table<Fr>(t);
     switch (radices[0]) {      // instantiated for the radices a fused transform can start with (log_n >= NTT_SEAM_MIN_LOG)
-      case 5: ntt_launch_seam<Fr, 5>(a, b, seam, stream); break;
-      case 6: ntt_launch_seam<Fr, 6>(a, b, seam, stream); break;
-      case 7: ntt_launch_seam<Fr, 7>(a, b, seam, stream); break;
-      case 8: ntt_launch_seam<Fr, 8>(a, b, seam, stream); break;
-      case 9: ntt_launch_seam<Fr, 9>(a, b, seam, stream); break;
+      case 5: ntt_launch_seam<Fr, 5>(a, b, seam, stream, batch); break;
+      case 6: ntt_launch_seam<Fr, 6>(a, b, seam, stream, batch); break;
+      case 7: ntt_launch_seam<Fr, 7>(a, b, seam, stream, batch); break;
+      case 8: ntt_launch_seam<Fr, 8>(a, b, seam, stream, batch); break;
+      case 9: ntt_launch_seam<Fr, 9>(a, b, seam, stream, batch); break;
       default: throw HipError{ARK355_EINVAL, "no seam kernel for this radix"};
     }
-    ntt_twiddle_fallback<Fr>(b, radices[0], stream);
+    ntt_twiddle_fallback<Fr>(b, radices[0], stream, batch);
     Fr* tmp = src; src = dst; dst = tmp;
   }
   // coset transform, remaining passes
@@ -790,8 +806,8 @@ static void* ntt_inverse_then_coset(ark355_ctx* ctx, void* data, void* scratch, 
     NttPassArgs a = make(false, pass, s_log);
     a.in = src;
     a.out = dst;
-    ARK_NTT_DISPATCH(radices[pass], (ntt_launch_pass<Fr, RL>(a, stream)));
-    ntt_twiddle_fallback<Fr>(a, radices[pass], stream);
+    ARK_NTT_DISPATCH(radices[pass], (ntt_launch_pass<Fr, RL>(a, stream, batch)));
+    ntt_twiddle_fallback<Fr>(a, radices[pass], stream, batch);
     s_log += radices[pass];
     Fr* tmp = src; src = dst; dst = tmp;
   }

@@ -41,6 +41,7 @@ struct TunePolicy {
   int32_t device_finalize = 0;    // O(1) proof tail on the device instead of the host
   int32_t trace_host = 0;         // host wall-clock phases on stderr
   int32_t sched_explore = 3;      // samples per candidate before SCHED_AUTO latches (0: static default, no exploration)
+  int32_t batch_tails = 1;        // one-stream proofs: merge / reduce / combine of the four G1 MSMs as ONE launch each
   // ---- per key load
   int32_t msm_c = 0;              // window size of resident tables (0: planner)
   int32_t msm_c_h = 0;            // window size of the h_query table alone (0: same rule as the others)
@@ -83,6 +84,7 @@ inline const TunePolicy::Field* TunePolicy::fields(int* count) {
       ARK_POLICY_FIELD32("DEVICE_FINALIZE", device_finalize),
       ARK_POLICY_FIELD32("TRACE_HOST", trace_host),
       ARK_POLICY_FIELD32("SCHED_EXPLORE", sched_explore),
+      ARK_POLICY_FIELD32("BATCH_TAILS", batch_tails),
       ARK_POLICY_FIELD32("MSM_C", msm_c),
       ARK_POLICY_FIELD32("MSM_C_H", msm_c_h),
       ARK_POLICY_FIELD32("LIMB28", limb28),

@@ -164,14 +164,26 @@ static R1csDev* r1cs_upload(uint64_t n, uint64_t ell, uint64_t w, const uint64_t
 
 // Scratch of one witness map: a, b, c and their ping-pong partners (N Fr each).
 struct WitnessScratch {
-  DevBuf buf[6];
+  // ONE allocation of 6 N elements, buf[2v] / buf[2v + 1] = vector v (a, b, c) and its ping-pong partner: the three
+  // vectors sit at a uniform stride of 2 N elements, so every NTT pass over them is one launch (ntt_inverse_then_coset)
+  struct View {
+    void* p = nullptr;
+    template <class T>
+    T* as() const { return reinterpret_cast<T*>(p); }
+  };
+  DevBuf all;
+  View buf[6];
   DevBuf first_bad;
+  void ensure(size_t vec_bytes) {
+    all.ensure(6 * vec_bytes);
+    for (int i = 0; i < 6; i++) buf[i].p = static_cast<uint8_t*>(all.p) + (size_t)i * vec_bytes;
+  }
 };
 
 template <class Curve>
 static void spmv_run(const R1csDev& r, const void* d_z, WitnessScratch& ws, hipStream_t stream) {
   using Fr = typename Curve::Fr;
-  for (int i = 0; i < 6; i++) ws.buf[i].ensure(r.N * sizeof(Fr));
+  ws.ensure(r.N * sizeof(Fr));
   const uint32_t grid = (uint32_t)((r.N + 255) / 256);
   ARK_LAUNCH((r1cs_spmv_kernel<Fr>), dim3(grid, 3), dim3(256), 0, stream, r.row_ptr[0].as<uint32_t>(),
              r.col[0].as<uint32_t>(), r.cidx[0].as<uint32_t>(), r.row_ptr[1].as<uint32_t>(), r.col[1].as<uint32_t>(),
@@ -189,12 +201,16 @@ static void* witness_map_run(ark355_ctx* ctx, const R1csDev& r, const void* d_z,
   spmv_run<Curve>(r, d_z, ws, stream);
   void* cur[3];
   void* oth[3];
-  for (int v = 0; v < 3; v++) {
-    cur[v] = ws.buf[2 * v].p;
-    oth[v] = ws.buf[2 * v + 1].p;
-    // evaluations on H -> evaluations on g H: inverse NTT and coset NTT with the seam fused (ntt_impl.cuh)
-    void* res = ntt_inverse_then_coset<Curve>(ctx, cur[v], oth[v], r.log_n, stream);
-    if (res != cur[v]) { oth[v] = cur[v]; cur[v] = res; }
+  {
+    // evaluations on H -> evaluations on g H: inverse NTT and coset NTT with the seam fused (ntt_impl.cuh), the three
+    // vectors in one launch per pass
+    const uint64_t stride = 2 * r.N;
+    Fr* res0 = (Fr*)ntt_inverse_then_coset<Curve>(ctx, ws.buf[0].p, ws.buf[1].p, r.log_n, stream, 3, stride);
+    const bool swapped = res0 != ws.buf[0].as<Fr>();
+    for (int v = 0; v < 3; v++) {
+      cur[v] = ws.buf[2 * v + (swapped ? 1 : 0)].p;
+      oth[v] = ws.buf[2 * v + (swapped ? 0 : 1)].p;
+    }
   }
   const uint32_t grid = (uint32_t)((r.N + 255) / 256);
   ARK_LAUNCH((qap_pointwise_kernel<Fr>), dim3(grid), dim3(256), 0, stream, (const Fr*)cur[0], (const Fr*)cur[1],
