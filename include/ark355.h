@@ -265,6 +265,12 @@ int32_t ark355_proof_from_bytes(int32_t curve, const uint8_t* in, uint64_t len, 
 /* R1CS -> QAP witness map h[0..N) (Montgomery), SURVEY Appendix A steps 1-5 */
 int32_t ark355_witness_map(ark355_ctx* ctx, const ark355_r1cs* r1cs, const uint8_t* z, uint64_t z_len,
                            uint8_t* h_out);
+/* The same map computed the way the `world` GPUs of a sharded proof compute it (every rank owns 1/world of each vector,
+ * three all-to-all exchanges; snark_amd/csrc/witness_dist_impl.cuh), with ALL ranks on this one device and
+ * device-to-device copies as the exchange: the test / diagnostic entry of the distributed path on a single GPU
+ * (ark355_prove_sharded runs it over RCCL).  world: a power of two >= 2 with 8 * world^2 <= N; ARK355_EINVAL otherwise. */
+int32_t ark355_witness_map_dist_sim(ark355_ctx* ctx, const ark355_r1cs* r1cs, const uint8_t* z, uint64_t z_len,
+                                    uint32_t world, uint8_t* h_out);
 /* which_is_unsatisfied (constraint_system.rs:661-687) for the R1CS predicate: first_bad = -1 if
  * satisfied, else the first constraint index with <A_i,z>*<B_i,z> != <C_i,z> */
 int32_t ark355_is_satisfied(ark355_ctx* ctx, const ark355_r1cs* r1cs, const uint8_t* z, uint64_t z_len,

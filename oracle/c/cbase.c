@@ -577,3 +577,89 @@ int cb_setup_scalars(int curve, uint64_t n, uint64_t ell, uint64_t wn, const uin
   }
   return 0;
 }
+
+/* ---- ark-serialize point encodings (oracle side of the wire-format tests at BASELINE key sizes) -----------------------
+ * Restates oracle/serialize.py (itself: ark-serialize + ark-bls12-381 curves/util.rs + ark-ec SWFlags; SURVEY.md
+ * Appendix A "Serialisation") for VECTORS of raw affine points, so that a 2^20-constraint proving key (5.2 M points) can
+ * be turned into a ProvingKey byte stream in seconds; checked against the Python encoders in tests/test_oracle_c.py.
+ *   BLS12-381: big-endian coordinates, G2 as c1 || c0; flags in the top bits of the FIRST byte (0x80 compressed,
+ *              0x40 infinity, 0x20 y is the lexicographically larger root);
+ *   BN254:     little-endian coordinates, G2 as c0 || c1; flags in the top bits of the LAST byte (0x80 y > -y, 0x40 infinity).
+ * raw: n points, x || y as Montgomery LE limbs (an all-zero point is infinity).  out: n * size bytes, size =
+ * nb (G1 compressed), 2 nb (G1 uncompressed, G2 compressed), 4 nb (G2 uncompressed), nb = 48 / 32. */
+static int limbs_gt(const uint64_t* a, const uint64_t* b, int nl) {
+  for (int i = nl - 1; i >= 0; i--) {
+    if (a[i] != b[i]) return a[i] > b[i];
+  }
+  return 0;
+}
+static void limbs_out(uint8_t* dst, const uint64_t* l, int nl, int big_endian) {
+  const int nb = 8 * nl;
+  for (int i = 0; i < nb; i++) {
+    const uint8_t v = (uint8_t)(l[i / 8] >> (8 * (i % 8)));
+    dst[big_endian ? nb - 1 - i : i] = v;
+  }
+}
+#define SER_BODY(FT, NLIMBS, PARAMS)                                                                                  \
+  const int nl = NLIMBS, nb = 8 * NLIMBS, nc = group == 1 ? 1 : 2;                                                    \
+  const size_t psz = (size_t)nb * nc * (compressed ? 1 : 2);                                                          \
+  const int be = (curve == 0);                                                                                        \
+  _Pragma("omp parallel for schedule(static)") for (size_t i = 0; i < n; i++) {                                       \
+    const uint64_t* p = raw + i * (size_t)(2 * nc * nl);                                                              \
+    uint8_t* o = out + i * psz;                                                                                       \
+    memset(o, 0, psz);                                                                                                \
+    int inf = 1;                                                                                                      \
+    for (int k = 0; k < 2 * nc * nl; k++) inf &= (p[k] == 0);                                                         \
+    uint8_t* flag = be ? o : o + psz - 1;                                                                             \
+    if (inf) {                                                                                                        \
+      *flag |= be ? (compressed ? 0xC0 : 0x40) : 0x40;                                                                \
+      continue;                                                                                                       \
+    }                                                                                                                 \
+    FT##_t c[4], neg[2];                                                                                                 \
+    for (int k = 0; k < 2 * nc; k++) {                                                                                \
+      FT##_t m;                                                                                                          \
+      memcpy(m.l, p + (size_t)k * nl, (size_t)nb);                                                                    \
+      FT##_from_mont(&c[k], &m, PARAMS);                                                                              \
+    }                                                                                                                 \
+    /* y > -y, Fq2: c1 first, then c0 (canonical integers) */                                                         \
+    int ygt;                                                                                                          \
+    {                                                                                                                 \
+      const FT##_t* y = c + nc;                                                                                          \
+      for (int k = 0; k < nc; k++) {                                                                                  \
+        int z = 1;                                                                                                    \
+        for (int t = 0; t < nl; t++) z &= (y[k].l[t] == 0);                                                           \
+        if (z) memset(neg[k].l, 0, (size_t)nb);                                                                       \
+        else {                                                                                                        \
+          uint64_t br = 0;                                                                                            \
+          for (int t = 0; t < nl; t++) {                                                                              \
+            const unsigned __int128 d = (unsigned __int128)(PARAMS)->mod[t] - y[k].l[t] - br;                         \
+            neg[k].l[t] = (uint64_t)d;                                                                                \
+            br = (uint64_t)(d >> 64) & 1;                                                                             \
+          }                                                                                                           \
+        }                                                                                                             \
+      }                                                                                                               \
+      if (nc == 2 && memcmp(y[1].l, neg[1].l, (size_t)nb) != 0) ygt = limbs_gt(y[1].l, neg[1].l, nl);                 \
+      else ygt = limbs_gt(y[0].l, neg[0].l, nl);                                                                      \
+    }                                                                                                                 \
+    /* coordinate order on the wire */                                                                                \
+    const int ncoord = compressed ? nc : 2 * nc;                                                                      \
+    for (int k = 0; k < ncoord; k++) {                                                                                \
+      const int comp = k / nc, idx = k % nc;                                                                          \
+      const int src = comp * nc + (be && nc == 2 ? 1 - idx : idx);                                                    \
+      limbs_out(o + (size_t)k * nb, c[src].l, nl, be);                                                                \
+    }                                                                                                                 \
+    if (be) {                                                                                                         \
+      if (compressed) *flag |= 0x80 | (ygt ? 0x20 : 0);                                                               \
+    } else if (ygt) {                                                                                                 \
+      *flag |= 0x80;                                                                                                  \
+    }                                                                                                                 \
+  }                                                                                                                   \
+  return 0;
+
+int cb_points_serialize(int curve, int group, const uint64_t* raw, uint64_t n, int compressed, uint8_t* out) {
+  if (curve == 0) {
+    SER_BODY(f6, 6, &g_curves[0].fq6)
+  } else {
+    SER_BODY(f4, 4, &g_curves[1].fq4)
+  }
+}

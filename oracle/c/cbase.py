@@ -116,6 +116,37 @@ def witness_map(curve: CurveParams, n, ell, w, mats, z: bytes) -> bytes:
     return out.tobytes()
 
 
+def points_serialize(curve: CurveParams, group: int, raw, compressed: bool) -> bytes:
+    """ark-serialize encoding of a vector of raw affine points (cb_points_serialize), without the length prefix."""
+    nb = curve.fq_bytes
+    rsz = 2 * nb * (1 if group == 1 else 2)
+    raw = np.frombuffer(raw, dtype=np.uint8) if not isinstance(raw, np.ndarray) else raw.view(np.uint8).reshape(-1)
+    assert len(raw) % rsz == 0
+    n = len(raw) // rsz
+    psz = nb * (1 if group == 1 else 2) * (1 if compressed else 2)
+    out = np.zeros(max(1, n * psz), dtype=np.uint8)
+    src = np.ascontiguousarray(raw) if n else np.zeros(8, dtype=np.uint8)
+    rc = lib().cb_points_serialize(curve.curve_id, group, src.ctypes.data_as(C.c_void_p), C.c_uint64(n), int(bool(compressed)),
+                                   out.ctypes.data_as(C.c_void_p))
+    if rc:
+        raise ValueError(rc)
+    return out[:n * psz].tobytes()
+
+
+def pk_stream(curve: CurveParams, pk_raw: dict, compressed: bool) -> bytes:
+    """`ProvingKey` byte stream (oracle/serialize.py pk_bytes layout) from the raw key of setup_raw_c."""
+    def e(group, raw):
+        return points_serialize(curve, group, raw, compressed)
+
+    def vec(group, raw):
+        rsz = 2 * curve.fq_bytes * (1 if group == 1 else 2)
+        return (len(raw) // rsz).to_bytes(8, "little") + e(group, raw)
+    return (e(1, pk_raw["alpha_g1"]) + e(2, pk_raw["beta_g2"]) + e(2, pk_raw["gamma_g2"]) + e(2, pk_raw["delta_g2"])
+            + vec(1, pk_raw["gamma_abc_g1"]) + e(1, pk_raw["beta_g1"]) + e(1, pk_raw["delta_g1"])
+            + vec(1, pk_raw["a_query"]) + vec(1, pk_raw["b_g1_query"]) + vec(2, pk_raw["b_g2_query"])
+            + vec(1, pk_raw["h_query"]) + vec(1, pk_raw["l_query"]))
+
+
 def prove(curve: CurveParams, n, ell, w, mats, z: bytes, pk_raw: dict, r: int, s: int, timings=None):
     """pk_raw: dict of raw byte arrays with the names of ark355_pk_desc.  Returns (a, b, c) raw affine."""
     g1, g2 = 2 * curve.fq_bytes, 4 * curve.fq_bytes

@@ -268,34 +268,87 @@ static void G(_msm)(G(_jac) * out, const G(_aff) * bases, const uint64_t* scalar
   free(digits);
 }
 
-/* out[i] = k_i * base via an 8-bit fixed-base table (setup) */
+/* out[i] = k_i * base via a fixed-base window table (setup; ark-ec FixedBase::msm: windowed table, one mixed addition per
+ * window, batch normalisation).  8-bit windows for short vectors, 16-bit windows (16 additions per scalar, a table of 2^20
+ * points built in parallel) from 2^16 scalars on. */
+static void G(_normalize_chunk)(G(_aff) * out, const G(_jac) * in, size_t cnt, F(_t) * pref, const F(_params) * P) {
+  F(_t) run, inv;
+  F(_set_one)(&run, P);
+  for (size_t k = 0; k < cnt; k++) {
+    pref[k] = run;
+    if (!G(_is_inf)(&in[k])) F(_mul)(&run, &run, &in[k].z, P);
+  }
+  F(_inv)(&inv, &run, P);
+  for (size_t k = cnt; k-- > 0;) {
+    if (G(_is_inf)(&in[k])) {
+      F(_set_zero)(&out[k].x);
+      F(_set_zero)(&out[k].y);
+      continue;
+    }
+    F(_t) zi, zi2, zi3;
+    F(_mul)(&zi, &inv, &pref[k], P);               /* 1 / z_k */
+    F(_mul)(&inv, &inv, &in[k].z, P);
+    F(_sqr)(&zi2, &zi, P);
+    F(_mul)(&zi3, &zi2, &zi, P);
+    F(_mul)(&out[k].x, &in[k].x, &zi2, P);
+    F(_mul)(&out[k].y, &in[k].y, &zi3, P);
+  }
+}
+
 static void G(_fixed_base)(G(_aff) * out, const G(_aff) * base, const uint64_t* scalars, size_t n,
                            const F(_params) * P) {
-  enum { WB = 8, NW = 32 };
-  G(_aff)* table = (G(_aff)*)malloc(sizeof(G(_aff)) * NW * 256);
-  G(_jac) cur;
-  cur.x = base->x;
-  cur.y = base->y;
-  F(_set_one)(&cur.z, P);
-  if (G(_aff_is_inf)(base)) G(_set_inf)(&cur, P);
-  for (int w = 0; w < NW; w++) {
-    G(_jac) acc;
-    G(_set_inf)(&acc, P);
-    for (int d = 0; d < 256; d++) {
-      G(_to_affine)(&table[w * 256 + d], &acc, P);
-      G(_add)(&acc, &acc, &cur, P);
-    }
-    for (int j = 0; j < WB; j++) G(_double)(&cur, &cur, P);
-  }
-#pragma omp parallel for schedule(static)
-  for (size_t i = 0; i < n; i++) {
-    G(_jac) acc;
-    G(_set_inf)(&acc, P);
+  const int WB = n >= ((size_t)1 << 16) ? 16 : 8;
+  const int NW = 256 / WB;
+  const size_t TW = (size_t)1 << WB;                  /* entries per window */
+  enum { CH = 512 };
+  G(_aff)* table = (G(_aff)*)malloc(sizeof(G(_aff)) * NW * TW);
+  G(_jac)* wbase = (G(_jac)*)malloc(sizeof(G(_jac)) * NW);
+  {
+    G(_jac) cur;
+    cur.x = base->x;
+    cur.y = base->y;
+    F(_set_one)(&cur.z, P);
+    if (G(_aff_is_inf)(base)) G(_set_inf)(&cur, P);
     for (int w = 0; w < NW; w++) {
-      unsigned d = (unsigned)((scalars[4 * i + (w >> 3)] >> ((w & 7) * 8)) & 0xFF);
-      if (d) G(_madd)(&acc, &acc, &table[w * 256 + d], P);
+      wbase[w] = cur;
+      for (int j = 0; j < WB; j++) G(_double)(&cur, &cur, P);
     }
-    G(_to_affine)(&out[i], &acc, P);
+  }
+  /* table[w][d] = d * 2^(WB w) * base, normalised chunk by chunk (one inversion per CH entries) */
+  const size_t tchunks = (TW + CH - 1) / CH;
+#pragma omp parallel for schedule(dynamic, 1) collapse(2)
+  for (int w = 0; w < NW; w++) {
+    for (size_t tc = 0; tc < tchunks; tc++) {
+      const size_t d0 = tc * CH, d1 = (d0 + CH < TW) ? d0 + CH : TW;
+      G(_jac) tj[CH];
+      F(_t) pref[CH];
+      G(_jac) acc;
+      uint64_t k[4] = {(uint64_t)d0, 0, 0, 0};
+      G(_mul_scalar)(&acc, &wbase[w], k, P);           /* d0 * wbase (d0 = 0: infinity) */
+      for (size_t d = d0; d < d1; d++) {
+        tj[d - d0] = acc;
+        G(_add)(&acc, &acc, &wbase[w], P);
+      }
+      G(_normalize_chunk)(&table[(size_t)w * TW + d0], tj, d1 - d0, pref, P);
+    }
+  }
+  free(wbase);
+  const size_t nchunks = (n + CH - 1) / CH;
+#pragma omp parallel for schedule(dynamic, 4)
+  for (size_t ch = 0; ch < nchunks; ch++) {
+    const size_t i0 = ch * CH, i1 = (i0 + CH < n) ? i0 + CH : n;
+    G(_jac) acc[CH];
+    F(_t) pref[CH];
+    for (size_t i = i0; i < i1; i++) {
+      G(_jac)* a = &acc[i - i0];
+      G(_set_inf)(a, P);
+      for (int w = 0; w < NW; w++) {
+        const int bit = w * WB;
+        const size_t d = (size_t)((scalars[4 * i + (bit >> 6)] >> (bit & 63)) & (TW - 1));
+        if (d) G(_madd)(a, a, &table[(size_t)w * TW + d], P);
+      }
+    }
+    G(_normalize_chunk)(&out[i0], acc, i1 - i0, pref, P);
   }
   free(table);
 }

@@ -270,6 +270,7 @@ extern "C" {
     ) -> i32;
 
     pub fn ark355_witness_map(ctx: *mut ark355_ctx, r1cs: *const ark355_r1cs, z: *const u8, z_len: u64, h_out: *mut u8) -> i32;
+    pub fn ark355_witness_map_dist_sim(ctx: *mut ark355_ctx, r1cs: *const ark355_r1cs, z: *const u8, z_len: u64, world: u32, h_out: *mut u8) -> i32;
     pub fn ark355_is_satisfied(ctx: *mut ark355_ctx, r1cs: *const ark355_r1cs, z: *const u8, z_len: u64, first_bad: *mut i64) -> i32;
     pub fn ark355_r1cs_mat_vec(
         ctx: *mut ark355_ctx,

@@ -38,7 +38,7 @@ SYMBOLS = [
     "ark355_ctx_create", "ark355_ctx_destroy", "ark355_last_error", "ark355_version", "ark355_sizes",
     "ark355_host_alloc", "ark355_host_free",
     "ark355_pk_load", "ark355_pk_free", "ark355_r1cs_load", "ark355_r1cs_free",
-    "ark355_r1cs_domain_size", "ark355_prove", "ark355_prove_dev", "ark355_witness_map",
+    "ark355_r1cs_domain_size", "ark355_prove", "ark355_prove_dev", "ark355_witness_map", "ark355_witness_map_dist_sim",
     "ark355_is_satisfied", "ark355_r1cs_mat_vec", "ark355_ntt_fr", "ark355_ntt_fr_dev",
     "ark355_msm_g1", "ark355_msm_g2", "ark355_bases_load", "ark355_bases_free", "ark355_msm_dev",
     "ark355_msm_dev_partial", "ark355_xyzz_sum", "ark355_fixed_base_mul", "ark355_get_timings",
@@ -134,6 +134,7 @@ class Lib:
         d.ark355_prove.argtypes = [vp, vp, vp, vp, u64, vp, vp, P(ProofRaw)]
         d.ark355_prove_dev.argtypes = [vp, vp, vp, vp, u64, vp, vp, P(ProofRaw)]
         d.ark355_witness_map.argtypes = [vp, vp, vp, u64, vp]
+        d.ark355_witness_map_dist_sim.argtypes = [vp, vp, vp, u64, C.c_uint32, vp]
         d.ark355_is_satisfied.argtypes = [vp, vp, vp, u64, P(i64)]
         d.ark355_r1cs_mat_vec.argtypes = [vp, vp, vp, u64, vp, vp, vp]
         d.ark355_ntt_fr.argtypes = [vp, i32, vp, u32, i32, i32]
@@ -423,6 +424,14 @@ class Lib:
         out = np.zeros(N * fr_size, dtype=np.uint8)
         zb, k = _buf(z)
         self.check(ctx, self.dll.ark355_witness_map(ctx, r1cs, zb, z_len, out.ctypes.data_as(C.c_void_p)))
+        return out.tobytes()
+
+    def witness_map_dist_sim(self, ctx, r1cs, z, z_len, fr_size, world):
+        """h as the `world` ranks of a sharded proof compute it, all ranks on this device (test / diagnostic entry)"""
+        N = self.dll.ark355_r1cs_domain_size(r1cs)
+        out = np.zeros(N * fr_size, dtype=np.uint8)
+        zb, k = _buf(z)
+        self.check(ctx, self.dll.ark355_witness_map_dist_sim(ctx, r1cs, zb, z_len, int(world), out.ctypes.data_as(C.c_void_p)))
         return out.tobytes()
 
     def is_satisfied(self, ctx, r1cs, z, z_len):

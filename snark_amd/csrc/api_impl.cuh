@@ -111,6 +111,17 @@ struct Api {
     ARK_CHECK_HIP(hipStreamSynchronize(st));
   }
 
+  static void witness_map_dist_sim(ark355_ctx* ctx, ProverScratch& sc, const R1csDev& r1, const uint8_t* z, uint32_t world,
+                                   uint8_t* h_out) {
+    hipStream_t st = ctx->stream;
+    sc.zx.ensure((r1.m + 4) * sizeof(Fr));
+    ARK_CHECK_HIP(hipMemcpyAsync(sc.zx.p, z, r1.m * sizeof(Fr), hipMemcpyHostToDevice, st));
+    DevBuf h(r1.N * sizeof(Fr));
+    ark355::witness_map_dist_sim<Curve>(ctx, r1, sc.zx.p, world, h.p, st);
+    ARK_CHECK_HIP(hipMemcpyAsync(h_out, h.p, r1.N * sizeof(Fr), hipMemcpyDeviceToHost, st));
+    ARK_CHECK_HIP(hipStreamSynchronize(st));
+  }
+
   static void mat_vec(ark355_ctx* ctx, ProverScratch& sc, const R1csDev& r1, const uint8_t* z, uint8_t* az,
                       uint8_t* bz, uint8_t* cz, int64_t* first_bad) {
     hipStream_t st = ctx->stream;

@@ -470,6 +470,16 @@ int32_t ark355_witness_map(ark355_ctx* ctx, const ark355_r1cs* r1, const uint8_t
   });
 }
 
+int32_t ark355_witness_map_dist_sim(ark355_ctx* ctx, const ark355_r1cs* r1, const uint8_t* z, uint64_t z_len, uint32_t world,
+                                    uint8_t* h_out) {
+  if (!ctx || !r1 || !z || !h_out) return ARK355_EINVAL;
+  if (z_len < r1->d->m) return ARK355_E_ASSIGNMENT_MISSING;
+  return guarded(ctx, [&] {
+    CtxExtra& ex = extra(ctx);
+    CURVE_DISPATCH(r1->d->curve, A::witness_map_dist_sim(ctx, ex.prover, *r1->d, z, world, h_out));
+  });
+}
+
 int32_t ark355_is_satisfied(ark355_ctx* ctx, const ark355_r1cs* r1, const uint8_t* z, uint64_t z_len,
                             int64_t* first_bad) {
   if (!ctx || !r1 || !z || !first_bad) return ARK355_EINVAL;

@@ -27,6 +27,7 @@
 #include "msm_impl.cuh"
 #include "witness_impl.cuh"
 #include "comm_impl.cuh"
+#include "witness_dist_impl.cuh"
 #include "diag_impl.cuh"
 #include <thread>
 
@@ -43,6 +44,10 @@ struct PkDev {
   uint64_t z_lo = 0, z_cnt = 0;     // of the m+4 extended a/b/l terms
   uint64_t h_lo = 0, h_cnt = 0;     // of the N-1 h terms
   uint32_t wstride = 1;             // MsmPlan::wstride of the five tables (1 = every window has its table)
+  // h_query shard in the layout of the distributed witness map (witness_dist_impl.cuh): local row k2 (M/G) + j holds the
+  // base of coefficient (shard_index M/G + j) + M k2, M = N / shard_count; the row of coefficient N - 1 (which the proof
+  // does not use) is the point at infinity.  h_cnt = M on every rank then.
+  bool h_dist = false;
   uint64_t table_bytes() const {
     return a_ext.table.bytes + b1_ext.table.bytes + b2_ext.table.bytes + h_query.table.bytes + l_ext.table.bytes;
   }
@@ -298,6 +303,7 @@ struct ProverScratch {
       if (e) (void)hipEventDestroy(e);
   }
   WitnessScratch ws;
+  DwmScratch dwm;   // one rank of the distributed witness map (sharded proofs)
   DevBuf zx;        // extended scalar vector
   DevBuf results;   // XYZZ results: A, B1, L, H (G1) then B2 (G2)
   DevBuf proof;     // raw affine proof A | B | C
@@ -496,9 +502,18 @@ static PkDev* pk_upload(const TunePolicy& pol, const ark355_pk_desc* d, hipStrea
     const uint64_t hn = pk->N ? pk->N - 1 : 0;
     shard_range(m + 4, shard_index, shard_count, &pk->z_lo, &pk->z_cnt);
     shard_range(hn, shard_index, shard_count, &pk->h_lo, &pk->h_cnt);
+    {
+      uint32_t lgN = 0;
+      while ((1ull << lgN) < pk->N) lgN++;
+      pk->h_dist = pol.shard_dist_wm != 0 && dwm_supported(lgN, shard_count);
+      if (pk->h_dist) {
+        pk->h_lo = 0;
+        pk->h_cnt = pk->N / shard_count;
+      }
+    }
     // every shard of a key uses the window size of the largest shard (see precomp_build)
     const uint64_t z_plan = shard_count > 1 ? (m + 4 + shard_count - 1) / shard_count : 0;
-    const uint64_t h_plan = shard_count > 1 ? (hn + shard_count - 1) / shard_count : 0;
+    const uint64_t h_plan = shard_count > 1 ? (pk->h_dist ? pk->h_cnt : (hn + shard_count - 1) / shard_count) : 0;
     {
       // Window stride of the five tables: 1 (a table per window) whenever that fits next to the scratch of the proving
       // contexts that will work on this key (four of them: two sort areas of 16 B per (term, window), nine N-element NTT
@@ -522,7 +537,18 @@ static PkDev* pk_upload(const TunePolicy& pol, const ark355_pk_desc* d, hipStrea
     ext(d->b_g2_query, G2, d->beta_g2, nullptr, d->delta_g2);
     precomp_build<Fq2, Fr>(pol, pk->b2_ext, (uint8_t*)stage.p + pk->z_lo * G2, pk->z_cnt, stream, z_plan, ws);
     stage.ensure((pk->h_cnt ? pk->h_cnt : 1) * G1);
-    if (pk->h_cnt) ARK_CHECK_HIP(hipMemcpy(stage.p, d->h_query + pk->h_lo * G1, pk->h_cnt * G1, hipMemcpyDefault));
+    if (pk->h_dist) {
+      const uint64_t M = pk->h_cnt, mc = M / shard_count;
+      ARK_CHECK_HIP(hipMemset(stage.p, 0, M * G1));            // (the unused coefficient N - 1: infinity)
+      for (uint32_t k2 = 0; k2 < shard_count; k2++) {
+        const uint64_t first = (uint64_t)shard_index * mc + M * k2;
+        uint64_t cnt = mc;
+        if (first + cnt > hn) cnt = hn > first ? hn - first : 0;
+        if (cnt) ARK_CHECK_HIP(hipMemcpy((uint8_t*)stage.p + (uint64_t)k2 * mc * G1, d->h_query + first * G1, cnt * G1, hipMemcpyDefault));
+      }
+    } else if (pk->h_cnt) {
+      ARK_CHECK_HIP(hipMemcpy(stage.p, d->h_query + pk->h_lo * G1, pk->h_cnt * G1, hipMemcpyDefault));
+    }
     precomp_build<Fq, Fr>(pol, pk->h_query, stage.p, pk->h_cnt, stream, h_plan, ws, pol.msm_c_h);
     // l_ext aligned with zx: ell leading infinities (instance variables carry no l term), l_query, delta_1 at
     // the -rs slot, three trailing infinities
@@ -678,7 +704,30 @@ static void prove_run(ark355_ctx* ctx, ProverScratch& sc, const PkDev& pk, const
 
     // witness map -> h
     ARK_CHECK_HIP(hipStreamWaitEvent(sW, ev[E_Z], 0));
-    void* d_h = witness_map_run<Curve>(ctx, r1, sc.zx.p, sc.ws, sW);
+    void* d_h;
+    if (pk.h_dist && ((cm && shard_mode != ARK355_SHARD_BUCKET_RING) || (!cm && pol.dwm_loopback))) {
+      // the witness map sharded like the MSMs: this rank's 1/G of every vector, three all-to-all exchanges on the
+      // witness-map stream (witness_dist_impl.cuh).  They are ordered against the prover's other collectives by data
+      // dependence (the plan check above has completed; the all-gather of the partial sums waits for the H MSM), so the one
+      // communicator serves them all.  The bucket-ring exchange interleaves its own send / receive steps with the MSMs
+      // and therefore keeps the replicated map.
+      d_h = witness_map_dist_run<Curve>(ctx, r1, sc.zx.p, sc.dwm, cm, pk.shard_count, pk.shard_index, sW, /*loopback=*/!cm);
+      if (trace_host)
+        fprintf(stderr, "[ark355] witness map distributed over %u ranks (rank %u: N / G = %llu elements per vector)%s\n", pk.shard_count,
+                pk.shard_index, (unsigned long long)(pk.N / pk.shard_count), cm ? "" : " -- LOOPBACK exchange, timing only");
+    } else {
+      d_h = witness_map_run<Curve>(ctx, r1, sc.zx.p, sc.ws, sW);
+      if (pk.h_dist) {
+        // a key shard in the distributed layout under the replicated map: pick this rank's coefficients out of h
+        const uint64_t M = pk.h_cnt;
+        const uint32_t mc = (uint32_t)(M / pk.shard_count);
+        sc.dwm.h.ensure(M * sizeof(Fr));
+        ARK_LAUNCH((dwm_gather_kernel<Fr>), dim3((uint32_t)((M + 255) / 256)), dim3(256), 0, sW, (const Fr*)d_h, sc.dwm.h.as<Fr>(), mc,
+                   pk.shard_index, M, pk.shard_count);
+        ARK_CHECK_LAUNCH();
+        d_h = sc.dwm.h.p;
+      }
+    }
     ARK_CHECK_HIP(hipEventRecord(ev[E_H], sW));
 
     // sorts.  Everything the two sorts and the five bucket sets need cleared is planned first and cleared by ONE fill

@@ -728,6 +728,42 @@ static void* ntt_run(ark355_ctx* ctx, void* data, void* scratch, uint32_t log_n,
   return src;
 }
 
+// The passes of one transform and nothing else (no coset shift, no 1/N): `batch` vectors of 2^log_n elements, vector y at
+// data + y * batch_stride with its ping-pong partner at scratch + y * batch_stride, one launch per pass.  Returns where
+// vector 0 ended up.  The distributed witness map (witness_dist_impl.cuh) runs its local N/G-point transforms with this
+// and folds every scaling into its exchange kernels.  log_n >= 3.
+template <class Curve>
+static void* ntt_passes(ark355_ctx* ctx, void* data, void* scratch, uint32_t log_n, bool inverse, hipStream_t stream,
+                        uint32_t batch = 1, uint64_t batch_stride = 0) {
+  using Fr = typename Curve::Fr;
+  ARK_REQUIRE(log_n >= 3, ARK355_EINVAL, "ntt_passes: at least eight points");
+  NttTables* t = get_ntt_tables<Curve>(ctx, log_n);
+  const std::vector<uint32_t> radices = ntt_radices(ctx->policy, log_n);
+  uint32_t s_log = 0;
+  Fr* src = (Fr*)data;
+  Fr* dst = (Fr*)scratch;
+  for (size_t pass = 0; pass < radices.size(); pass++) {
+    const uint32_t r = radices[pass];
+    NttPassArgs a{};
+    a.in = src;
+    a.out = dst;
+    a.log_n = log_n;
+    a.s_log = s_log;
+    a.p_log = ntt_p_log(log_n, r);
+    a.tw = ntt_tw_table<Fr>(t, r, inverse);
+    a.direct = ntt_direct_table<Fr>(ctx->policy, t, s_log, r, inverse);
+    a.w_lo = (inverse ? t->wi_lo : t->w_lo).template as<Fr>();
+    a.w_hi = (inverse ? t->wi_hi : t->w_hi).template as<Fr>();
+    a.lo_bits = t->lo_bits;
+    a.batch_stride = batch > 1 ? batch_stride : 0;
+    ARK_NTT_DISPATCH(r, (ntt_launch_pass<Fr, RL>(a, stream, batch)));
+    ntt_twiddle_fallback<Fr>(a, r, stream, batch);
+    s_log += r;
+    Fr* tmp = src; src = dst; dst = tmp;
+  }
+  return src;
+}
+
 // inverse NTT followed by coset NTT of the same vector (witness map: evaluations on H -> evaluations on g H), with the
 // seam fused when the first and the last pass share a radix.  Same contract as ntt_run.
 // batch > 1: `batch` vectors of the same length, vector y at data + y * batch_stride with its ping-pong partner at

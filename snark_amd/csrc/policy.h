@@ -42,6 +42,8 @@ struct TunePolicy {
   int32_t trace_host = 0;         // host wall-clock phases on stderr
   int32_t sched_explore = 3;      // samples per candidate before SCHED_AUTO latches (0: static default, no exploration)
   int32_t batch_tails = 1;        // one-stream proofs: merge / reduce / combine of the four G1 MSMs as ONE launch each
+  int32_t dwm_loopback = 0;       // DIAGNOSTIC (timing only, wrong proofs): ark355_prove_shard runs the distributed witness map of its
+                                  // rank with the exchanges as local copies -- the per-rank cost of a G-GPU proof on one GPU
   // ---- per key load
   int32_t msm_c = 0;              // window size of resident tables (0: planner)
   int32_t msm_c_h = 0;            // window size of the h_query table alone (0: same rule as the others)
@@ -50,6 +52,7 @@ struct TunePolicy {
   int32_t ba_levels = 5;
   int32_t table_stride = 0;       // 0: planner
   int64_t hbm_budget_mb = 0;      // 0: 80 % of the device
+  int32_t shard_dist_wm = 1;      // key shards: h_query in the layout of the distributed witness map when the world size allows it
   // ---- per call
   int32_t msm_seg = 0;            // entries per accumulation lane (0: msm_seg_len)
   int32_t sort_legacy = 0;
@@ -94,6 +97,8 @@ inline const TunePolicy::Field* TunePolicy::fields(int* count) {
       ARK_POLICY_FIELD32("BA_LEVELS", ba_levels),
       ARK_POLICY_FIELD32("TABLE_STRIDE", table_stride),
       ARK_POLICY_FIELD64("HBM_BUDGET_MB", hbm_budget_mb),
+      ARK_POLICY_FIELD32("SHARD_DIST_WM", shard_dist_wm),
+      ARK_POLICY_FIELD32("DWM_LOOPBACK", dwm_loopback),
       ARK_POLICY_FIELD32("MSM_SEG", msm_seg),
       ARK_POLICY_FIELD32("SORT_LEGACY", sort_legacy),
       ARK_POLICY_FIELD32("G2_INLINE", g2_inline),

@@ -33,10 +33,13 @@ r1cs_spmv_kernel(const uint32_t* __restrict__ rp_a, const uint32_t* __restrict__
                  const uint32_t* __restrict__ rp_b, const uint32_t* __restrict__ col_b, const uint32_t* __restrict__ ci_b,
                  const uint32_t* __restrict__ rp_c, const uint32_t* __restrict__ col_c, const uint32_t* __restrict__ ci_c,
                  const Fr* __restrict__ pool, const Fr* __restrict__ z, uint64_t n, uint64_t ell, uint64_t N,
-                 Fr* __restrict__ out_a, Fr* __restrict__ out_b, Fr* __restrict__ out_c) {
-  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+                 Fr* __restrict__ out_a, Fr* __restrict__ out_b, Fr* __restrict__ out_c, uint64_t row0, uint64_t row_stride) {
+  // out[j] = row (row0 + j * row_stride) for j < N: the whole domain (0, 1), or the residue class of one rank of the
+  // distributed witness map (g, G; N = rows of that class)
+  const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t mat = blockIdx.y;
-  if (i >= N) return;
+  if (j >= N) return;
+  const uint64_t i = row0 + j * row_stride;
   const uint32_t* rp = mat == 0 ? rp_a : (mat == 1 ? rp_b : rp_c);
   const uint32_t* col = mat == 0 ? col_a : (mat == 1 ? col_b : col_c);
   const uint32_t* ci = mat == 0 ? ci_a : (mat == 1 ? ci_b : ci_c);
@@ -53,7 +56,7 @@ r1cs_spmv_kernel(const uint32_t* __restrict__ rp_a, const uint32_t* __restrict__
   } else if (mat == 0 && i - n < ell) {
     acc = z[i - n];
   }
-  out[i] = acc;
+  out[j] = acc;
 }
 
 template <class Fr>
@@ -181,15 +184,17 @@ struct WitnessScratch {
 };
 
 template <class Curve>
-static void spmv_run(const R1csDev& r, const void* d_z, WitnessScratch& ws, hipStream_t stream) {
+static void spmv_run(const R1csDev& r, const void* d_z, WitnessScratch& ws, hipStream_t stream, uint64_t row0 = 0,
+                     uint64_t row_stride = 1) {
   using Fr = typename Curve::Fr;
-  ws.ensure(r.N * sizeof(Fr));
-  const uint32_t grid = (uint32_t)((r.N + 255) / 256);
+  const uint64_t rows = r.N / row_stride;
+  ws.ensure(rows * sizeof(Fr));
+  const uint32_t grid = (uint32_t)((rows + 255) / 256);
   ARK_LAUNCH((r1cs_spmv_kernel<Fr>), dim3(grid, 3), dim3(256), 0, stream, r.row_ptr[0].as<uint32_t>(),
              r.col[0].as<uint32_t>(), r.cidx[0].as<uint32_t>(), r.row_ptr[1].as<uint32_t>(), r.col[1].as<uint32_t>(),
              r.cidx[1].as<uint32_t>(), r.row_ptr[2].as<uint32_t>(), r.col[2].as<uint32_t>(), r.cidx[2].as<uint32_t>(),
-             r.pool.as<Fr>(), (const Fr*)d_z, r.n, r.ell, r.N, ws.buf[0].as<Fr>(), ws.buf[2].as<Fr>(),
-             ws.buf[4].as<Fr>());
+             r.pool.as<Fr>(), (const Fr*)d_z, r.n, r.ell, rows, ws.buf[0].as<Fr>(), ws.buf[2].as<Fr>(),
+             ws.buf[4].as<Fr>(), row0, row_stride);
   ARK_CHECK_LAUNCH();
 }
 

@@ -11,6 +11,34 @@ from oracle.c import cbase
 TD = G.Trapdoor(tau=0x1F3D5B79A8C6E4F2_0123456789ABCDEF, alpha=0xA1, beta=0xB2B2, gamma=0xC3C3C3, delta=0xD4D4D4D4)
 
 
+# Oracle keys and oracle proofs are the expensive part of the BASELINE-size tests (2^20: generator ~10 s, a CPU proof ~7 s on
+# 16 cores): one generator run per (curve, instance) and one CPU proof per (curve, instance, r, s) for the whole session.
+_KEYS = {}
+_PROOFS = {}
+_KEYS_MAX = 6          # a 2^20 BLS12-381 key is ~0.6 GB of host memory
+
+
+def oracle_key(C, inst):
+    n, ell, w, mats, z = inst
+    k = (C.name, n, ell, w)
+    if k not in _KEYS:
+        while len(_KEYS) >= _KEYS_MAX:
+            old = next(iter(_KEYS))
+            _KEYS.pop(old)
+            for pk_ in [q for q in _PROOFS if q[:4] == old]:
+                _PROOFS.pop(pk_)
+        _KEYS[k] = cbase.setup_raw_c(C, n, ell, w, mats, TD)[0]
+    return _KEYS[k]
+
+
+def oracle_prove(C, inst, zb, pk, r_, s_):
+    n, ell, w, mats, z = inst
+    k = (C.name, n, ell, w, r_, s_)
+    if k not in _PROOFS:
+        _PROOFS[k] = cbase.prove(C, n, ell, w, mats, zb, pk, r_, s_)
+    return _PROOFS[k]
+
+
 def load(lib, ctx, C, inst, pk):
     n, ell, w, mats, z = inst
     N = 1
@@ -57,7 +85,7 @@ def check_instance(lib, ctx, C, inst, rs_pairs, batch=0, inflight=4, sharded=Fal
     import time
     n, ell, w, mats, z = inst
     t0 = time.perf_counter()
-    pk, _ = cbase.setup_raw_c(C, n, ell, w, mats, TD)
+    pk = oracle_key(C, inst)
     t1 = time.perf_counter()
     zb = S._mont_bytes(C.r, z)
     sizes = lib.sizes(C.curve_id)
@@ -69,7 +97,7 @@ def check_instance(lib, ctx, C, inst, rs_pairs, batch=0, inflight=4, sharded=Fal
         proofs = []
         for r_, s_ in rs_pairs:
             got = lib.prove(ctx, pkh, rh, zb, len(z), Z.fr_canon(C, r_), Z.fr_canon(C, s_), sizes)
-            exp = cbase.prove(C, n, ell, w, mats, zb, pk, r_, s_)
+            exp = oracle_prove(C, inst, zb, pk, r_, s_)
             assert got == exp, (C.name, n, "ark355_prove vs oracle/c")
             proofs.append(got)
             if sharded:
@@ -130,7 +158,7 @@ def bases(C, group, n):
     return cbase.fixed_base(C, group, gen, ks.tobytes(), n)
 
 
-def check_resident_msm(lib, ctx, C, group, n, to_dev, seed=1):
+def check_resident_msm(lib, ctx, C, group, n, to_dev, seed=1, dists=("uniform", "equal", "boolean")):
     """ark355_bases_load + ark355_msm_dev (window tables, radix-2^28 accumulation) vs cbase.msm for the three
     distributions.  to_dev(bytes) -> (device pointer, keepalive)."""
     sz = lib.sizes(C.curve_id)
@@ -138,7 +166,7 @@ def check_resident_msm(lib, ctx, C, group, n, to_dev, seed=1):
     pts = bases(C, group, n)
     bh = lib.bases_load(ctx, C.curve_id, group, pts, n)
     try:
-        for dist in ("uniform", "equal", "boolean"):
+        for dist in dists:
             sc = scalars(C, n, dist, seed=seed * 10 + group)
             ptr, keep = to_dev(sc)
             got = lib.msm_dev(ctx, bh, ptr, n, 0, psz)
@@ -161,7 +189,9 @@ def check_ntt_full(lib, ctx, C, log_n, seed=5):
         assert got == exp, (C.name, log_n, inv, cos)
 
 
-def check_witness_map_full(lib, ctx, C, inst):
+def check_witness_map_full(lib, ctx, C, inst, dist_worlds=()):
+    """dist_worlds: also the distributed map (witness_dist_impl.cuh; all ranks on this device, ark355_witness_map_dist_sim)
+    for these world sizes, every coefficient against the same oracle vector."""
     n, ell, w, mats, z = inst
     zb = S._mont_bytes(C.r, z)
     rh = lib.r1cs_load(ctx, C.curve_id, n, ell, w, mats)
@@ -169,5 +199,8 @@ def check_witness_map_full(lib, ctx, C, inst):
         got = lib.witness_map(ctx, rh, zb, len(z), 32)
         exp = cbase.witness_map(C, n, ell, w, mats, zb)
         assert len(got) == len(exp) and got == exp, (C.name, n)
+        for world in dist_worlds:
+            got = lib.witness_map_dist_sim(ctx, rh, zb, len(z), 32, world)
+            assert got == exp, (C.name, n, "distributed over", world)
     finally:
         lib.dll.ark355_r1cs_free(rh)

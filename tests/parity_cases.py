@@ -143,6 +143,43 @@ def r1cs_case(lib, ctx, C, A, B, Cm, z, ell):
         lib.dll.ark355_r1cs_free(r1)
 
 
+def witness_map_dist_case(lib, ctx, C, A, B, Cm, z, ell, worlds):
+    """The distributed witness map (every rank 1/world of each vector, three all-to-all exchanges), all ranks simulated on
+    one device (ark355_witness_map_dist_sim): every coefficient equals the oracle's and the replicated map's."""
+    sz = lib.sizes(C.curve_id)
+    m = len(z)
+    r1 = r1cs_load_from_rows(lib, ctx, C, A, B, Cm, ell, m - ell)
+    try:
+        zb = z_bytes(C, z)
+        exp = G.witness_map(C, A, B, Cm, z, ell)
+        h = lib.witness_map(ctx, r1, zb, m, sz["fr"])
+        assert fr_vec_from_mont(C, h) == exp
+        N = lib.dll.ark355_r1cs_domain_size(r1)
+        for world in worlds:
+            if 8 * world * world > N:
+                with pytest_raises_code(lib, -1):
+                    lib.witness_map_dist_sim(ctx, r1, zb, m, sz["fr"], world)
+                continue
+            hd = lib.witness_map_dist_sim(ctx, r1, zb, m, sz["fr"], world)
+            assert hd == h, (C.name, N, world)
+    finally:
+        lib.dll.ark355_r1cs_free(r1)
+
+
+class pytest_raises_code:
+    """context manager: the library call fails with the given ark355 status code"""
+
+    def __init__(self, lib, code):
+        self.code = code
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, et, ev, tb):
+        assert ev is not None and getattr(ev, "code", None) == self.code, (et, ev)
+        return True
+
+
 def prove_case(lib, ctx, C, A, B, Cm, z, ell, td=None, rs=((0x1234567890abcdef, 0xfedcba0987654321aabbccdd),),
                verify=False):
     sz = lib.sizes(C.curve_id)

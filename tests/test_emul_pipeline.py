@@ -71,6 +71,16 @@ def test_r1cs_ops_and_witness_map(emul_lib, emul_ctx, C):
 
 
 @pytest.mark.parametrize("C", [BLS12_381, BN254], ids=lambda c: c.name)
+def test_distributed_witness_map_all_ranks_on_one_device(emul_lib, emul_ctx, C):
+    """witness_dist_impl.cuh through ark355_witness_map_dist_sim: world sizes 2, 4 (and 8 refused: 8 G^2 > N) at N = 2^7 / 2^8,
+    general coefficients and the degenerate DummyCircuit, against the oracle and the replicated map."""
+    A, B, Cm, z, ell = S.cs_to_instance(S.bench_lc_cs(C.r, 100))         # N = 128
+    pc.witness_map_dist_case(emul_lib, emul_ctx, C, A, B, Cm, z, ell, worlds=(2, 4, 8))
+    A, B, Cm, z, ell = S.mulchain_direct(C.r, 200)                       # N = 256
+    pc.witness_map_dist_case(emul_lib, emul_ctx, C, A, B, Cm, z, ell, worlds=(2, 4))
+
+
+@pytest.mark.parametrize("C", [BLS12_381, BN254], ids=lambda c: c.name)
 def test_prove_bytes_equal_oracle(emul_lib, emul_ctx, C):
     A, B, Cm, z, ell = S.mulchain_direct(C.r, 13)
     pc.prove_case(emul_lib, emul_ctx, C, A, B, Cm, z, ell, rs=((0x1234567890abcdef, 0xfedcba0987654321aabbccdd), (0, 5)))

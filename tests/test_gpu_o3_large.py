@@ -41,6 +41,11 @@ def test_s2_2p20_bn254_vs_o3(gpu_lib, gpu_ctx):
 
 @pytest.mark.parametrize("n,label", [((1 << 22) - 100, "tight N=2^22"), (1 << 22, "literal N=2^23")], ids=["tight", "literal"])
 def test_s2_2p22_bls12_381_vs_o3_whole_and_sharded(gpu_lib, n, label):
+    import os
+    if label.startswith("tight") and not os.environ.get("ARK355_TEST_EXTENDED"):
+        # 160 s of oracle work for the second 2^22-size key of the file; the N = 2^22 domain itself is covered in full by
+        # test_ntt_large_vs_o3_in_full[bls12_381-22] and test_witness_map_large_vs_o3_in_full[N=2^22]
+        pytest.skip("extended run only (ARK355_TEST_EXTENDED=1)")
     """BASELINE configs[2]: S2 at n = 2^22 - 100 (N = 2^22) and the literal n = 2^22 (N = 2^23: the other radix split of the
     NTT and the largest direct twiddle table), key from the oracle's generator: `ark355_prove` AND `ark355_prove_sharded`
     (real RCCL, world size 1, window-level and bucket-ring exchange) byte-identical to `cbase.prove`; every proof through
@@ -85,7 +90,9 @@ def test_resident_msm_vs_o3(gpu_lib, gpu_ctx, group, log_n):
         torch.cuda.synchronize()
         return d.data_ptr(), d
 
-    O.check_resident_msm(gpu_lib, gpu_ctx, BLS12_381, group, 1 << log_n, to_dev, seed=log_n)
+    # the skewed distributions at 2^20 (G1, G2); the 2^22-term MSM with uniform scalars
+    O.check_resident_msm(gpu_lib, gpu_ctx, BLS12_381, group, 1 << log_n, to_dev, seed=log_n,
+                         dists=("uniform", "equal", "boolean") if log_n <= 20 else ("uniform",))
 
 
 @pytest.mark.parametrize("C,log_n", [(BLS12_381, 21), (BLS12_381, 22), (BLS12_381, 23), (BN254, 22)],
@@ -96,7 +103,16 @@ def test_ntt_large_vs_o3_in_full(gpu_lib, gpu_ctx, C, log_n):
     O.check_ntt_full(gpu_lib, gpu_ctx, C, log_n)
 
 
-@pytest.mark.parametrize("n", [(1 << 20), (1 << 21) - 7, (1 << 22)], ids=["N=2^21", "N=2^21-tight", "N=2^23"])
+@pytest.mark.parametrize("n", [(1 << 20), (1 << 21) - 7, (1 << 22) - 7, (1 << 22)], ids=["N=2^21", "N=2^21-tight", "N=2^22", "N=2^23"])
 def test_witness_map_large_vs_o3_in_full(gpu_lib, gpu_ctx, n):
     """`ark355_witness_map` (SpMV + 7 NTTs + pointwise) against `cb_witness_map`, all N coefficients of h."""
     O.check_witness_map_full(gpu_lib, gpu_ctx, BLS12_381, S.mulchain_csr(BLS12_381.r, n))
+
+
+@pytest.mark.parametrize("C,n,worlds", [(BLS12_381, 1 << 20, (2, 8, 16)), (BLS12_381, 1 << 22, (8,)), (BN254, (1 << 19) + 5, (4,))],
+                         ids=["bls-N=2^21", "bls-N=2^23", "bn254-N=2^20"])
+def test_distributed_witness_map_vs_o3_in_full(gpu_lib, gpu_ctx, C, n, worlds):
+    """The witness map as the G ranks of a sharded proof compute it (1/G of every vector per rank, three all-to-all
+    exchanges, local N/G-point transforms; configs[2] is N = 2^23 over 8 GPUs), all ranks simulated on this GPU: every
+    coefficient of h against `cb_witness_map`."""
+    O.check_witness_map_full(gpu_lib, gpu_ctx, C, S.mulchain_csr(C.r, n), dist_worlds=worlds)

@@ -118,3 +118,40 @@ def test_c_msm_is_independent_of_the_thread_partition():
     finally:
         L.cb_set_threads(nt)
     assert outs[0] == outs[1] == outs[2]
+
+
+@pytest.mark.parametrize("C", [BLS12_381, BN254], ids=lambda c: c.name)
+def test_c_point_serializer_equals_python_serializer(C):
+    """cb_points_serialize (the encoder behind the BASELINE-size key streams of tests/test_gpu_wire_large.py) against
+    oracle/serialize.py: both groups, compressed / uncompressed, incl. infinity and both signs of y."""
+    import random
+    from oracle import serialize as Z
+    from oracle.c import cbase
+    from oracle.curves import g1, g2
+    rnd = random.Random(5)
+    for group, Gp, raw_enc, comp, unc in ((1, g1(C), Z.g1_raw, Z.g1_compressed, Z.g1_uncompressed),
+                                          (2, g2(C), Z.g2_raw, Z.g2_compressed, Z.g2_uncompressed)):
+        pts = Gp.fixed_base_muls(Gp.gen, [rnd.randrange(C.r) for _ in range(12)])
+        pts += [Gp.neg(p) for p in pts[:6]] + [None]
+        raw = b"".join(raw_enc(C, p) for p in pts)
+        assert cbase.points_serialize(C, group, raw, True) == b"".join(comp(C, p) for p in pts)
+        assert cbase.points_serialize(C, group, raw, False) == b"".join(unc(C, p) for p in pts)
+
+
+def test_c_fixed_base_window_sizes_agree():
+    """cb_fixed_base switches from 8-bit to 16-bit windows at 2^16 scalars: the long call and two short calls over the same
+    scalars give the same points (G1 and G2), incl. zero scalars."""
+    import numpy as np
+    C = BLS12_381
+    n = 1 << 16
+    rng = np.random.default_rng(7)
+    sc = rng.integers(0, 1 << 62, size=(n, 4), dtype=np.uint64)
+    sc[:, 3] &= np.uint64((1 << 60) - 1)
+    sc[5] = 0
+    sc[n - 1] = 0
+    sb = sc.astype("<u8").tobytes()
+    for group, gen in ((1, Z.g1_raw(C, C.g1_gen)), (2, Z.g2_raw(C, C.g2_gen))):
+        whole = cbase.fixed_base(C, group, gen, sb, n)
+        h = n // 2
+        halves = cbase.fixed_base(C, group, gen, sb[:h * 32], h) + cbase.fixed_base(C, group, gen, sb[h * 32:], h)
+        assert whole == halves

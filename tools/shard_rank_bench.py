@@ -33,6 +33,10 @@ def main():
     ap.add_argument("--steps", type=int, default=6)
     ap.add_argument("--curve", default="bls12_381")
     ap.add_argument("--whole", action="store_true", help="also time the unsharded proof (shard 0 of 1) for the ratio")
+    ap.add_argument("--wm", default="both", choices=["replicated", "dist", "both"],
+                    help="witness map of the rank: replicated (rounds 1-3: every rank repeats the whole map), dist (the rank's 1/G "
+                         "of the distributed map, exchanges as LOCAL copies of the same size: timing only, the sums are "
+                         "meaningless), both")
     args = ap.parse_args()
     import torch
     assert torch.cuda.is_available()
@@ -57,7 +61,17 @@ def main():
     todo = [(int(x), args.world) for x in args.ranks.split(",")]
     if args.whole:
         todo.append((0, 1))
+    variants = []
     for rank, world in todo:
+        for wm in (("replicated", "dist") if args.wm == "both" else (args.wm,)):
+            if wm == "dist" and world == 1:
+                continue
+            variants.append((rank, world, wm))
+    for rank, world, wm in variants:
+        # replicated: the key shard in the contiguous layout of rounds 1-3; dist: the layout of the distributed map and the
+        # diagnostic loopback exchange (policy DWM_LOOPBACK: ark355_prove_shard has no communicator)
+        L.ctx_set_policy(g.ctx, "SHARD_DIST_WM", 1 if wm == "dist" else 0)
+        L.ctx_set_policy(g.ctx, "DWM_LOOPBACK", 1 if wm == "dist" else 0)
         h = L.pk_load(g.ctx, cv.curve_id, pk.ell, pk.w, pk.N, pk.a_query, pk.b_g1_query, pk.b_g2_query, pk.h_query,
                       pk.l_query, pk.vk.alpha_g1, pk.beta_g1, pk.delta_g1, pk.vk.beta_g2, pk.vk.delta_g2,
                       shard=(rank, world))
@@ -76,6 +90,7 @@ def main():
             med = ts[len(ts) // 2]
             tm = {k: round(sorted(t[k] for t in tims)[len(tims) // 2], 3) for k in tims[0]}
             print(json.dumps({"what": "ark355_prove_shard, host-pinned z -> partial sums, no collective",
+                              "witness_map": wm + (" (exchanges as local copies of the same size: TIMING ONLY)" if wm == "dist" else ""),
                               "curve": args.curve, "n": n, "N": r1.domain_size, "shard": "%d/%d" % (rank, world),
                               "ms_median": round(med, 3), "ms_all": [round(x, 3) for x in ts],
                               "accumulate_ms": round(L.kernel_stats(g.ctx)["accumulate_ms"], 3),
