@@ -62,7 +62,12 @@ def parse_args():
     ap.add_argument("--no-ab", action="store_true", help="skip the in-run A/B of the schedules (after the timed region)")
     ap.add_argument("--no-micro", action="store_true", help="skip the stand-alone MSM / NTT readings (after the timed region)")
     ap.add_argument("--no-telemetry", action="store_true", help="no clock / power sampling")
+    ap.add_argument("--profile-run", action="store_true",
+                    help="for rocprofv3: nothing but preparation, warm-up and the timed region (no A/B, isolated, single-proof, "
+                         "latency or stand-alone readings), so that every proof of the trace ran under ONE schedule (ARK355_SCHED)")
     args = ap.parse_args()
+    if args.profile_run:
+        args.no_ab = args.no_micro = args.no_telemetry = args.no_cpu_baseline = True
     if args.dry_run_emul:
         args.inflight = 1                # the emulator is single-threaded
     if args.log_n is None:
@@ -397,7 +402,7 @@ def main():
             telemetry["error"] = "%s: %s" % (type(e).__name__, str(e)[:160])
     # which of the proving streams share an in-order hardware queue of the runtime (idle device; see ark355_diag_streams)
     stream_map = None
-    if not emul and rank == 0:
+    if not emul and rank == 0 and not args.profile_run:
         try:
             # GPU-side cost of a dispatch in an in-order stream on THIS box (ark355_diag_dispatch): the fingerprint that
             # separates the boxes of the pool -- a few us on most, 50-90 us on some, where everything but the long
@@ -503,7 +508,7 @@ def main():
     # are ISOLATED kernel times -- the box-independent check of the kernels themselves ("kernels equal, overlap slower" shows
     # at a glance), and the clean source of the secondary metrics (MSM scalar-mul/s, NTT elements/s).
     isolated = None
-    if not shard and not emul and rank == 0:
+    if not shard and not emul and rank == 0 and not args.profile_run:
         g.lib.ctx_set_policy(g.ctx, "SCHED", 0)
         acc, tms = [], []
         for _ in range(3):
@@ -529,12 +534,12 @@ def main():
     # schedule choice for the "alone" class has latched, then three for the uncontended launch duration of the dominant
     # kernel (with several proofs in flight its launches share the chip with the other proofs' kernels)
     solo = None
-    if not shard and pkh is not None and not emul:
+    if not shard and pkh is not None and not emul and not args.profile_run:
         for _ in range(16):
             if g.lib.sched_info(g.ctx, pkh, False)["latched"] != "auto":
                 break
             prove_on(g.ctx, rnd.randrange(cv.r), rnd.randrange(cv.r))
-    if not shard and len(ctxs) > 1:
+    if not shard and len(ctxs) > 1 and not args.profile_run:
         solo_rec = [0.0, 0, 0]
         for _ in range(3):
             prove_on(g.ctx, rnd.randrange(cv.r), rnd.randrange(cv.r))
@@ -552,7 +557,7 @@ def main():
     latency = None
     # (a sharded proof is a collective: with several ranks rank 0 cannot prove on its own -- there every step already IS a
     # single proof from start to finish, so ms_per_step is the latency)
-    if rank == 0 and not (shard and world > 1) and (not emul or os.environ.get('ARK355_BENCH_EMUL_LATENCY')):
+    if rank == 0 and not (shard and world > 1) and not args.profile_run and (not emul or os.environ.get('ARK355_BENCH_EMUL_LATENCY')):
         import ctypes
         ptr = ctypes.c_void_p()
         assert g.lib.dll.ark355_host_alloc(len(zb), ctypes.byref(ptr)) == 0
@@ -701,7 +706,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args.curve)
         if sampler is not None:
             telemetry["host_at_end"] = GT.host_counters()
-        if not emul:
+        if not emul and not args.profile_run:
             try:
                 telemetry["dispatch_gap_after"] = g.lib.diag_dispatch(g.ctx)
             except Exception as e:                            # noqa: BLE001
