@@ -426,14 +426,16 @@ def main():
     if not shard and pkh is not None and not emul:
         t_c = time.perf_counter()
         rounds = 0
-        per_round = 6                       # one exploration phase of the in-flight class is 8 + 16 completions
-        while rounds < 6:
-            run(per_round, None, per_worker=True)
+        # the in-flight class explores in four phases of 8 + 16 completions: ONE continuous run of proofs (the ramp-down and
+        # ramp-up between separate runs would sit inside the scored windows), then shorter runs until it has latched
+        per_round = max(1, -(-96 // len(ctxs)))
+        while rounds < 4:
+            run(per_round if rounds == 0 else max(1, per_round // 4), None, per_worker=True)
             rounds += 1
             info = g.lib.sched_info(g.ctx, pkh, len(ctxs) > 1)
             if info["latched"] != "auto" or g.lib.ctx_get_policy(g.ctx, "SCHED") >= 0:
                 break
-        calib = {"proofs": rounds * per_round * len(ctxs), "seconds": round(time.perf_counter() - t_c, 3),
+        calib = {"proofs": (per_round + (rounds - 1) * max(1, per_round // 4)) * len(ctxs), "seconds": round(time.perf_counter() - t_c, 3),
                  "in_flight" if len(ctxs) > 1 else "alone": g.lib.sched_info(g.ctx, pkh, len(ctxs) > 1)}
         stage("schedule calibration done: %s" % json.dumps(calib))
     run(max(1, -(-args.warmup // len(ctxs))) if args.warmup else 0, None, per_worker=True)

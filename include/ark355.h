@@ -223,14 +223,15 @@ int32_t ark355_prove_sharded_dev(ark355_ctx* ctx, ark355_comm* comm, const ark35
  *                              (uncompressed form; compressed points are on the curve by construction) AND membership in
  *                              the prime-order subgroup ([r]P = O: BLS12-381 G1/G2, BN254 G2) -- use it for anything that
  *                              comes from an untrusted party (proofs: a small-order component vanishes in the pairing, so
- *                              without the test one proof has many accepted encodings); an encoding whose infinity flag
- *                              is set must be all-zero otherwise;
+ *                              without the test one proof has many accepted encodings);
  *   ARK355_VALIDATE_CURVE (2)  the same without the subgroup test (a 255-bit scalar multiplication per point): the
  *                              explicit opt-out for key material from a trusted source;
  *   ARK355_VALIDATE_NONE (0)   Validate::No.
  * Flag combinations upstream rejects in every mode are rejected in every mode here: BLS12-381 sort bit without the
  * compressed bit or together with the infinity bit, a compressed bit that does not match the requested form
- * (ark-bls12-381 EncodingFlags::get_flags); BN254 both flag bits set (ark-ec SWFlags::from_u8). */
+ * (ark-bls12-381 EncodingFlags::get_flags); BN254 both flag bits set (ark-ec SWFlags::from_u8).  Bytes under an infinity
+ * flag, in every mode as upstream: BLS12-381 must be all zero (its point readers refuse anything else), BN254 must be
+ * reduced field elements and are otherwise ignored (ark-ec's generic reader returns the identity). */
 #define ARK355_VALIDATE_NONE 0
 #define ARK355_VALIDATE_FULL 1
 #define ARK355_VALIDATE_CURVE 2

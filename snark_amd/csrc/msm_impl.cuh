@@ -1981,7 +1981,7 @@ static void msm_reduce_phase(ark355_ctx* ctx, const MsmSort& s, MsmBuckets& b, X
 
 // Phase 2 of `count` (<= TAIL_BATCH_MAX) G1 MSMs whose accumulations have been queued on `stream`, as one launch per
 // step.  Returns false -- nothing queued -- when the MSMs cannot share launches (different bucket layouts, an empty one,
-// the lazy-flush build, the two-level reduction of very large bucket sets): the caller then runs msm_reduce_phase per MSM.
+// the two-level reduction of very large bucket sets): the caller then runs msm_reduce_phase per MSM.
 template <class F>
 static bool msm_reduce_phase_batch(ark355_ctx* ctx, int count, const MsmSort* const* sorts, MsmBuckets* const* bks,
                                    XYZZ<F>* const* outs, hipStream_t stream) {
@@ -1994,7 +1994,7 @@ static bool msm_reduce_phase_batch(ark355_ctx* ctx, int count, const MsmSort* co
   if (p0.key_windows > 64) return false;
   for (int i = 0; i < count; i++) {
     const MsmPlan& p = sorts[i]->plan;
-    if (p.n == 0 || bks[i]->lazy28) return false;
+    if (p.n == 0) return false;
     if (p.total_buckets != p0.total_buckets || p.buckets_per_window != p0.buckets_per_window || p.key_windows != p0.key_windows ||
         p.c != p0.c)
       return false;
@@ -2002,6 +2002,19 @@ static bool msm_reduce_phase_batch(ark355_ctx* ctx, int count, const MsmSort* co
   const uint32_t grid_b = (p0.total_buckets + MSM_THREADS - 1) / MSM_THREADS;
   const uint32_t chunks = (p0.buckets_per_window + MSM_RED_K - 1) / MSM_RED_K;
   const uint32_t blocks_per_window = (chunks + MSM_THREADS - 1) / MSM_THREADS;
+  for (int i = 0; i < count; i++) {
+    MsmBuckets& b = *bks[i];
+    if (!b.lazy28) continue;
+    // lazy-flush build (ARK_LAZY_FLUSH): the runs were stored as raw 28-bit limbs; convert them in front of the merge
+    using S = msm_slot28<F>;
+    using Fq = Fp<typename S::P>;
+    const uint64_t lanes = ((uint64_t)p0.total_buckets + 2ull * b.segs) * S::COORDS;
+    ARK_LAUNCH((msm_unlazy28_kernel<typename S::P, S::COORDS>), dim3((uint32_t)((lanes + 255) / 256)), dim3(256), 0, stream,
+               b.raw28.as<uint32_t>(), p0.total_buckets, b.segs, b.head_key.as<uint32_t>(), b.tail_key.as<uint32_t>(),
+               b.buckets.as<Fq>(), b.head.as<Fq>(), b.tail.as<Fq>());
+    ARK_CHECK_LAUNCH();
+    b.lazy28 = false;
+  }
   TailBatch<F> tb;
   memset(&tb, 0, sizeof(tb));
   uint32_t max_heavy_all = 1;

@@ -204,7 +204,16 @@ struct Wire {
     read_flags(in, size, &inf, &sign, &cbit);
     if (!flags_ok(compressed, inf, sign, cbit)) return WIRE_BAD_FLAGS;
     if (inf) {
-      if (validate && !payload_is_zero(in, size)) return WIRE_BAD_FLAGS;
+      // What upstream does with the bytes under an infinity flag differs by curve and does NOT depend on the validation mode:
+      // ark-bls12-381's own point readers (curves/util.rs read_g1_* / read_g2_*) refuse a non-zero payload; ark-ec's generic
+      // short-Weierstrass reader (BN254) parses the coordinates as field elements -- they must be reduced -- and then returns
+      // the identity whatever they hold.
+      if (BLS) {
+        if (!payload_is_zero(in, size)) return WIRE_BAD_FLAGS;
+      } else {
+        if (!is_reduced(limbs_from_bytes(in, FIRST_MASK, compressed ? LAST_MASK : 0xFF))) return WIRE_NOT_REDUCED;
+        if (!compressed && !is_reduced(limbs_from_bytes(in + NB, 0xFF, LAST_MASK))) return WIRE_NOT_REDUCED;
+      }
       *out = Affine<Fq>::inf();
       return WIRE_OK;
     }
@@ -233,7 +242,14 @@ struct Wire {
     read_flags(in, size, &inf, &sign, &cbit);
     if (!flags_ok(compressed, inf, sign, cbit)) return WIRE_BAD_FLAGS;
     if (inf) {
-      if (validate && !payload_is_zero(in, size)) return WIRE_BAD_FLAGS;
+      if (BLS) {                     // (see g1_decode)
+        if (!payload_is_zero(in, size)) return WIRE_BAD_FLAGS;
+      } else {
+        const int nc = compressed ? 2 : 4;
+        for (int k = 0; k < nc; k++)
+          if (!is_reduced(limbs_from_bytes(in + (size_t)k * NB, (k == 0) ? FIRST_MASK : 0xFF, (k == nc - 1) ? LAST_MASK : 0xFF)))
+            return WIRE_NOT_REDUCED;
+      }
       *out = Affine<Fq2>::inf();
       return WIRE_OK;
     }

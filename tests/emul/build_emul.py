@@ -29,6 +29,17 @@ def build(force=False, extra_flags=(), tag=""):
     out = OUT if not tag else OUT.replace(".so", "_%s.so" % tag)
     if not force and os.path.exists(out) and os.path.getmtime(out) >= newest_src():
         return out
+    # several processes may get here at once (the ranks of a multi-process test after a source edit): one builds, the others
+    # wait for the lock and find the library fresh; the library appears atomically (os.replace), never half written
+    import fcntl
+    with open(out + ".lock", "w") as lk:
+        fcntl.flock(lk, fcntl.LOCK_EX)
+        if not force and os.path.exists(out) and os.path.getmtime(out) >= newest_src():
+            return out
+        return _build_locked(out, extra_flags, tag)
+
+
+def _build_locked(out, extra_flags, tag):
     objs = []
     flags = list(extra_flags) + ["-O2", "-std=c++17", "-fPIC", "-DARK_EMUL", "-DARK_MSM_HEAVY_SPAN=2", "-DARK_MSM_HEAVY_GRID=3u", "-DARK_MSM_TWO_LEVEL_MIN=64u", "-I", HERE, "-I", CSRC, "-w"]
 
@@ -39,7 +50,9 @@ def build(force=False, extra_flags=(), tag=""):
 
     with ThreadPoolExecutor(4) as ex:
         objs = list(ex.map(cc, SRCS))
-    subprocess.check_call(["g++", "-shared", "-Wl,-Bsymbolic", "-o", out, *objs, "-lpthread", "-lrt"])
+    tmp = out + ".tmp.%d" % os.getpid()
+    subprocess.check_call(["g++", "-shared", "-Wl,-Bsymbolic", "-o", tmp, *objs, "-lpthread", "-lrt"])
+    os.replace(tmp, out)
     return out
 
 

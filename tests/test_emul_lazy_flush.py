@@ -52,3 +52,12 @@ def test_lazy_flush_large_window_two_level_reduction(lazy_lib, lazy_ctx):
     with lazy_lib.policy(lazy_ctx, MSM_C=13, MSM_SEG=37):
         O.check_resident_msm(lazy_lib, lazy_ctx, BLS12_381, 1, 1100, _to_dev, seed=5)
         O.check_resident_msm(lazy_lib, lazy_ctx, BLS12_381, 2, 1050, _to_dev, seed=6)
+
+
+def test_lazy_flush_one_stream_batched_tails(lazy_lib, lazy_ctx):
+    """A one-stream proof of the lazy-flush build: the raw runs are converted in front of the BATCHED G1 tails
+    (msm_reduce_phase_batch) -- same bytes as the oracle, incl. the heavy buckets of the all-equal DummyCircuit."""
+    C = BLS12_381
+    with lazy_lib.policy(lazy_ctx, SCHED=0):
+        pc.prove_case(lazy_lib, lazy_ctx, C, *S.mulchain_direct(C.r, 29), rs=((7, 9),))
+        pc.prove_case(lazy_lib, lazy_ctx, C, *S.cs_to_instance(S.dummy_cs(C.r, 40)), rs=((3, 4),))
