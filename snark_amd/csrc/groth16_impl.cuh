@@ -101,8 +101,8 @@ static inline void wait_event_polite(hipEvent_t ev, bool spin, double expect_ms 
 //     proofs running beside it; the tuner latched the schedule that the bench's own throughput A/B then showed to be 4 %
 //     slower).  The class therefore explores in PHASES: every proof started during a phase runs the phase's candidate, the
 //     first SKIP completions of a phase are ignored (proofs of the previous phase are still draining), and the phase's
-//     score is the time per completion over the next 4 * SCHED_EXPLORE + 4 completions -- throughput, measured the way
-//     bench.py measures it.  The static default (one stream) runs the first AND the last phase (its better one counts) and is
+//     score is the mean wall time of the next 4 * SCHED_EXPLORE + 4 proofs -- in a HOMOGENEOUS phase throughput is the
+//     number of proofs in flight over exactly that.  The static default (one stream) runs the first AND the last phase (its better one counts) and is
 //     only abandoned for a candidate that beats it by 5 %.
 // A context's first proof of a shape (allocations, table builds) is neither explored nor recorded.  The spinning wait is
 // no candidate of the automatic choice (it costs a host core per proof in flight); policy SCHED = 3 forces it.
@@ -117,7 +117,7 @@ struct SchedTuner {
     int cand[SCHED_COUNT] = {};
     // in-flight classes
     uint32_t phase = 0, phase_done = 0;
-    Clock::time_point t_mark;
+    double phase_sum = 0.0;
   };
   std::mutex mu;
   std::map<uint64_t, Entry> entries;
@@ -171,15 +171,20 @@ struct SchedTuner {
       if (e.phase >= e.ncand || variant != e.cand[e.phase]) return;       // a straggler of an earlier phase
       const uint32_t len = phase_len(explore_n);
       e.phase_done++;
-      if (e.phase_done == PHASE_SKIP) e.t_mark = Clock::now();
+      if (e.phase_done <= PHASE_SKIP) return;
+      // The score of a phase is the SUMMED wall time of its scored proofs.  Inside a phase every proof in flight runs the
+      // same schedule, and with threads that start their next proof as soon as one returns, throughput = proofs in flight /
+      // mean latency -- so the mean latency of a homogeneous phase orders the schedules exactly as throughput does.  (The first
+      // version timed the span between the 8th and the 24th completion: proofs in flight complete in lockstep waves of four,
+      // and where the window's ends fell inside a wave moved the reading by +-6 % -- run D latched a schedule on a 21.7 ms
+      // phase whose timed region then ran at 23.7 ms.)
+      e.phase_sum += ms;
       if (e.phase_done < PHASE_SKIP + len) return;
-      {
-        const double span = std::chrono::duration<double, std::milli>(Clock::now() - e.t_mark).count();
-        if (e.done[variant] == 0 || span < e.sum_ms[variant]) e.sum_ms[variant] = span;      // a schedule's best phase counts
-        e.done[variant] = len;
-      }
+      if (e.done[variant] == 0 || e.phase_sum < e.sum_ms[variant]) e.sum_ms[variant] = e.phase_sum;      // a schedule's best phase counts
+      e.done[variant] = len;
       e.phase++;
       e.phase_done = 0;
+      e.phase_sum = 0.0;
       if (e.phase < e.ncand) return;
       int best = -1;
       for (uint32_t i = 0; i < e.ncand; i++)
@@ -210,7 +215,7 @@ struct SchedTuner {
     std::lock_guard<std::mutex> lk(mu);
     entries.clear();
   }
-  // mean_ms: alone = mean wall time of a proof; in flight = time per completed proof over the scored part of the phase
+  // mean_ms: mean wall time of a proof (in flight: over the scored proofs of the schedule's best phase)
   bool info(uint64_t k, int* latched, double mean_ms[SCHED_COUNT], uint32_t samples[SCHED_COUNT]) {
     std::lock_guard<std::mutex> lk(mu);
     auto it = entries.find(k);
@@ -677,7 +682,7 @@ static void prove_run(ark355_ctx* ctx, ProverScratch& sc, const PkDev& pk, const
         ARK_REQUIRE(all[4 * (size_t)g + k] == mine[k], ARK355_EINVAL,
                     "key shards of different ranks were planned with different window sizes / table strides");
   }
-  enum { E_START, E_Z, E_ZS, E_H, E_SORT0, E_SORT1, E_SORT2, E_ACC_DONE0, E_END = E_ACC_DONE0 + 5, E_COUNT };
+  enum { E_START, E_Z, E_ZS, E_H, E_SORT0, E_SORT1, E_SORT2, E_G2T, E_ACC_DONE0, E_END = E_ACC_DONE0 + 5, E_COUNT };
   static_assert(E_COUNT + 10 <= ProverScratch::N_EVENTS, "event pool too small");
   sc.ensure_events();
   hipEvent_t* ev = sc.events;
@@ -841,7 +846,20 @@ static void prove_run(ark355_ctx* ctx, ProverScratch& sc, const PkDev& pk, const
       }
     }
     if (batch_tails) {
-      msm_reduce_phase<Fq2>(ctx, sc.sortZ, sc.bkB2, g2res, 0, sR);
+      // A one-stream proof that is ALONE on the device has nobody to fill the gaps of its latency-bound tails: its G2 tails
+      // (the longest chain: merge + reduction + combination on lane pairs, 1.9 ms at 2^20) go to the context's reduction
+      // stream and run underneath the four G1 accumulations; the proof's stream picks the result up before its last copy.
+      // With other proofs in flight everything stays on the one stream (a second stream per proof is exactly what the
+      // one-stream schedule exists to avoid).  Policy SIDE_G2_TAILS=0: always on the proof's stream.
+      const bool side_g2 = !concurrent && pol.side_g2_tails != 0;
+      if (side_g2) {
+        sc.ensure_streams(pol.stream_prio != 0);
+        ARK_CHECK_HIP(hipStreamWaitEvent(sc.sR, ev[E_ACC_DONE0 + 0], 0));
+        msm_reduce_phase<Fq2>(ctx, sc.sortZ, sc.bkB2, g2res, 0, sc.sR);
+        ARK_CHECK_HIP(hipEventRecord(ev[E_G2T], sc.sR));
+      } else {
+        msm_reduce_phase<Fq2>(ctx, sc.sortZ, sc.bkB2, g2res, 0, sR);
+      }
       const MsmSort* sorts[4] = {&sc.sortZ, &sc.sortZ, &sc.sortZ, &sc.sortH};
       MsmBuckets* bks[4] = {&sc.bkA, &sc.bkB1, &sc.bkL, &sc.bkH};
       XYZZ<Fq>* outs[4] = {g1res + 0, g1res + 1, g1res + 2, g1res + 3};
@@ -849,6 +867,7 @@ static void prove_run(ark355_ctx* ctx, ProverScratch& sc, const PkDev& pk, const
       if (!batched)
         for (int i = 0; i < 4; i++) msm_reduce_phase<Fq>(ctx, *sorts[i], *bks[i], outs[i], 0, sR);
       if (trace_host) fprintf(stderr, "[ark355] G1 tails: %s\n", batched ? "one launch per step for the four MSMs" : "per MSM");
+      if (side_g2) ARK_CHECK_HIP(hipStreamWaitEvent(sR, ev[E_G2T], 0));
     }
 
     if (out) memset(out, 0, sizeof(*out));
