@@ -716,20 +716,25 @@ static void prove_run(ark355_ctx* ctx, ProverScratch& sc, const PkDev& pk, const
     const uint64_t s_lo = pk.z_lo < m ? pk.z_lo : m;
     const uint64_t s_hi = (pk.z_lo + pk.z_cnt) < m ? (pk.z_lo + pk.z_cnt) : m;
     const bool split = pk.shard_count > 1 && (s_lo > 0 || s_hi < m);
-    auto copy_z = [&](uint64_t lo, uint64_t hi) {
+    auto copy_z = [&](uint64_t lo, uint64_t hi, hipStream_t st) {
       if (hi > lo)
-        ARK_CHECK_HIP(hipMemcpyAsync((uint8_t*)sc.zx.p + lo * sizeof(Fr), (const uint8_t*)z_src + lo * sizeof(Fr), (hi - lo) * sizeof(Fr), zkind, sM));
+        ARK_CHECK_HIP(hipMemcpyAsync((uint8_t*)sc.zx.p + lo * sizeof(Fr), (const uint8_t*)z_src + lo * sizeof(Fr), (hi - lo) * sizeof(Fr), zkind, st));
     };
-    if (split) copy_z(s_lo, s_hi);
-    else copy_z(0, m);
+    if (split) copy_z(s_lo, s_hi, sM);
+    else copy_z(0, m, sM);
     ARK_CHECK_HIP(hipMemcpyAsync((uint8_t*)sc.zx.p + m * sizeof(Fr), stg, sizeof(tail), hipMemcpyHostToDevice, sM));
     ARK_CHECK_HIP(hipMemcpyAsync(sc.rs.p, stg + sizeof(tail), sizeof(rs_c), hipMemcpyHostToDevice, sM));
     ARK_CHECK_HIP(hipEventRecord(ev[E_ZS], sM));
     if (split) {
-      copy_z(0, s_lo);
-      copy_z(s_hi, m);
+      // the rest travels on the WITNESS-MAP stream (its only consumer): the context's stream carries the accumulations, which
+      // must not queue up behind 2 ms of copies they do not need
+      ARK_CHECK_HIP(hipStreamWaitEvent(sW, ev[E_ZS], 0));
+      copy_z(0, s_lo, sW);
+      copy_z(s_hi, m, sW);
+      ARK_CHECK_HIP(hipEventRecord(ev[E_Z], sW));
+    } else {
+      ARK_CHECK_HIP(hipEventRecord(ev[E_Z], sM));
     }
-    ARK_CHECK_HIP(hipEventRecord(ev[E_Z], sM));
 
     // witness map -> h
     ARK_CHECK_HIP(hipStreamWaitEvent(sW, ev[E_Z], 0));

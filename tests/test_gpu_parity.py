@@ -259,6 +259,20 @@ def test_prove_with_window_17_negating_high_scalars(gpu_lib, gpu_ctx, gpu_policy
     pc.prove_case(gpu_lib, gpu_ctx, C, A, B, Cm, z, ell, rs=((C.r - 3, 12345),))
 
 
+@pytest.mark.parametrize("batch,side", [(1, 1), (1, 0), (0, 0)], ids=["batched+side", "batched", "per-msm"])
+@pytest.mark.parametrize("circuit", ["mulchain", "dummy"])
+def test_one_stream_tail_variants(gpu_lib, gpu_ctx, gpu_policy, circuit, batch, side):
+    """A one-stream proof: the four G1 tails as one launch per step (policy BATCH_TAILS) and -- the proof being alone on the
+    device -- the G2 tails on a side stream underneath the G1 accumulations (SIDE_G2_TAILS), against the per-MSM tails of
+    rounds 1-3; uniform scalars and the all-equal DummyCircuit (heavy buckets).  Proof bytes == oracle every way."""
+    gpu_policy.setenv("ARK355_SCHED", "0")
+    gpu_policy.setenv("ARK355_BATCH_TAILS", str(batch))
+    gpu_policy.setenv("ARK355_SIDE_G2_TAILS", str(side))
+    C = BLS12_381
+    inst = S.mulchain_direct(C.r, 700) if circuit == "mulchain" else S.cs_to_instance(S.dummy_cs(C.r, 900))
+    pc.prove_case(gpu_lib, gpu_ctx, C, *inst, rs=((11, 0xABCDEF),))
+
+
 @pytest.mark.parametrize("serial", ["1", "0"])
 def test_prove_one_stream_schedule(gpu_lib, gpu_ctx, gpu_policy, serial):
     """The schedule prove_run picks with other proofs in flight (one stream) and the one it picks for a proof alone (five
