@@ -227,6 +227,7 @@ def micro_readings(g, cv, pk, torch, np, dev_sync, rnd):
 
 
 _T0 = time.perf_counter()
+_JSON_FD = None
 
 
 def stage(msg):
@@ -237,6 +238,13 @@ def stage(msg):
 
 def main():
     args = parse_args()
+    # stdout carries ONE line, the JSON record: whatever the libraries underneath print there (RCCL announces its version on
+    # stdout when a communicator is created) goes to stderr instead, and the record is written to the saved descriptor
+    global _JSON_FD
+    if _JSON_FD is None and not (args.gpus > 1 and "WORLD_SIZE" not in os.environ):
+        sys.stdout.flush()
+        _JSON_FD = os.dup(1)
+        os.dup2(2, 1)
     wd = os.environ.get("ARK355_BENCH_WATCHDOG")
     if wd:                                   # diagnostic: dump every thread's Python stack and exit if the run takes longer
         import faulthandler
@@ -713,7 +721,8 @@ def main():
                 telemetry["dispatch_gap_after"] = g.lib.diag_dispatch(g.ctx)
             except Exception as e:                            # noqa: BLE001
                 telemetry["dispatch_gap_after"] = {"error": str(e)[:160]}
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(_JSON_FD if _JSON_FD is not None else 1, (json.dumps(out) + "\n").encode())
     if sampler is not None:
         sampler.stop()
     for c in ctxs[1:]:
