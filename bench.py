@@ -436,7 +436,7 @@ def main():
         rounds = 0
         # the in-flight class explores in four phases of 8 + 16 completions: ONE continuous run of proofs (the ramp-down and
         # ramp-up between separate runs would sit inside the scored windows), then shorter runs until it has latched
-        per_round = max(1, -(-96 // len(ctxs)))
+        per_round = max(1, -(-(96 + 4 * len(ctxs)) // len(ctxs)))      # four phases of 24 completions + the stragglers between them
         while rounds < 4:
             run(per_round if rounds == 0 else max(1, per_round // 4), None, per_worker=True)
             rounds += 1

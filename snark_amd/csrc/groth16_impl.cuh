@@ -172,9 +172,9 @@ struct SchedTuner {
       const uint32_t len = phase_len(explore_n);
       e.phase_done++;
       if (e.phase_done <= PHASE_SKIP) return;
-      // The score of a phase is the SUMMED wall time of its scored proofs.  Inside a phase every proof in flight runs the
-      // same schedule, and with threads that start their next proof as soon as one returns, throughput = proofs in flight /
-      // mean latency -- so the mean latency of a homogeneous phase orders the schedules exactly as throughput does.  (The first
+      // The score of a phase is the summed (wall time / proofs in flight) of its scored proofs (prove_run divides).  Inside a
+      // phase every proof in flight runs the same schedule, and with threads that start their next proof as soon as one
+      // returns, throughput = proofs in flight / mean latency -- so this orders the schedules exactly as throughput does.  (The first
       // version timed the span between the 8th and the 24th completion: proofs in flight complete in lockstep waves of four,
       // and where the window's ends fell inside a wave moved the reading by +-6 % -- run D latched a schedule on a 21.7 ms
       // phase whose timed region then ran at 23.7 ms.)
@@ -220,7 +220,8 @@ struct SchedTuner {
     std::lock_guard<std::mutex> lk(mu);
     entries.clear();
   }
-  // mean_ms: mean wall time of a proof (in flight: over the scored proofs of the schedule's best phase)
+  // mean_ms: alone = mean wall time of a proof; in flight = mean of (wall time / proofs sharing the device) over the scored
+  // proofs of the schedule's best phase, i.e. an estimate of the time per proof
   bool info(uint64_t k, int* latched, double mean_ms[SCHED_COUNT], uint32_t samples[SCHED_COUNT]) {
     std::lock_guard<std::mutex> lk(mu);
     auto it = entries.find(k);
@@ -953,8 +954,18 @@ static void prove_run(ark355_ctx* ctx, ProverScratch& sc, const PkDev& pk, const
       }
     }
     if (exploring) {
-      if (!concurrent && inflight.c.load() > 1) SchedTuner::of(ctx->device).unstart(tune_key, sched);
-      else SchedTuner::of(ctx->device).report(tune_key, concurrent, sched, since(t_enter), pol.sched_explore, static_sched);
+      const int now_in_flight = inflight.c.load();
+      if (!concurrent && now_in_flight > 1) {
+        SchedTuner::of(ctx->device).unstart(tune_key, sched);
+      } else {
+        // in flight: the proof's wall time over the number of proofs that shared the device with it (mean of the counts at its
+        // start and at its end) -- an estimate of the time per proof that does not reward a phase for running while the
+        // caller's batch ramps down (run G: six in flight, a phase at the end of a batch read 107 ms of latency against
+        // 129 ms and was latched; the timed region then ran 7 % slower)
+        const double share = concurrent ? 0.5 * (double)(inflight.mine + now_in_flight) : 1.0;
+        SchedTuner::of(ctx->device).report(tune_key, concurrent, sched, since(t_enter) / (share < 1.0 ? 1.0 : share), pol.sched_explore,
+                                           static_sched);
+      }
     }
     auto el = [&](hipEvent_t a, hipEvent_t b) {
       float ms = 0;
