@@ -1,7 +1,7 @@
 // TEST INFRASTRUCTURE ONLY -- see rccl_emul.h.  One shared-memory segment per communicator:
 //   header (world, per-rank "joined" flags) + world*world mailboxes, mailbox (src -> dst) = {full flag, length, data}.
 // Sends and receives are queued while a group is open and progressed together at ncclGroupEnd (a blocking
-// call outside a group is a group of one), which is what makes a ring step (send to the right, receive from the left)
+// call outside a group is a group of one; several operations with one peer complete in posting order), which is what makes a ring step (send to the right, receive from the left)
 // deadlock-free exactly as in RCCL.
 #include "rccl_emul.h"
 
@@ -68,9 +68,17 @@ ncclResult_t progress(emuNcclComm* c) {
   const double deadline = now_s() + 300.0;
   for (;;) {
     bool all_done = true, moved = false;
+    // Several sends to (receives from) ONE peer inside a group are matched in the order they were posted, as in RCCL: only the
+    // first unfinished send / receive per peer may touch the pair's mailbox in a pass.  (Without this, a later send could slip
+    // into a mailbox that the peer emptied between two checks of the same pass and overtake an earlier one -- the all-to-all of
+    // the distributed witness map posts three sends per peer and hit exactly that about once in six runs at world size 8.)
+    bool send_busy[MAX_WORLD] = {}, recv_busy[MAX_WORLD] = {};
     for (Op& op : c->pending) {
       if (op.remaining == 0) continue;
       all_done = false;
+      bool* busy = op.send ? send_busy : recv_busy;
+      if (busy[op.peer]) continue;
+      busy[op.peer] = true;
       if (op.send) {
         Mailbox& b = box(c, c->rank, op.peer);
         if (b.full.load(std::memory_order_acquire)) continue;

@@ -84,6 +84,8 @@ def _worker(rank, world, port, n, key_path, modes, whole, q, stride_on_rank1=Non
                   for m in modes]
         proof_w = proofs[0]
         ok = all(p == closed for p in proofs)
+        if not ok:
+            sys.stderr.write("[rank %d] proofs that differ from the closed form: %s\n" % (rank, [m for m, p in zip(modes, proofs) if p != closed]))
         if rank == 0 and whole:
             # single-device proof of the same statement
             ok = ok and (g.prove(pk, r1, z, r=12345, s=67890) == closed)
