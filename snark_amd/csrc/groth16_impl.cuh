@@ -531,7 +531,10 @@ static void prove_run(ark355_ctx* ctx, ProverScratch& sc, const PkDev& pk, const
     // checked" flag could differ between ranks (one rank reloaded its shard, or failed before it set the flag), and then
     // only some ranks would enter this all-gather while the others went on to the ring steps -- mismatched collectives on
     // one communicator.  16 bytes per rank and one stream synchronise: ~50 us against a proof of tens of milliseconds.
-    const uint32_t mine[4] = {pk.a_ext.plan.c, pk.a_ext.plan.wstride, pk.h_query.plan.c, pk.h_query.plan.wstride};
+    // (the layout of the h_query shard rides along: a rank that loaded its shard with policy SHARD_DIST_WM = 0 would skip the
+    // witness map's all-to-alls while the others wait in them)
+    const uint32_t mine[4] = {pk.a_ext.plan.c, pk.a_ext.plan.wstride, pk.h_query.plan.c,
+                              pk.h_query.plan.wstride | (pk.h_dist ? 0x10000u : 0u)};
     cm->gather.ensure(sizeof(mine) * (size_t)(cm->world + 1));
     uint8_t* d_mine = cm->gather.as<uint8_t>() + sizeof(mine) * (size_t)cm->world;
     uint8_t* stg = static_cast<uint8_t*>(sc.stage());
@@ -544,7 +547,7 @@ static void prove_run(ark355_ctx* ctx, ProverScratch& sc, const PkDev& pk, const
     for (int g = 0; g < cm->world; g++)
       for (int k = 0; k < 4; k++)
         ARK_REQUIRE(all[4 * (size_t)g + k] == mine[k], ARK355_EINVAL,
-                    "key shards of different ranks were planned with different window sizes / table strides");
+                    "key shards of different ranks were planned with different window sizes / table strides / witness-map layouts");
   }
   enum { E_START, E_Z, E_ZS, E_H, E_SORT0, E_SORT1, E_SORT2, E_G2T, E_ACC_DONE0, E_END = E_ACC_DONE0 + 5, E_COUNT };
   static_assert(E_COUNT + 10 <= ProverScratch::N_EVENTS, "event pool too small");

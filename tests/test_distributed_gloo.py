@@ -40,7 +40,12 @@ def _make_key(n, path):
 def _worker(rank, world, port, n, key_path, modes, whole, q, stride_on_rank1=None):
     try:
         if stride_on_rank1 and rank == 1:
-            os.environ["ARK355_TABLE_STRIDE"] = stride_on_rank1      # this rank alone plans its tables differently
+            # this rank alone plans its tables differently ("2": another window stride) or lays its h_query shard out for the
+            # replicated witness map ("dist_wm=0")
+            if stride_on_rank1 == "dist_wm=0":
+                os.environ["ARK355_SHARD_DIST_WM"] = "0"
+            else:
+                os.environ["ARK355_TABLE_STRIDE"] = stride_on_rank1
         os.environ["MASTER_ADDR"] = "127.0.0.1"
         os.environ["MASTER_PORT"] = str(port)
         for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "emul")):
@@ -143,8 +148,10 @@ def test_sharded_prove_tiny_instance_with_empty_shards(tmp_path):
     _run(8, 3, tmp_path)
 
 
-def test_sharded_prove_refuses_ranks_with_different_table_plans(tmp_path):
-    """One rank plans its window tables with another stride (an environment override on that rank only): the bucket-level
-    exchange would add bucket arrays of different shapes.  The ranks compare their plans over the communicator once per
-    key and every one of them returns ARK355_EINVAL instead."""
-    _run(2, 150, tmp_path, stride_on_rank1="2")
+@pytest.mark.parametrize("override", ["2", "dist_wm=0"], ids=["table-stride", "witness-map-layout"])
+def test_sharded_prove_refuses_ranks_with_different_table_plans(tmp_path, override):
+    """One rank plans its window tables with another stride, or loads its h_query shard in the layout of the replicated
+    witness map (an environment override on that rank only): the bucket-level exchange would add bucket arrays of different
+    shapes, the other ranks would wait in all-to-alls that rank never enters.  The ranks compare their plans over the
+    communicator on every sharded proof and every one of them returns ARK355_EINVAL instead."""
+    _run(2, 150, tmp_path, stride_on_rank1=override)

@@ -46,7 +46,10 @@ def main():
     n = 1 << args.log_n
     g = Groth16(cv, device=0)
     L = g.lib
-    L.ctx_set_policy(g.ctx, "SCHED_EXPLORE", 0)       # static default schedule (a lone proof: the five-stream pipeline)
+    # the schedule ark355_prove_sharded runs every rank's proof as: the five-stream pipeline, unmeasured (a collective cannot
+    # depend on one rank's measurements; prove_run, groth16_impl.cuh) -- ark355_prove_shard has no communicator and would
+    # otherwise take the one-stream default of a lone proof
+    L.ctx_set_policy(g.ctx, "SCHED", 1)
     r1, z = synthetic.mulchain(cv, n, seed=0x355)
     rnd = random.Random(1)
     t0 = time.perf_counter()
