@@ -235,7 +235,7 @@ struct Fp28 {
   // (sum_j x_j * y_j) / R' mod p, one reduction.  Column bound: J*N products of < 2^(x+y) plus N of < 2^56 plus a
   // carry-in of < 2^37 must stay below 2^64: J = 1: x + y <= 60, J = 2: x + y <= 59 (or 59.6 + 57), J = 4: 58.
   template <int J>
-  ARK_HD static Fp28 mulsum(const Fp28* const (&x)[J], const Fp28* const (&y)[J]) {
+  ARK_HD static Fp28 mulsum_school(const Fp28* const (&x)[J], const Fp28* const (&y)[J]) {
     uint32_t m[N];
     Fp28 r;
     Col c;
@@ -244,6 +244,168 @@ struct Fp28 {
     col_hi<N, J>(c, x, y, m, r);
     r.l[N - 1] = (uint32_t)c.acc;
     return r;
+  }
+
+  // ---- one Karatsuba level over the operand products (round 5) --------------------------------------------
+  // x = x0 + x1 B^H, y = y0 + y1 B^H (H = N / 2, B = 2^28):
+  //     x y = (1 + B^H)(x0 y0 + x1 y1 B^H) + (x1 - x0)(y0 - y1) B^H
+  // With G_k = column k of x0 y0 + x1 y1 B^H (k <= 3H - 2; the two half products share ONE accumulator chain per
+  // column) and D_k = column k of the SIGNED product (x1 - x0)(y0 - y1) (v_mad_i64_i32; k <= 2H - 2):
+  //     column k of x y  =  G_k + G_{k-H} + D_{k-H}
+  // 3 H^2 = 147 operand multiply-adds per product instead of 4 H^2 = 196 (N = 14), paid with 2H subtractions per
+  // product and H-1 more 64-bit additions per REDUCTION (shared by the J products of a mulsum: the dual / quad
+  // product passes of the lane-pair G2 kernel save 98 / 196 multiply-adds for the same 13 additions).  Every
+  // column's true value is the schoolbook column (same bounds, same result limb for limb); partial sums of the
+  // signed chain may wrap modulo 2^64, which is harmless -- the emulator build checks each column when it closes.
+  static constexpr int H = N / 2;
+  static_assert(N % 2 == 0, "Karatsuba split needs an even limb count");
+  struct KCol {
+    uint64_t acc;
+#if ARK_F28_CHECK
+    __int128 shadow;
+#endif
+    ARK_HD void init() {
+      acc = 0;
+#if ARK_F28_CHECK
+      shadow = 0;
+#endif
+    }
+    ARK_HD void mad(uint32_t a, uint32_t b) {
+      acc += (uint64_t)a * b;
+#if ARK_F28_CHECK
+      shadow += (__int128)((unsigned __int128)a * b);
+#endif
+    }
+    ARK_HD void mads(int32_t a, int32_t b) {
+      acc += (uint64_t)((int64_t)a * (int64_t)b);
+#if ARK_F28_CHECK
+      shadow += (__int128)a * (__int128)b;
+#endif
+    }
+    ARK_HD void add(const KCol& o) {
+      acc += o.acc;
+#if ARK_F28_CHECK
+      shadow += o.shadow;
+#endif
+    }
+    // the column is complete: its true value must be a non-negative 64-bit number
+    ARK_HD void close() const {
+#if ARK_F28_CHECK
+      if (shadow < 0 || (shadow >> 64) != 0 || (uint64_t)shadow != acc) __builtin_trap();
+#endif
+    }
+    ARK_HD void shift() {
+      acc >>= 28;
+#if ARK_F28_CHECK
+      shadow >>= 28;
+#endif
+    }
+  };
+  // G_K: column K of x0 y0 + x1 y1 B^H, summed over the J operand pairs
+  template <int K, int J>
+  ARK_HD static KCol kara_g(const Fp28* const (&x)[J], const Fp28* const (&y)[J]) {
+    KCol g;
+    g.init();
+#pragma unroll
+    for (int j = 0; j < J; j++) {
+      if constexpr (K <= 2 * H - 2) {
+        constexpr int lo = (K - H + 1 > 0) ? K - H + 1 : 0, hi = (K < H - 1) ? K : H - 1;
+#pragma unroll
+        for (int i = lo; i <= hi; i++) g.mad(x[j]->l[i], y[j]->l[K - i]);
+      }
+      if constexpr (K >= H && K <= 3 * H - 2) {
+        constexpr int K1 = K - H;
+        constexpr int lo = (K1 - H + 1 > 0) ? K1 - H + 1 : 0, hi = (K1 < H - 1) ? K1 : H - 1;
+#pragma unroll
+        for (int i = lo; i <= hi; i++) g.mad(x[j]->l[H + i], y[j]->l[H + K1 - i]);
+      }
+    }
+    return g;
+  }
+  // operand part of column K: G_K + G_{K-H} + D_{K-H}; g[] is a ring of the last H values of G
+  template <int K, int J>
+  ARK_HD static void kara_col(KCol& c, KCol (&g)[H], const Fp28* const (&x)[J], const Fp28* const (&y)[J],
+                              const int32_t (&dx)[J][H], const int32_t (&dy)[J][H]) {
+    if constexpr (K >= H && K <= 4 * H - 2) {
+      KCol t = g[K % H];                                   // G_{K-H}: last use
+      constexpr int K1 = K - H;
+      if constexpr (K1 <= 2 * H - 2) {
+        constexpr int lo = (K1 - H + 1 > 0) ? K1 - H + 1 : 0, hi = (K1 < H - 1) ? K1 : H - 1;
+#pragma unroll
+        for (int j = 0; j < J; j++) {
+#pragma unroll
+          for (int i = lo; i <= hi; i++) t.mads(dx[j][i], dy[j][K1 - i]);
+        }
+      }
+      c.add(t);
+    }
+    if constexpr (K <= 3 * H - 2) {
+      g[K % H] = kara_g<K, J>(x, y);
+      c.add(g[K % H]);
+    }
+  }
+  template <int K, int J>
+  ARK_HD static void kcol_lo(KCol& c, KCol (&g)[H], const Fp28* const (&x)[J], const Fp28* const (&y)[J],
+                             const int32_t (&dx)[J][H], const int32_t (&dy)[J][H], uint32_t* m) {
+    if constexpr (K < N) {
+      kara_col<K, J>(c, g, x, y, dx, dy);
+#pragma unroll
+      for (int i = 0; i < K; i++) c.mad(m[i], kp<1>(K - i));
+      m[K] = ((uint32_t)c.acc * INV) & MASK;
+      c.mad(m[K], kp<1>(0));
+      c.close();
+      c.shift();
+      kcol_lo<K + 1, J>(c, g, x, y, dx, dy, m);
+    }
+  }
+  template <int K, int J>
+  ARK_HD static void kcol_hi(KCol& c, KCol (&g)[H], const Fp28* const (&x)[J], const Fp28* const (&y)[J],
+                             const int32_t (&dx)[J][H], const int32_t (&dy)[J][H], const uint32_t* m, Fp28& r) {
+    if constexpr (K < 2 * N - 1) {
+      kara_col<K, J>(c, g, x, y, dx, dy);
+#pragma unroll
+      for (int i = K - N + 1; i < N; i++) c.mad(m[i], kp<1>(K - i));
+      c.close();
+      r.l[K - N] = (uint32_t)c.acc & MASK;
+      c.shift();
+      kcol_hi<K + 1, J>(c, g, x, y, dx, dy, m, r);
+    }
+  }
+  template <int J>
+  ARK_HD static Fp28 mulsum_kara(const Fp28* const (&x)[J], const Fp28* const (&y)[J]) {
+    int32_t dx[J][H], dy[J][H];
+#pragma unroll
+    for (int j = 0; j < J; j++) {
+#pragma unroll
+      for (int i = 0; i < H; i++) {
+        dx[j][i] = (int32_t)(x[j]->l[H + i] - x[j]->l[i]);       // limbs < 2^31: the difference fits
+        dy[j][i] = (int32_t)(y[j]->l[i] - y[j]->l[H + i]);
+#if ARK_F28_CHECK
+        if ((x[j]->l[H + i] | x[j]->l[i] | y[j]->l[i] | y[j]->l[H + i]) >> 31) __builtin_trap();
+#endif
+      }
+    }
+    uint32_t m[N];
+    Fp28 r;
+    KCol c, g[H];
+    c.init();
+#pragma unroll
+    for (int i = 0; i < H; i++) g[i].init();
+    kcol_lo<0, J>(c, g, x, y, dx, dy, m);
+    kcol_hi<N, J>(c, g, x, y, dx, dy, m, r);
+    r.l[N - 1] = (uint32_t)c.acc;
+    return r;
+  }
+#ifndef ARK_F28_KARATSUBA
+#define ARK_F28_KARATSUBA 1
+#endif
+  template <int J>
+  ARK_HD static Fp28 mulsum(const Fp28* const (&x)[J], const Fp28* const (&y)[J]) {
+#if ARK_F28_KARATSUBA
+    return mulsum_kara<J>(x, y);
+#else
+    return mulsum_school<J>(x, y);
+#endif
   }
   ARK_HD static Fp28 mul(const Fp28& a, const Fp28& b) {
     const Fp28* const x[1] = {&a};

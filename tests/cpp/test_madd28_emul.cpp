@@ -169,7 +169,58 @@ static void run_g2(const char* name) {
   printf("%s G2 (lane pair): ok\n", name);
 }
 
+// One Karatsuba level (mulsum_kara, field28.cuh) against the schoolbook pass it replaces: single, dual and quad product
+// passes, operand limbs at the widest classes each pass admits (x + y <= 60 / 59 / 58), all-ones and half-zero patterns
+// (the signed middle term at its extremes).  Limb for limb, not just modulo p; every column is checked against its
+// 128-bit shadow on the way (ARK_EMUL).
+template <class F>
+static void run_kara(const char* name) {
+  Rng rng{0x5a5a};
+  for (int t = 0; t < 60000; t++) {
+    F a[4], b[4];
+    const int bits = 28 + (t % 3);
+    for (int j = 0; j < 4; j++)
+      for (int i = 0; i < F::N; i++) {
+        a[j].l[i] = (uint32_t)rng.next() & ((1u << bits) - 1);
+        b[j].l[i] = (uint32_t)rng.next() & F::MASK;
+      }
+    if (t % 7 == 0)
+      for (int i = 0; i < F::N; i++) {
+        a[0].l[i] = (1u << bits) - 1;
+        b[0].l[i] = F::MASK;
+      }
+    if (t % 11 == 0)
+      for (int i = 0; i < F::N; i++) {
+        a[0].l[i] = (i < F::H) ? (1u << bits) - 1 : 0;
+        b[0].l[i] = (i < F::H) ? 0 : F::MASK;
+      }
+    auto same_limbs = [](const F& x, const F& y) {
+      for (int i = 0; i < F::N; i++)
+        if (x.l[i] != y.l[i]) return false;
+      return true;
+    };
+    {
+      const F* const x[1] = {&a[0]};
+      const F* const y[1] = {&b[0]};
+      CHECK(same_limbs(F::template mulsum_school<1>(x, y), F::template mulsum_kara<1>(x, y)));
+    }
+    if (bits <= 29) {
+      const F* const x[2] = {&a[0], &a[1]};
+      const F* const y[2] = {&b[0], &b[1]};
+      CHECK(same_limbs(F::template mulsum_school<2>(x, y), F::template mulsum_kara<2>(x, y)));
+    }
+    if (bits <= 28) {
+      const F* const x[4] = {&a[0], &a[1], &a[2], &a[3]};
+      const F* const y[4] = {&b[0], &b[1], &b[2], &b[3]};
+      CHECK(same_limbs(F::template mulsum_school<4>(x, y), F::template mulsum_kara<4>(x, y)));
+    }
+  }
+  printf("%s Karatsuba == schoolbook: ok\n", name);
+}
+
 int main() {
+  run_kara<BlsFq28>("bls12_381");
+  run_kara<BnFq28>("bn254");
   run_g1<BlsCurve>("bls12_381");
   run_g1<BnCurve>("bn254");
   run_g2<BlsCurve>("bls12_381");
