@@ -39,8 +39,10 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 # whole chip issues 28.8 T of them per second (tools/ubench.hip, profiles/r01_ubench_*.txt: 46.8 per clock per CU).
 # Multiply-adds per mixed addition are read off the ISA of the shipped kernels (tools/isa_blocks.py, hot blocks):
 #   G1 and lane-split G2 (two lanes per addition) on radix-2^28 limbs (msm_accumulate28_kernel, msm_accumulate_g2l28_kernel).
-MAD_PEAK_T = 28.8
-MADS_PER_ADD = {"bls12_381": {"g1": 3542, "g2": 2 * 5292}, "bn254": {"g1": 1720, "g2": 2 * 2610}}
+MAD_PEAK_T = 29.3            # tools/ubench5, two waves per SIMD (profiles/r05_runA_ubench5.txt); round 1 read 28.7 with eight
+# Round 5 (one Karatsuba level over the operand products, v_mad_u64_u32 + v_mad_i64_i32): 3155 / 2 x 4410 (BLS12-381),
+# 1526 / 2 x 2162 (BN254); rounds 2-4: 3542 / 2 x 5292, 1720 / 2 x 2610.
+MADS_PER_ADD = {"bls12_381": {"g1": 3155, "g2": 2 * 4410}, "bn254": {"g1": 1526, "g2": 2 * 2162}}
 
 
 def parse_args():
@@ -62,12 +64,14 @@ def parse_args():
     ap.add_argument("--no-ab", action="store_true", help="skip the in-run A/B of the schedules (after the timed region)")
     ap.add_argument("--no-micro", action="store_true", help="skip the stand-alone MSM / NTT readings (after the timed region)")
     ap.add_argument("--no-telemetry", action="store_true", help="no clock / power sampling")
+    ap.add_argument("--no-e2e", action="store_true",
+                    help="skip the synthesis-in-the-loop reading (host mirror feeding in-flight proofs; after the timed region)")
     ap.add_argument("--profile-run", action="store_true",
                     help="for rocprofv3: nothing but preparation, warm-up and the timed region (no A/B, isolated, single-proof, "
                          "latency or stand-alone readings), so that every proof of the trace ran under ONE schedule (ARK355_SCHED)")
     args = ap.parse_args()
     if args.profile_run:
-        args.no_ab = args.no_micro = args.no_telemetry = args.no_cpu_baseline = True
+        args.no_ab = args.no_micro = args.no_telemetry = args.no_cpu_baseline = args.no_e2e = True
     if args.dry_run_emul:
         args.inflight = 1                # the emulator is single-threaded
     if args.log_n is None:
@@ -108,6 +112,51 @@ def cpu_baseline(curve_name, log_n_sample=None):
     dt = time.perf_counter() - t0
     return {"value": n / dt, "unit": "constraints/s", "cores": 1, "kind": "port",
             "sample": "pure-Python oracle (scalar, naive MSM), 2^7-constraint mulchain, 1 proof"}
+
+
+def e2e_reading(curve, n, inflight, device_value):
+    """SURVEY 8f-4, outside the timed region: SNARK::prove WITH synthesis in the loop on the reference's own benchmark shape
+    (relations/examples/bench.rs:22-83 made satisfiable: S3 / BenchLc).  K witness-only synthesis threads (one constraint
+    system each -- the reference's ConstraintSystemRef is Rc<RefCell>, so a thread per proof is its parallel unit) hand
+    assignments in page-locked buffers to `inflight` proving threads (Groth16::prove_pipelined of host_mirror/snark.hpp, the
+    C++ stand-in for a Rust host; tests/cpp/test_host_mirror --e2e).  Runs in its own process with its own key."""
+    import subprocess
+    try:
+        from snark_amd import build as B
+        exe = B.build_host_mirror_exe()
+        quota = os.cpu_count() or 1
+        try:                                       # the container's CPU quota, not the host's thread count
+            q = open("/sys/fs/cgroup/cpu.max").read().split()
+            if q[0] != "max":
+                quota = max(1, int(int(q[0]) / int(q[1])))
+        except (OSError, ValueError, IndexError):
+            pass
+        threads = max(2, min(12, quota - 2 - inflight // 2))
+        count = 6 * inflight
+        env = dict(os.environ)
+        env.pop("ARK355_E2E_SWEEP", None)
+        t0 = time.perf_counter()
+        r = subprocess.run([exe, "--e2e", curve, str(n), str(count), str(threads), str(inflight), "benchlc"],
+                           capture_output=True, text=True, timeout=240, env=env)
+        kv = dict(l.split("=", 1) for l in r.stdout.splitlines() if "=" in l and not l.startswith("sweep"))
+        if r.returncode != 0 or "e2e_constraints_per_s" not in kv:
+            return {"error": "rc=%d %s" % (r.returncode, (r.stderr or r.stdout)[-200:])}
+        val = float(kv["e2e_constraints_per_s"])
+        dev = float(kv.get("device_only_pinned_constraints_per_s", kv.get("device_only_constraints_per_s", 0)))
+        synth_cpu = float(kv["e2e_synth_cpu_s"])
+        wall = float(kv["e2e_wall_s"])
+        out = {"value": val, "unit": "constraints/s", "circuit": "S3 bench-LC (relations/examples/bench.rs shape), n=%d" % n,
+               "proofs": count, "synthesis_threads": threads, "inflight": inflight, "host_cpu_quota_cores": quota,
+               "synthesis_cpu_cores_used": synth_cpu / wall if wall > 0 else None,
+               "device_only_same_process": dev, "ratio_to_device_only_same_process": val / dev if dev else None,
+               "ratio_to_value": val / device_value if device_value else None,
+               "seconds": round(time.perf_counter() - t0, 2),
+               "host": "C++ mirror of ark-relations (host_mirror/), witness-only synthesis; a Rust host runs the real crate"}
+        out["bound"] = ("device" if out["ratio_to_device_only_same_process"] and out["ratio_to_device_only_same_process"] >= 0.9
+                        else "host synthesis (%d threads of a %d-core quota)" % (threads, quota))
+        return out
+    except Exception as e:                                    # noqa: BLE001
+        return {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
 
 
 def thread_cpu_times():
@@ -712,6 +761,9 @@ def main():
             # how the resident key sits in HBM (window size, windows, table stride, bytes of its five window tables)
             "key_tables": g.lib.pk_table_info(pkh if pkh is not None else sg.load_pk_shard(pk)),
         }
+        if not args.no_e2e and world == 1 and not emul and not shard:
+            stage("e2e (synthesis in the loop) ...")
+            out["e2e"] = e2e_reading(args.curve, n, len(ctxs), out["value"])
         if not args.no_cpu_baseline and world == 1 and not emul:
             out["cpu_baseline"] = cpu_baseline(args.curve)
         if sampler is not None:

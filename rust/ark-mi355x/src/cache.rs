@@ -95,6 +95,12 @@ pub struct Resident {
     pub num_instance: usize,
     pub num_witness: usize,
     pub num_constraints: usize,
+    /// Hash of the three matrices this entry was loaded with (`matrices_hash`): what tells two circuits apart whose proving
+    /// keys share a sampled fingerprint.
+    pub matrices_hash: MatHash,
+    /// Circuit types (`core::any::type_name`) whose matrices were compared with this entry and found equal: only those
+    /// may take the witness-only path.
+    confirmed: Mutex<Vec<&'static str>>,
 }
 // SAFETY: the handles are immutable after load and the library allows concurrent readers (include/ark355.h).
 unsafe impl Send for Resident {}
@@ -109,6 +115,18 @@ pub struct TableInfo {
     pub table_bytes: u64,
 }
 impl Resident {
+    pub fn is_confirmed(&self, circuit_type: &'static str) -> bool {
+        self.confirmed.lock().unwrap().iter().any(|t| *t == circuit_type)
+    }
+    pub fn confirm(&self, circuit_type: &'static str) {
+        let mut c = self.confirmed.lock().unwrap();
+        if !c.iter().any(|t| *t == circuit_type) {
+            c.push(circuit_type);
+        }
+    }
+    pub fn unconfirm(&self, circuit_type: &'static str) {
+        self.confirmed.lock().unwrap().retain(|t| *t != circuit_type);
+    }
     pub fn table_info(&self) -> TableInfo {
         let (mut c, mut w, mut s, mut b) = (0u32, 0u32, 0u32, 0u64);
         // SAFETY: `self.pk` is a live handle until drop; the out-pointers are valid for the call.
@@ -126,6 +144,7 @@ impl Drop for Resident {
 }
 
 type Key = [u8; 32];
+pub type MatHash = [u8; 32];
 
 /// Resident keys of this process, most recently used last.  BOUNDED: a key's window tables are ~25x its size (15 GB at
 /// n = 2^20), so an unbounded map turns "one `pk.clone()` per request" into an out-of-memory condition.  When a load would
@@ -135,15 +154,18 @@ struct Registry {
     entries: Vec<(Key, Arc<Resident>)>,
 }
 impl Registry {
-    fn get(&mut self, k: &Key) -> Option<Arc<Resident>> {
-        let i = self.entries.iter().position(|(key, _)| key == k)?;
-        let e = self.entries.remove(i);
-        let r = e.1.clone();
-        self.entries.push(e);
-        Some(r)
+    /// Every entry under this fingerprint (several circuits may share one, see `fingerprint`), most recently used last.
+    fn get_all(&mut self, k: &Key) -> Vec<Arc<Resident>> {
+        self.entries.iter().filter(|(key, _)| key == k).map(|(_, r)| r.clone()).collect()
+    }
+    fn touch(&mut self, k: &Key, r: &Arc<Resident>) {
+        if let Some(i) = self.entries.iter().position(|(key, e)| key == k && Arc::ptr_eq(e, r)) {
+            let e = self.entries.remove(i);
+            self.entries.push(e);
+        }
     }
     fn insert(&mut self, k: Key, r: Arc<Resident>) {
-        self.entries.retain(|(key, _)| key != &k);
+        self.entries.retain(|(key, e)| !(key == &k && e.matrices_hash == r.matrices_hash));
         while self.entries.len() >= max_resident_keys() {
             self.entries.remove(0);
         }
@@ -163,15 +185,20 @@ fn registry() -> &'static Mutex<Registry> {
     R.get_or_init(|| Mutex::new(Registry { entries: Vec::new() }))
 }
 
-/// Fingerprint of a proving key, by CONTENT only.  Covers the verifying key, the two prover-only points, the query lengths
-/// AND the query vectors themselves: 1024 evenly spaced elements (plus the last one) of each of the five vectors.  The
-/// verifying key alone is not enough: two circuits of the same shape set up from the same deterministic seed (the usual
-/// `test_rng` pattern) that differ only in witness constraints share vk, beta_g1, delta_g1 and every length, and a lookup
-/// keyed on those would prove with the other circuit's key and matrices -- but their QAP polynomials differ, and with
-/// them (almost) every element of the query vectors, so the samples separate them.  Hashing all ~600 MB of a 2^20 key on
-/// every `prove` is not an option.  The address of the key's buffers is deliberately NOT part of the fingerprint (round 3
-/// mixed it in): a clone or a move of the same key must hit the cache instead of uploading another 15 GB of tables, and a
-/// freed key whose buffer is reused by a same-shape key must not alias.
+/// Fingerprint of a proving key, by CONTENT only: the verifying key, the two prover-only points, the query lengths and
+/// 1024 evenly spaced elements (plus the last one) of each of the five query vectors.  Hashing all ~600 MB of a 2^20 key on
+/// every `prove` is not an option, and the address of the key's buffers is deliberately NOT part of it (a clone or a move
+/// of the same key must hit the cache instead of uploading another 10 GB of tables; a freed key whose buffer is reused by
+/// a same-shape key must not alias).
+///
+/// The fingerprint is a PRE-FILTER, not an identity.  Two circuits of the same shape set up from the same deterministic
+/// seed (the usual `test_rng` pattern) share `vk` (it depends on the instance columns only), `h_query` (it depends on the
+/// domain only) and every length; their `a / b / l_query` differ only at the variables of the constraints that differ -- a
+/// handful of elements out of millions, which 1024 samples miss with probability ~99.9 %.  What identifies a cache entry
+/// is therefore the fingerprint AND the hash of the matrices it was loaded with (`matrices_hash`); several entries may
+/// share a fingerprint.  The witness-only fast path (`Groth16Mi355x::prepare`) is open only to circuit TYPES whose matrices
+/// were compared with the entry once, and every use of it re-checks the assignment against the cached matrices on the
+/// device (`confirm_hit`).
 pub fn fingerprint<E: Mi355xCurve>(pk: &ProvingKey<E>) -> Key {
     let mut bytes = Vec::new();
     pk.vk.serialize_compressed(&mut bytes).expect("vk serialization");
@@ -210,8 +237,71 @@ pub fn fingerprint<E: Mi355xCurve>(pk: &ProvingKey<E>) -> Key {
     out
 }
 
+/// The most recently used entry under this key's fingerprint (callers that hold ONE circuit per key: `prove_assignments`,
+/// the pool).  `SNARK::prove` goes through `candidates` and confirms the entry against its circuit.
 pub fn lookup<E: Mi355xCurve>(pk: &ProvingKey<E>) -> Option<Arc<Resident>> {
-    registry().lock().unwrap().get(&fingerprint(pk))
+    registry().lock().unwrap().get_all(&fingerprint(pk)).pop()
+}
+
+/// Every entry whose key has this key's fingerprint.
+pub fn candidates<E: Mi355xCurve>(pk: &ProvingKey<E>) -> Vec<Arc<Resident>> {
+    registry().lock().unwrap().get_all(&fingerprint(pk))
+}
+
+/// Mark `res` as the most recently used entry of its fingerprint.
+pub fn touch<E: Mi355xCurve>(pk: &ProvingKey<E>, res: &Arc<Resident>) {
+    registry().lock().unwrap().touch(&fingerprint(pk), res);
+}
+
+/// Hash of the R1CS matrices (rows, columns, canonical coefficients) and the constraint count.
+pub fn matrices_hash<F: PrimeField>(matrices: &[Matrix<F>], num_constraints: usize) -> MatHash {
+    let mut lanes = [0xcbf29ce484222325u64, 0x84222325cbf29ce4, 0x9e3779b97f4a7c15, 0xd6e8feb86659fd93];
+    let mut n = 0usize;
+    let mut feed = |w: u64| {
+        let l = &mut lanes[n & 3];
+        *l = (*l ^ w).wrapping_mul(0x100000001b3);
+        *l ^= *l >> 29;
+        n += 1;
+    };
+    feed(num_constraints as u64);
+    feed(matrices.len() as u64);
+    for m in matrices {
+        feed(m.len() as u64);
+        for row in m {
+            feed(row.len() as u64);
+            for (coeff, col) in row {
+                feed(*col as u64);
+                for limb in coeff.into_bigint().as_ref() {
+                    feed(*limb);
+                }
+            }
+        }
+    }
+    let mut out = [0u8; 32];
+    for (i, l) in lanes.iter().enumerate() {
+        out[8 * i..8 * i + 8].copy_from_slice(&l.to_le_bytes());
+    }
+    out
+}
+
+/// Does the full assignment `z` of the caller's circuit satisfy the matrices of the cached entry (one SpMV + compare on the
+/// device, `ark355_is_satisfied`)?  `false`: the entry belongs to another circuit, or the circuit is not satisfied by its
+/// own assignment.  `ARK_MI355X_TRUST_CACHE=1` skips the check (one H2D copy of z and ~0.2 ms of kernels per proof at
+/// n = 2^20) for hosts that prove one circuit per key.
+pub fn confirm_hit<F: PrimeField>(res: &Resident, z: &[F]) -> Result<bool, Mi355xError> {
+    static TRUST: OnceLock<bool> = OnceLock::new();
+    if *TRUST.get_or_init(|| std::env::var("ARK_MI355X_TRUST_CACHE").map(|v| v == "1").unwrap_or(false)) {
+        return Ok(true);
+    }
+    if z.len() != res.num_instance + res.num_witness {
+        return Ok(false);
+    }
+    with_ctx(|ctx| {
+        let zi = scalars_image(z);
+        let mut first_bad: i64 = -1;
+        check(ctx, unsafe { ffi::ark355_is_satisfied(ctx, res.r1cs, zi.as_ptr(), z.len() as u64, &mut first_bad) })?;
+        Ok(first_bad < 0)
+    })
 }
 
 /// Release the HBM of a key (window tables: ~15 GB at n = 2^20) once no proof uses it any more.
@@ -270,7 +360,15 @@ where
             unsafe { ffi::ark355_pk_free(pk_h) };
             return Err(e);
         }
-        Ok(Resident { pk: pk_h, r1cs: r1_h, num_instance, num_witness, num_constraints })
+        Ok(Resident {
+            pk: pk_h,
+            r1cs: r1_h,
+            num_instance,
+            num_witness,
+            num_constraints,
+            matrices_hash: matrices_hash(matrices, num_constraints),
+            confirmed: Mutex::new(Vec::new()),
+        })
     })?;
     let res = Arc::new(res);
     registry().lock().unwrap().insert(fingerprint(pk), res.clone());

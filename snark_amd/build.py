@@ -74,5 +74,29 @@ def build(force=False, verbose=True, resource_log=False):
     return OUT
 
 
+def build_host_mirror_exe(verbose=False):
+    """tests/cpp/test_host_mirror: the C++ stand-in for a Rust host (host_mirror/*.hpp) linked against libark355.so --
+    the parity harness of tests/test_host_mirror_cpp.py and the synthesis-in-the-loop reading of bench.py (`e2e`).
+    Rebuilt whenever the sources differ from what the binary was built from (content hash, not mtime: a stale binary
+    from another checkout must never run in place of the current sources)."""
+    import hashlib
+    root = os.path.normpath(os.path.join(HERE, ".."))
+    cpp = os.path.join(root, "tests", "cpp")
+    exe = os.path.join(cpp, "test_host_mirror")
+    src = os.path.join(cpp, "test_host_mirror.cpp")
+    deps = [src] + [os.path.join(root, "host_mirror", f) for f in ("relations.hpp", "snark.hpp")]
+    h = hashlib.sha256()
+    for d in deps + [os.path.join(INCLUDE, "ark355.h")]:
+        h.update(open(d, "rb").read())
+    stamp = exe + ".srchash"
+    if not os.path.exists(exe) or not os.path.exists(stamp) or open(stamp).read() != h.hexdigest():
+        cmd = ["g++", "-O2", "-pthread", "-std=c++17", src, "-o", exe, "-L" + HERE, "-lark355", "-Wl,-rpath," + HERE]
+        if verbose:
+            print("[snark_amd.build]", " ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+        open(stamp, "w").write(h.hexdigest())
+    return exe
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, resource_log="--resources" in sys.argv))

@@ -13,7 +13,9 @@
 //     usual weighted bucket reduction over its range, and the all-gather above finishes.  Per proof and rank this moves
 //     (G-1)/G of 5 bucket arrays (4 x 6.3 MB + 12.6 MB at c = 16, BLS12-381) over one xGMI link (~153 GB/s): ~0.25 ms
 //     of wire time at G = 8 plus 5 x (G-1) grouped steps of latency; it exists to be measured against the default.
-// Both give byte-identical proofs (tests/test_comm_emul.py at world sizes 2, 3, 8; GPU test at world size 1).
+// Both give byte-identical proofs (tests/test_distributed_gloo.py at world sizes 2, 3, 8 over the emulated RCCL; on the GPU at
+// world size 1, where policy RCCL_SELF makes the rank exchange with ITSELF so that the grouped ncclSend / ncclRecv steps and the
+// EC-add kernel of the ring really run on RCCL: tests/rccl_single_rank.py).
 #pragma once
 #include "common.h"
 #include "curve.cuh"
@@ -59,10 +61,26 @@ static inline void ring_chunk(uint32_t total, int world, int c, uint32_t* lo, ui
 // Ring reduce-scatter of `total` XYZZ buckets; afterwards rank g's range (g+1) mod G holds the sum over all ranks and
 // every other range is zeroed (= infinity), so the ordinary bucket reduction over the whole array yields this rank's
 // share of sum_b (b+1) B_b.
+// self_exchange (policy RCCL_SELF, world size 1 only): one ring step of the rank with itself -- the lower half of the
+// array travels through ncclSend / ncclRecv (peer = own rank, grouped) into the staging buffer, is cleared in place and
+// comes back through the same EC-add kernel: 0 + x = x, the array is unchanged.
 template <class F>
-static void ring_reduce_scatter_buckets(CommDev& cm, XYZZ<F>* buckets, uint32_t total, hipStream_t stream) {
+static void ring_reduce_scatter_buckets(CommDev& cm, XYZZ<F>* buckets, uint32_t total, hipStream_t stream, bool self_exchange = false) {
   const int G = cm.world, g = cm.rank;
-  if (G == 1) return;
+  if (G == 1) {
+    const uint32_t half = total / 2;
+    if (!self_exchange || half == 0) return;
+    cm.ring_tmp.ensure((size_t)half * sizeof(XYZZ<F>));
+    XYZZ<F>* tmp = cm.ring_tmp.as<XYZZ<F>>();
+    ARK_CHECK_NCCL(ncclGroupStart());
+    ARK_CHECK_NCCL(ncclSend(buckets, (size_t)half * sizeof(XYZZ<F>), ncclUint8, g, cm.comm, stream));
+    ARK_CHECK_NCCL(ncclRecv(tmp, (size_t)half * sizeof(XYZZ<F>), ncclUint8, g, cm.comm, stream));
+    ARK_CHECK_NCCL(ncclGroupEnd());
+    ARK_CHECK_HIP(hipMemsetAsync(buckets, 0, (size_t)half * sizeof(XYZZ<F>), stream));
+    ARK_LAUNCH((xyzz_add_inplace_kernel<F>), dim3((half + 255) / 256), dim3(256), 0, stream, buckets, (const XYZZ<F>*)tmp, half);
+    ARK_CHECK_LAUNCH();
+    return;
+  }
   uint32_t max_n = 0;
   for (int c = 0; c < G; c++) {
     uint32_t lo, n;

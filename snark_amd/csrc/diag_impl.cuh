@@ -96,7 +96,9 @@ static inline float diag_dispatch_gap_us(hipStream_t st, uint32_t launches = 200
 // two of bench.py's four context streams on one queue on a fresh box -- two of the four proofs "in flight" took turns --
 // because the runtime assigns queues by creation order across everything the process creates (torch's streams, the null
 // stream, ...).  Contexts take lanes round-robin; more contexts than lanes share (that is what a hardware queue would
-// make them do anyway).
+// make them do anyway).  The probe is timing-based and wants an idle device: when it cannot establish a FULL set (another
+// process on the GPU, work of the host application in flight, a slow first launch), the pool stays EMPTY and every
+// context keeps its own stream -- a short pool would funnel all proofs "in flight" into one or two in-order streams.
 struct LanePool {
   std::mutex mu;
   std::vector<hipStream_t> lanes;        // pairwise on different hardware queues (as far as that could be established)
@@ -115,7 +117,8 @@ struct LanePool {
 #if defined(ARK_EMUL)
     (void)want; (void)max_create;
 #else
-    for (uint32_t made = 0; made < max_create && lanes.size() < want; made++) {
+    bool failed = false;
+    for (uint32_t made = 0; made < max_create && lanes.size() < want && !failed; made++) {
       hipStream_t st = nullptr;
       if (hipStreamCreate(&st) != hipSuccess) break;
       bool clash = false;
@@ -127,9 +130,14 @@ struct LanePool {
           }
         }
       } catch (...) {
-        clash = false;       // the probe failed: take the stream as it is
+        failed = true;       // the probe itself failed: no pool
+        clash = true;
       }
       (clash ? parked : lanes).push_back(st);
+    }
+    if (failed || lanes.size() < want) {   // no full set: no pool (see above)
+      for (hipStream_t st : lanes) parked.push_back(st);
+      lanes.clear();
     }
 #endif
   }

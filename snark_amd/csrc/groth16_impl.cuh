@@ -377,7 +377,7 @@ static PkDev* pk_upload(const TunePolicy& pol, const ark355_pk_desc* d, hipStrea
     {
       uint32_t lgN = 0;
       while ((1ull << lgN) < pk->N) lgN++;
-      pk->h_dist = pol.shard_dist_wm != 0 && dwm_supported(lgN, shard_count);
+      pk->h_dist = pol.shard_dist_wm != 0 && dwm_supported(lgN, shard_count, pol.rccl_self != 0);
       if (pk->h_dist) {
         pk->h_lo = 0;
         pk->h_cnt = pk->N / shard_count;
@@ -612,7 +612,8 @@ static void prove_run(ark355_ctx* ctx, ProverScratch& sc, const PkDev& pk, const
       // dependence (the plan check above has completed; the all-gather of the partial sums waits for the H MSM), so the one
       // communicator serves them all.  The bucket-ring exchange interleaves its own send / receive steps with the MSMs
       // and therefore keeps the replicated map.
-      d_h = witness_map_dist_run<Curve>(ctx, r1, sc.zx.p, sc.dwm, cm, pk.shard_count, pk.shard_index, sW, /*loopback=*/!cm);
+      d_h = witness_map_dist_run<Curve>(ctx, r1, sc.zx.p, sc.dwm, cm, pk.shard_count, pk.shard_index, sW, /*loopback=*/!cm,
+                                        /*self_rccl=*/cm && pk.shard_count == 1 && pol.rccl_self != 0);
       if (trace_host)
         fprintf(stderr, "[ark355] witness map distributed over %u ranks (rank %u: N / G = %llu elements per vector)%s\n", pk.shard_count,
                 pk.shard_index, (unsigned long long)(pk.N / pk.shard_count), cm ? "" : " -- LOOPBACK exchange, timing only");
@@ -705,11 +706,11 @@ static void prove_run(ark355_ctx* ctx, ProverScratch& sc, const PkDev& pk, const
         // bucket-level exchange: the ranks run their MSMs in the same order, so the ring steps pair up
         if (jb.g2)
           msm_reduce_phase<Fq2>(ctx, *red_sort, *jb.bk, g2res, 0, sR, [&](XYZZ<Fq2>* bk, uint32_t nb, hipStream_t st) {
-            ring_reduce_scatter_buckets<Fq2>(*cm, bk, nb, st);
+            ring_reduce_scatter_buckets<Fq2>(*cm, bk, nb, st, pol.rccl_self != 0);
           });
         else
           msm_reduce_phase<Fq>(ctx, *red_sort, *jb.bk, g1res + jb.res, 0, sR, [&](XYZZ<Fq>* bk, uint32_t nb, hipStream_t st) {
-            ring_reduce_scatter_buckets<Fq>(*cm, bk, nb, st);
+            ring_reduce_scatter_buckets<Fq>(*cm, bk, nb, st, pol.rccl_self != 0);
           });
       } else if (jb.g2) {
         msm_reduce_phase<Fq2>(ctx, *red_sort, *jb.bk, g2res, 0, sR);

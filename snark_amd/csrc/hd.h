@@ -28,7 +28,7 @@ static inline uint32_t ark_pair_xchg(uint32_t v) { return __emu_pair_xchg(v); }
 // value held by the other lane of this lane's pair (lane ^ 1): one v_mov_b32_dpp quad_perm:[1,0,3,2]
 __device__ __forceinline__ uint32_t ark_pair_xchg(uint32_t v) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false);
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);   // bound_ctrl: no lane of this pattern reads out of bounds, and with it hipcc needs no v_mov to initialise the destination
 #else
   return v;   // never executed on the host pass
 #endif

@@ -10,16 +10,46 @@
 
 namespace ark355 {
 
-// One table row: x, y in the canonical 28-bit Montgomery form, padded to a multiple of 16 B (128 B for
-// BLS12-381: two 64 B sectors per gather).  Infinity is the all-zero row.
+// One table row: x, y in the canonical 28-bit Montgomery form (value < p, radix R' = 2^(28 N)), BIT-PACKED: each
+// coordinate is the plain little-endian binary image of its value in NB 32-bit words (48 B for BLS12-381, 32 B for
+// BN254), so a row is 96 B / 64 B instead of the 128 B / 80 B of one word per limb (round 5: -25 % / -20 % table
+// bytes; a BN254 row is exactly one 64-byte sector).  The accumulation kernels cut the words into 28-bit limbs in
+// registers (one v_alignbit_b32 + one v_and_b32 per limb: ~50 of ~4 500 instructions per addition).  Infinity is the
+// all-zero row.
 template <class P>
 struct alignas(16) Affine28 {
   using F = Fp28<P>;
-  static constexpr int USED = 2 * F::N;
-  static constexpr int WORDS = (USED * 4 > 96) ? 32 : ((USED + 3) / 4) * 4;
-  static constexpr int Q = USED / 4;                 // 16-byte loads that carry data
-  static_assert(USED % 4 == 0, "limb count must be even");
+  static constexpr int NB = F::NB;                   // words per coordinate
+  static constexpr int WORDS = 2 * NB;
+  static constexpr int Q = WORDS / 4;                // 16-byte loads per row
+  static_assert(WORDS % 4 == 0, "row must be a multiple of 16 bytes");
   uint32_t w[WORDS];
+  // limbs of one coordinate from its NB words (compile-time shifts)
+  ARK_HD static F unpack(const uint32_t* c) {
+    F r;
+#pragma unroll
+    for (int i = 0; i < F::N; i++) {
+      const int bit = 28 * i, q = bit / 32, sh = bit % 32;
+      uint32_t v = 0;
+      if (q < NB) {
+        v = c[q] >> sh;
+        if (sh + 28 > 32 && q + 1 < NB) v |= c[q + 1] << (32 - sh);
+      }
+      r.l[i] = v & F::MASK;
+    }
+    return r;
+  }
+  // canonical limbs (< 2^28 each, value < p < 2^(32 NB)) -> NB words
+  ARK_HD static void pack(const F& a, uint32_t* c) {
+#pragma unroll
+    for (int q = 0; q < NB; q++) c[q] = 0;
+#pragma unroll
+    for (int i = 0; i < F::N; i++) {
+      const int bit = 28 * i, q = bit / 32, sh = bit % 32;
+      if (q < NB) c[q] |= a.l[i] << sh;
+      if (sh + 28 > 32 && q + 1 < NB) c[q + 1] |= a.l[i] >> (32 - sh);
+    }
+  }
 };
 
 template <class P>
@@ -27,60 +57,11 @@ struct Acc28 {
   Fp28<P> x, y, zz, zzz;
 };
 
-// ARK_LAZY_FLUSH: the accumulation kernels store a finished run as it stands -- the lazily reduced 28-bit limbs of the
-// accumulator, 4 x N words (G1) or this lane's 4 x N of 8 x N (G2) -- into a raw slot array [buckets | head | tail],
-// and msm_unlazy28_kernel converts every slot to the canonical 32-bit XYZZ form once, in front of the merge.  The
-// conversion (carry propagation, three conditional subtractions, repacking, one Montgomery step: ~500 instructions per
-// coordinate) used to sit in the flush, where ONE lane of a wave closing a run made all 64 wait for it: 12 % of the
-// iterations at 512 entries per bucket.  0 keeps the conversion in the flush (A/B).
-#ifndef ARK_LAZY_FLUSH
-#define ARK_LAZY_FLUSH 0
-#endif
 #define ARK_KEY_NONE 0xFFFFFFFFu
 
-// What the accumulation kernels write a run into: raw limbs when ARK_LAZY_FLUSH, the canonical point otherwise.
-#if ARK_LAZY_FLUSH
-template <class P, int COORDS>
-struct alignas(8) Msm28SlotRaw {
-  uint32_t w[COORDS * Fp28<P>::N];
-};
-template <class P, int COORDS>
-using Msm28Slot = Msm28SlotRaw<P, COORDS>;
-#else
+// What the accumulation kernels write a finished run into: the canonical 32-bit XYZZ point every other kernel uses.
 template <class P, int COORDS>
 using Msm28Slot = typename std::conditional<COORDS == 4, XYZZ<Fp<P>>, XYZZ<Fp2<P>>>::type;
-#endif
-
-// one lane per (slot, coordinate); COORDS = 4 (XYZZ over Fq) or 8 (over Fq2: x.c0, x.c1, y.c0, ...).  An empty run was
-// stored as zeros, which convert to the all-zero XYZZ = infinity; head / tail slots without a key were never written.
-template <class P, int COORDS>
-__global__ void __launch_bounds__(256)
-msm_unlazy28_kernel(const uint32_t* __restrict__ raw, uint32_t nb, uint32_t segs, const uint32_t* __restrict__ head_key,
-                    const uint32_t* __restrict__ tail_key, Fp<P>* __restrict__ buckets, Fp<P>* __restrict__ head,
-                    Fp<P>* __restrict__ tail) {
-  using F = Fp28<P>;
-  const uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const uint64_t slot = idx / COORDS;
-  const uint32_t c = (uint32_t)(idx % COORDS);
-  if (slot >= (uint64_t)nb + 2ull * segs) return;
-  Fp<P>* dst;
-  if (slot < nb) {
-    dst = buckets + slot * COORDS + c;
-  } else if (slot < (uint64_t)nb + segs) {
-    const uint64_t sg = slot - nb;
-    if (head_key[sg] == ARK_KEY_NONE) return;
-    dst = head + sg * COORDS + c;
-  } else {
-    const uint64_t sg = slot - nb - segs;
-    if (tail_key[sg] == ARK_KEY_NONE) return;
-    dst = tail + sg * COORDS + c;
-  }
-  const uint32_t* src = raw + (slot * COORDS + c) * F::N;
-  F v;
-#pragma unroll
-  for (int i = 0; i < F::N; i++) v.l[i] = src[i];
-  *dst = F::to_fp_lt8(v);
-}
 
 template <class P>
 __global__ void __launch_bounds__(256)
@@ -93,12 +74,8 @@ table_to28_kernel(const Affine<Fp<P>>* __restrict__ src, Affine28<P>* __restrict
 #pragma unroll
   for (int k = 0; k < Affine28<P>::WORDS; k++) o.w[k] = 0;
   if (!a.is_inf()) {
-    const F x = F::from_fp(a.x), y = F::from_fp(a.y);
-#pragma unroll
-    for (int k = 0; k < F::N; k++) {
-      o.w[k] = x.l[k];
-      o.w[F::N + k] = y.l[k];
-    }
+    Affine28<P>::pack(F::from_fp(a.x), o.w);
+    Affine28<P>::pack(F::from_fp(a.y), o.w + Affine28<P>::NB);
   }
   dst[i] = o;
 }
@@ -185,10 +162,65 @@ ARK_D void madd28(Acc28<P>& acc, bool& empty, const Fp28<P>& px, const Fp28<P>& 
   acc.x = X3;
 }
 
+// ---- the segment walk shared by the G1 and the lane-pair G2 kernel -----------------------------------------------------
+// Run / flush protocol as in msm_accumulate_kernel (msm_impl.cuh): a lane walks ONE segment of the sorted entry list; a
+// maximal stretch of equal keys is a run; a finished run goes to buckets[key] when it is the bucket's only run, to
+// head[seg] when it opened the segment, to tail[seg] otherwise.
+//
+// Round 5, two changes that keep the multiplier busy (tools/ubench5: the register-resident mixed addition runs at 96 % of
+// the chip's multiply-add rate because the two waves of a SIMD hide each other's other instructions -- the kernels of
+// rounds 2-4 reached 72 %, i.e. a quarter of the time at least one of the two waves was NOT issuing multiply-adds):
+//   * deferred flush.  Converting a finished run to the canonical form (4 x to_fp_lt8 + stores, ~2 000 instructions) used
+//     to happen where the run ended: in ~23 % of a wave's iterations SOME lane met a bucket boundary and all 64 waited
+//     for it.  The first run a lane finishes inside its segment is now PARKED in LDS (4 N words per lane, word-major:
+//     no bank conflicts; 56 KiB per workgroup, two workgroups per CU) and flushed at the end of the segment, right
+//     behind the last run, by the same code (a two-pass loop) -- wave-uniformly.  A second interior boundary in one
+//     segment (a bucket shorter than the segment) is flushed on the spot, as before.
+//   * nothing the next iteration needs is waited for: the row of entry e+1 is gathered at the top of iteration e from an
+//     index that arrived during iteration e-1, the index of entry e+2 and the key of entry e+1 are loaded beside it.
+template <class P>
+struct Park28 {
+  using F = Fp28<P>;
+  static constexpr int WORDS = 4 * F::N + 4;          // the run's four coordinates + key, start, end, flags
+  // word-major: word k of lane t at lds[k * MSM_THREADS + t].  The run's bookkeeping lives in LDS as well: it is touched
+  // twice per segment, and as registers it pushed the lane-pair kernel's hot loop into scratch memory.
+  ARK_D static void store(uint32_t* lds, const Acc28<P>& a, bool empty, bool first, uint32_t key, uint32_t start, uint32_t end) {
+    uint32_t* d = lds + threadIdx.x;
+    if (!empty) {
+#pragma unroll
+      for (int i = 0; i < F::N; i++) {
+        d[(0 * F::N + i) * MSM_THREADS] = a.x.l[i];
+        d[(1 * F::N + i) * MSM_THREADS] = a.y.l[i];
+        d[(2 * F::N + i) * MSM_THREADS] = a.zz.l[i];
+        d[(3 * F::N + i) * MSM_THREADS] = a.zzz.l[i];
+      }
+    }
+    d[(4 * F::N + 0) * MSM_THREADS] = key;
+    d[(4 * F::N + 1) * MSM_THREADS] = start;
+    d[(4 * F::N + 2) * MSM_THREADS] = end;
+    d[(4 * F::N + 3) * MSM_THREADS] = (empty ? 1u : 0u) | (first ? 2u : 0u);
+  }
+  ARK_D static void load(const uint32_t* lds, Acc28<P>& a, bool& empty, bool& first, uint32_t& key, uint32_t& start, uint32_t& end) {
+    const uint32_t* d = lds + threadIdx.x;
+    key = d[(4 * F::N + 0) * MSM_THREADS];
+    start = d[(4 * F::N + 1) * MSM_THREADS];
+    end = d[(4 * F::N + 2) * MSM_THREADS];
+    const uint32_t fl = d[(4 * F::N + 3) * MSM_THREADS];
+    empty = (fl & 1u) != 0;
+    first = (fl & 2u) != 0;
+    if (!empty) {
+#pragma unroll
+      for (int i = 0; i < F::N; i++) {
+        a.x.l[i] = d[(0 * F::N + i) * MSM_THREADS];
+        a.y.l[i] = d[(1 * F::N + i) * MSM_THREADS];
+        a.zz.l[i] = d[(2 * F::N + i) * MSM_THREADS];
+        a.zzz.l[i] = d[(3 * F::N + i) * MSM_THREADS];
+      }
+    }
+  }
+};
+
 // Same contract as msm_accumulate_kernel<Fp<P>, false>; `bases` holds Affine28 rows.
-#ifndef ARK_ACC_PREFETCH_KEY
-#define ARK_ACC_PREFETCH_KEY 0   // the bucket key of the next entry travels with its row index, one iteration ahead
-#endif
 template <class P>
 __global__ void __launch_bounds__(MSM_THREADS)
 msm_accumulate28_kernel(const Affine28<P>* __restrict__ bases, const uint32_t* __restrict__ sorted_keys,
@@ -199,15 +231,18 @@ msm_accumulate28_kernel(const Affine28<P>* __restrict__ bases, const uint32_t* _
                         uint32_t* __restrict__ tail_key, uint32_t seg_len) {
   using F = Fp28<P>;
   using Fq = Fp<P>;
-  constexpr int Q = Affine28<P>::Q;
+  using Row = Affine28<P>;
+  constexpr int Q = Row::Q;
+  __shared__ uint32_t park_lds[Park28<P>::WORDS * MSM_THREADS];
   const uint32_t seg = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t total = *total_ptr;
   const uint64_t start64 = (uint64_t)seg * seg_len;
   if (start64 >= total) return;
   const uint32_t start = (uint32_t)start64;
   const uint32_t end = (start + seg_len < total) ? start + seg_len : total;
+  const uint32_t last = end - 1;
   uint32_t cur_key = sorted_keys[start];
-  uint32_t run_start = start;
+  uint32_t run_start = start, run_end = end;
   bool first_run = true;
   bool empty = true;
   Acc28<P> acc;
@@ -215,33 +250,9 @@ msm_accumulate28_kernel(const Affine28<P>* __restrict__ bases, const uint32_t* _
   acc.y = F::zero();
   acc.zz = F::zero();
   acc.zzz = F::zero();
+  bool parked = false;
   // always_inline: a closure that is inlined late keeps every captured variable (the accumulator!) in scratch memory
-#if ARK_LAZY_FLUSH
-  auto flush = [&](uint32_t key, uint32_t run_end) __attribute__((always_inline)) {
-    const uint32_t o = offsets[key], cnt = counts[key];
-    const bool complete = (run_start == o) && (run_end == o + cnt);
-    // three explicit branches, not a select among the captured pointers (see msm_accumulate_g2l28_kernel)
-    auto store = [&](uint32_t* d) __attribute__((always_inline)) {
-#pragma unroll
-      for (int i = 0; i < F::N; i++) {
-        d[i] = empty ? 0u : acc.x.l[i];
-        d[F::N + i] = empty ? 0u : acc.y.l[i];
-        d[2 * F::N + i] = empty ? 0u : acc.zz.l[i];
-        d[3 * F::N + i] = empty ? 0u : acc.zzz.l[i];
-      }
-    };
-    if (complete) {
-      store(buckets[key].w);
-    } else if (first_run) {
-      store(head[seg].w);
-      head_key[seg] = key;
-    } else {
-      store(tail[seg].w);
-      tail_key[seg] = key;
-    }
-  };
-#else
-  auto flush = [&](uint32_t key, uint32_t run_end) __attribute__((always_inline)) {
+  auto flush = [&]() __attribute__((always_inline)) {
     XYZZ<Fq> out = XYZZ<Fq>::inf();
     if (!empty) {
       out.x = F::to_fp_lt8(acc.x);
@@ -249,68 +260,68 @@ msm_accumulate28_kernel(const Affine28<P>* __restrict__ bases, const uint32_t* _
       out.zz = F::to_fp_lt8(acc.zz);
       out.zzz = F::to_fp_lt8(acc.zzz);
     }
-    msm_flush_run<Fq>(key, out, first_run, run_start, run_end, seg, offsets, counts, buckets, head, head_key, tail,
+    msm_flush_run<Fq>(cur_key, out, first_run, run_start, run_end, seg, offsets, counts, buckets, head, head_key, tail,
                       tail_key);
   };
-#endif
-  // software prefetch of the next row into explicit 16-byte registers (see msm_accumulate_kernel)
+  // entry e: key k0, row index v0, row nx (explicit 16-byte registers); entry e + 1: row index v1
+  uint32_t k0 = cur_key;
+  uint32_t v0 = sorted_vals[start];
+  uint32_t v1 = sorted_vals[start < last ? start + 1 : last];
   uint4 nx[Q];
-  uint32_t v_next = sorted_vals[start];
-#if ARK_ACC_PREFETCH_KEY
-  uint32_t key_next = cur_key;
-#endif
   {
-    const uint4* src = reinterpret_cast<const uint4*>(bases + (v_next & ARK_TBL_MASK));
+    const uint4* src = reinterpret_cast<const uint4*>(bases + (v0 & ARK_TBL_MASK));
 #pragma unroll
     for (int k = 0; k < Q; k++) nx[k] = src[k];
   }
   for (uint32_t e = start; e < end; e++) {
-#if ARK_ACC_PREFETCH_KEY
-    const uint32_t key = key_next;
-#else
-    const uint32_t key = sorted_keys[e];
-#endif
-    const uint32_t v = v_next;
-    F px, py;
-    {
-      uint32_t d[4 * Q];
+    const uint32_t key = k0;
+    const uint32_t v = v0;
+    uint32_t d[4 * Q];
 #pragma unroll
-      for (int k = 0; k < Q; k++) {
-        d[4 * k + 0] = nx[k].x;
-        d[4 * k + 1] = nx[k].y;
-        d[4 * k + 2] = nx[k].z;
-        d[4 * k + 3] = nx[k].w;
-      }
-#pragma unroll
-      for (int k = 0; k < F::N; k++) {
-        px.l[k] = d[k];
-        py.l[k] = d[F::N + k];
-      }
+    for (int k = 0; k < Q; k++) {
+      d[4 * k + 0] = nx[k].x;
+      d[4 * k + 1] = nx[k].y;
+      d[4 * k + 2] = nx[k].z;
+      d[4 * k + 3] = nx[k].w;
     }
-    const uint32_t en = (e + 1 < end) ? e + 1 : e;       // clamp: the last iteration re-reads its own entry
-    v_next = sorted_vals[en];
-#if ARK_ACC_PREFETCH_KEY
-    key_next = sorted_keys[en];
-#endif
+    // what the next iteration needs (clamped: the last iterations re-read the last entry)
+    k0 = sorted_keys[e < last ? e + 1 : last];
+    v0 = v1;
     {
-      const uint4* src = reinterpret_cast<const uint4*>(bases + (v_next & ARK_TBL_MASK));
+      const uint4* src = reinterpret_cast<const uint4*>(bases + (v0 & ARK_TBL_MASK));
 #pragma unroll
       for (int k = 0; k < Q; k++) nx[k] = src[k];
     }
+    v1 = sorted_vals[e + 2 < end ? e + 2 : last];
     if (key != cur_key) {
-      flush(cur_key, e);
+      run_end = e;
+      if (!parked) {
+        Park28<P>::store(park_lds, acc, empty, first_run, cur_key, run_start, e);
+        parked = true;
+      } else {
+        flush();
+      }
       cur_key = key;
       run_start = e;
+      run_end = end;
       first_run = false;
       empty = true;
     }
     uint32_t any = 0;
 #pragma unroll
-    for (int k = 0; k < F::N; k++) any |= px.l[k] | py.l[k];
+    for (int k = 0; k < Row::WORDS; k++) any |= d[k];
     if (any == 0) continue;                              // base at infinity
+    const F px = Row::unpack(d), py = Row::unpack(d + Row::NB);
     madd28<P>(acc, empty, px, py, (v >> 31) != 0);
   }
-  flush(cur_key, end);
+  // the segment's last run, then the parked one: one copy of the flush code, two passes
+#pragma nounroll
+  for (int pass = 0; pass < 2; pass++) {
+    flush();
+    if (!parked) break;
+    Park28<P>::load(park_lds, acc, empty, first_run, cur_key, run_start, run_end);
+    parked = false;
+  }
 }
 
 
@@ -323,9 +334,6 @@ msm_accumulate28_kernel(const Affine28<P>* __restrict__ bases, const uint32_t* _
 // kernel only tied: its flush picked the destination with a select among captured pointers, hipcc turned that into an
 // indexed load from the lambda's closure object, the closure could not be scalarised, and EVERY captured variable (the
 // accumulator included) stayed in scratch memory: 28 x 16-byte scratch accesses per mixed addition.
-#ifndef ARK_G2L28_FUSE_Y3
-#define ARK_G2L28_FUSE_Y3 1
-#endif
 template <class P>
 struct Affine28G2 {
   Affine28<P> half[2];
@@ -345,20 +353,20 @@ table_to28_g2_kernel(const Affine<Fp2<P>>* __restrict__ src, Affine28G2<P>* __re
     for (int k = 0; k < Affine28<P>::WORDS; k++) o.half[h].w[k] = 0;
   }
   if (!a.is_inf()) {
-    const F x0 = F::from_fp(a.x.c0), x1 = F::from_fp(a.x.c1), y0 = F::from_fp(a.y.c0), y1 = F::from_fp(a.y.c1);
-#pragma unroll
-    for (int k = 0; k < F::N; k++) {
-      o.half[0].w[k] = x0.l[k];
-      o.half[0].w[F::N + k] = y0.l[k];
-      o.half[1].w[k] = x1.l[k];
-      o.half[1].w[F::N + k] = y1.l[k];
-    }
+    constexpr int NB = Affine28<P>::NB;
+    Affine28<P>::pack(F::from_fp(a.x.c0), o.half[0].w);
+    Affine28<P>::pack(F::from_fp(a.y.c0), o.half[0].w + NB);
+    Affine28<P>::pack(F::from_fp(a.x.c1), o.half[1].w);
+    Affine28<P>::pack(F::from_fp(a.y.c1), o.half[1].w + NB);
   }
   dst[i] = o;
 }
 
 // Fq2 arithmetic of a lane pair on Fp28 components.  KA / BETA describe the PARTNER component of the first
 // operand (value < (KA-1) p, limbs <= BETA (2^28 - 1)): it is negated lazily on the even lane.
+#ifndef ARK_PAIR_SEL_BFI
+#define ARK_PAIR_SEL_BFI 0
+#endif
 template <class P>
 struct Pair28 {
   using F = Fp28<P>;
@@ -377,30 +385,43 @@ struct Pair28 {
     for (int i = 0; i < N; i++) r.l[i] = c ? a.l[i] : b.l[i];
     return r;
   }
+  // odd lane ? a : b.  ARK_PAIR_SEL_BFI: as (m & a) | (~m & b) with the lane-parity mask m = 0 - (lane & 1) in a VGPR:
+  // one v_bfi_b32 per limb instead of one v_cndmask_b32_e64 on an SGPR pair (A/B switch; tools/ubench5 prices both).
+  ARK_D static F sel_odd(const F& a, const F& b) {
+#if ARK_PAIR_SEL_BFI
+    F r;
+    uint32_t m = 0u - (threadIdx.x & 1u);
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm("" : "+v"(m));          // opaque: hipcc otherwise recognises the sign splat and folds the expression back into selects
+#endif
+#pragma unroll
+    for (int i = 0; i < N; i++) r.l[i] = (m & a.l[i]) | (~m & b.l[i]);
+    return r;
+#else
+    return sel(odd(), a, b);
+#endif
+  }
   //   even: a0 b0 + (-a1) b1          odd: a0 b1 + a1 b0
   template <uint32_t KA, uint32_t BETA>
   ARK_D static F mul(const F& a, const F& b) {
     const F pa = xchg(a), pb = xchg(b);
     const F npa = F::template neg<KA, BETA>(pa);
-    const bool o = odd();
-    return F::mul2sum(sel(o, pa, a), b, sel(o, a, npa), pb);
+    return F::mul2sum(sel_odd(pa, a), b, sel_odd(a, npa), pb);
   }
   //   even: (a0 + a1)(a0 - a1)        odd: (2 a0) a1            (a normalised, components < (KA-1) p)
   template <uint32_t KA>
   ARK_D static F sqr(const F& a) {
     const F pa = xchg(a);
-    const bool o = odd();
-    const F u = F::add(pa, sel(o, pa, a));
+    const F u = F::add(pa, sel_odd(pa, a));
     const F d = F::template sub<KA, 1>(a, pa);
-    return F::mul(u, sel(o, a, d));
+    return F::mul(u, sel_odd(a, d));
   }
   // a b + c d, four products and one reduction per lane
   template <uint32_t KA, uint32_t BA, uint32_t KC, uint32_t BC>
   ARK_D static F mul2(const F& a, const F& b, const F& c, const F& d) {
     const F pa = xchg(a), pb = xchg(b), pc = xchg(c), pd = xchg(d);
     const F npa = F::template neg<KA, BA>(pa), npc = F::template neg<KC, BC>(pc);
-    const bool o = odd();
-    return F::mul4sum(sel(o, pa, a), b, sel(o, a, npa), pb, sel(o, pc, c), d, sel(o, c, npc), pd);
+    return F::mul4sum(sel_odd(pa, a), b, sel_odd(a, npa), pb, sel_odd(pc, c), d, sel_odd(c, npc), pd);
   }
 };
 
@@ -485,15 +506,7 @@ ARK_D void madd28_g2_tail(Acc28<P>& acc, const Fp28<P>& Pd, const Fp28<P>& R) {
   const F X3 = F::norm(F::add(L::template sqr<6>(R), F::template neg<5, 4>(W)));
   const F T = F::norm(F::template sub<8, 1>(Q, X3));
   const F NY = F::template neg<3, 1>(acc.y);
-#if ARK_G2L28_FUSE_Y3
   acc.y = L::template mul2<6, 1, 4, 3>(R, T, NY, PPP);
-#else
-  // two dual-product passes and a lazy sum: 196 more multiply-adds than the fused four-product pass (A/B knob;
-  // it does not change the register spills of this kernel)
-  const F Y3a = L::template mul<6, 1>(R, T);
-  const F Y3b = L::template mul<4, 3>(NY, PPP);
-  acc.y = F::norm(F::add(Y3a, Y3b));
-#endif
   acc.x = X3;
 }
 template <class P>
@@ -502,13 +515,10 @@ ARK_D void madd28_g2(Acc28<P>& acc, bool& empty, const Fp28<P>& px, const Fp28<P
   if (madd28_g2_head<P>(acc, empty, px, py, negate, Pd, R)) madd28_g2_tail<P>(acc, Pd, R);
 }
 
-#ifndef ARK_G2L28_PREFETCH
-#define ARK_G2L28_PREFETCH 0  // 0: load key, row index and row at the top of every iteration; 1: key and index one
-                              // iteration ahead; 2: also the row, gathered between the two halves of the addition
-#endif
 #ifndef ARK_G2L28_WAVES
-#define ARK_G2L28_WAVES 2     // waves per SIMD the register budget is sized for; 3 (168 VGPRs, ~90 spills per
-                              // addition) was measured: 10.5 vs 9.2 ms per 2^20-term MSM
+#define ARK_G2L28_WAVES 2     // waves per SIMD the register budget is sized for.  3 (168 VGPRs, ~90 spills per addition):
+                              // 10.5 vs 9.2 ms per 2^20-term MSM (round 2); 1 (512 registers): 23.2-23.5 vs 22.1-22.5 ms per
+                              // proof (round 5, profiles/r05_runA_karatsuba_ab.txt) -- the hot loop has no scratch access at 2
 #endif
 template <class P>
 __global__ void __launch_bounds__(MSM_THREADS, ARK_G2L28_WAVES)
@@ -520,8 +530,9 @@ msm_accumulate_g2l28_kernel(const Affine28G2<P>* __restrict__ bases, const uint3
                             uint32_t* __restrict__ tail_key, uint32_t seg_len) {
   using F = Fp28<P>;
   using Fq = Fp<P>;
-  using L = Pair28<P>;
-  constexpr int Q = Affine28<P>::Q;
+  using Row = Affine28<P>;
+  constexpr int Q = Row::Q;
+  __shared__ uint32_t park_lds[Park28<P>::WORDS * MSM_THREADS];      // this lane's halves of the parked run
   const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t seg = gid >> 1, par = gid & 1u;       // blockDim is even: par == lane parity
   const uint32_t total = *total_ptr;
@@ -529,8 +540,9 @@ msm_accumulate_g2l28_kernel(const Affine28G2<P>* __restrict__ bases, const uint3
   if (start64 >= total) return;                        // both lanes of a pair leave together
   const uint32_t start = (uint32_t)start64;
   const uint32_t end = (start + seg_len < total) ? start + seg_len : total;
+  const uint32_t last = end - 1;
   uint32_t cur_key = sorted_keys[start];
-  uint32_t run_start = start;
+  uint32_t run_start = start, run_end = end;
   bool first_run = true;
   bool empty = true;
   Acc28<P> acc;
@@ -538,37 +550,9 @@ msm_accumulate_g2l28_kernel(const Affine28G2<P>* __restrict__ bases, const uint3
   acc.y = F::zero();
   acc.zz = F::zero();
   acc.zzz = F::zero();
+  bool parked = false;
   // always_inline: a closure that is inlined late keeps every captured variable (the accumulator!) in scratch memory
-#if ARK_LAZY_FLUSH
-  auto flush = [&](uint32_t key, uint32_t run_end) __attribute__((always_inline)) {
-    const uint32_t o = offsets[key], cnt = counts[key];
-    const bool complete = (run_start == o) && (run_end == o + cnt);
-    // this lane's halves of the four Fq2 coordinates as they stand: coordinate k, component par -> words
-    // [(2k + par) N, (2k + par + 1) N) of the slot (the order of the Fq values inside XYZZ<Fp2>).
-    // Three explicit branches, NOT a select among the captured pointers: hipcc turns such a select into an indexed
-    // load from the closure object, which then cannot be scalarised -- and every captured variable, the accumulator
-    // included, lives in scratch memory for the whole loop (28 x 16-byte scratch accesses per mixed addition)
-    auto store = [&](uint32_t* d) __attribute__((always_inline)) {
-#pragma unroll
-      for (int i = 0; i < F::N; i++) {
-        d[(0 + par) * F::N + i] = empty ? 0u : acc.x.l[i];
-        d[(2 + par) * F::N + i] = empty ? 0u : acc.y.l[i];
-        d[(4 + par) * F::N + i] = empty ? 0u : acc.zz.l[i];
-        d[(6 + par) * F::N + i] = empty ? 0u : acc.zzz.l[i];
-      }
-    };
-    if (complete) {
-      store(buckets[key].w);
-    } else if (first_run) {
-      store(head[seg].w);
-      if (par == 0) head_key[seg] = key;
-    } else {
-      store(tail[seg].w);
-      if (par == 0) tail_key[seg] = key;
-    }
-  };
-#else
-  auto flush = [&](uint32_t key, uint32_t run_end) __attribute__((always_inline)) {
+  auto flush = [&]() __attribute__((always_inline)) {
     // this lane's halves of the four Fq2 coordinates, canonical 32-bit form
     XYZZ<Fq> mine = XYZZ<Fq>::inf();
     if (!empty) {
@@ -577,7 +561,7 @@ msm_accumulate_g2l28_kernel(const Affine28G2<P>* __restrict__ bases, const uint3
       mine.zz = F::to_fp_lt8(acc.zz);
       mine.zzz = F::to_fp_lt8(acc.zzz);
     }
-    const uint32_t o = offsets[key], cnt = counts[key];
+    const uint32_t o = offsets[cur_key], cnt = counts[cur_key];
     const bool complete = (run_start == o) && (run_end == o + cnt);
     // three explicit branches, NOT a select among the captured pointers: hipcc turns such a select into an indexed
     // load from the closure object, which then cannot be scalarised -- and every captured variable, the accumulator
@@ -590,43 +574,26 @@ msm_accumulate_g2l28_kernel(const Affine28G2<P>* __restrict__ bases, const uint3
       d[6 + par] = mine.zzz;
     };
     if (complete) {
-      store(&buckets[key]);
+      store(&buckets[cur_key]);
     } else if (first_run) {
       store(&head[seg]);
-      if (par == 0) head_key[seg] = key;
+      if (par == 0) head_key[seg] = cur_key;
     } else {
       store(&tail[seg]);
-      if (par == 0) tail_key[seg] = key;
+      if (par == 0) tail_key[seg] = cur_key;
     }
   };
-#endif
-#if ARK_G2L28_PREFETCH
-  // entry e + 1's key and row index are loaded during entry e (both are needed before anything else can start);
-  // with ARK_G2L28_PREFETCH == 2 the row itself is gathered between the two halves of the addition
-  uint32_t v_next = sorted_vals[start], key_next = cur_key;
-#if ARK_G2L28_PREFETCH == 2
-  uint4 nx[Q];
-  {
-    const uint4* src = reinterpret_cast<const uint4*>(&bases[v_next & ARK_TBL_MASK].half[par]);
-#pragma unroll
-    for (int k = 0; k < Q; k++) nx[k] = src[k];
-  }
-#endif
+  // Key and row index of entry e + 1 are loaded during entry e.  The half row itself is gathered at the top of its own
+  // iteration: held in registers across the lane-pair addition (24 VGPRs) it pushes the hot loop into scratch memory
+  // (39 scratch accesses per addition in the listing), and the G2 kernel loses less to that wait than it would to the
+  // spills -- an addition is 2.2x as long as in G1 and a wave holds 32 segments, not 64.
+  uint32_t k0 = cur_key;
+  uint32_t v0 = sorted_vals[start];
   for (uint32_t e = start; e < end; e++) {
-    const uint32_t key = key_next;
-    const uint32_t v = v_next;
-    F px, py;
+    const uint32_t key = k0;
+    const uint32_t v = v0;
+    uint32_t d[4 * Q];
     {
-      uint32_t d[4 * Q];
-#if ARK_G2L28_PREFETCH == 2
-#pragma unroll
-      for (int k = 0; k < Q; k++) {
-        d[4 * k + 0] = nx[k].x;
-        d[4 * k + 1] = nx[k].y;
-        d[4 * k + 2] = nx[k].z;
-        d[4 * k + 3] = nx[k].w;
-      }
-#else
       const uint4* src = reinterpret_cast<const uint4*>(&bases[v & ARK_TBL_MASK].half[par]);
 #pragma unroll
       for (int k = 0; k < Q; k++) {
@@ -636,76 +603,37 @@ msm_accumulate_g2l28_kernel(const Affine28G2<P>* __restrict__ bases, const uint3
         d[4 * k + 2] = t.z;
         d[4 * k + 3] = t.w;
       }
-#endif
-#pragma unroll
-      for (int k = 0; k < F::N; k++) {
-        px.l[k] = d[k];
-        py.l[k] = d[F::N + k];
-      }
     }
-    const uint32_t en = (e + 1 < end) ? e + 1 : e;       // clamp: the last iteration re-reads its own entry
-    v_next = sorted_vals[en];
-    key_next = sorted_keys[en];
+    k0 = sorted_keys[e < last ? e + 1 : last];
+    v0 = sorted_vals[e < last ? e + 1 : last];
     if (key != cur_key) {
-      flush(cur_key, e);
+      run_end = e;
+      if (!parked) {
+        Park28<P>::store(park_lds, acc, empty, first_run, cur_key, run_start, e);
+        parked = true;
+      } else {
+        flush();
+      }
       cur_key = key;
       run_start = e;
+      run_end = end;
       first_run = false;
       empty = true;
     }
     uint32_t any = 0;
 #pragma unroll
-    for (int k = 0; k < F::N; k++) any |= px.l[k] | py.l[k];
-    F Pd, R;
-    bool more = false;
-    if ((any | ark_pair_xchg(any)) != 0)                 // else: base at infinity (pair-wide)
-      more = madd28_g2_head<P>(acc, empty, px, py, (v >> 31) != 0, Pd, R);
-#if ARK_G2L28_PREFETCH == 2
-    {
-      const uint4* src = reinterpret_cast<const uint4*>(&bases[v_next & ARK_TBL_MASK].half[par]);
-#pragma unroll
-      for (int k = 0; k < Q; k++) nx[k] = src[k];
-    }
-#endif
-    if (more) madd28_g2_tail<P>(acc, Pd, R);
-  }
-#else
-  for (uint32_t e = start; e < end; e++) {
-    const uint32_t key = sorted_keys[e];
-    const uint32_t v = sorted_vals[e];
-    F px, py;
-    {
-      const uint4* src = reinterpret_cast<const uint4*>(&bases[v & ARK_TBL_MASK].half[par]);
-      uint32_t d[4 * Q];
-#pragma unroll
-      for (int k = 0; k < Q; k++) {
-        const uint4 t = src[k];
-        d[4 * k + 0] = t.x;
-        d[4 * k + 1] = t.y;
-        d[4 * k + 2] = t.z;
-        d[4 * k + 3] = t.w;
-      }
-#pragma unroll
-      for (int k = 0; k < F::N; k++) {
-        px.l[k] = d[k];
-        py.l[k] = d[F::N + k];
-      }
-    }
-    if (key != cur_key) {
-      flush(cur_key, e);
-      cur_key = key;
-      run_start = e;
-      first_run = false;
-      empty = true;
-    }
-    uint32_t any = 0;
-#pragma unroll
-    for (int k = 0; k < F::N; k++) any |= px.l[k] | py.l[k];
+    for (int k = 0; k < Row::WORDS; k++) any |= d[k];
     if ((any | ark_pair_xchg(any)) == 0) continue;       // base at infinity (pair-wide)
+    const F px = Row::unpack(d), py = Row::unpack(d + Row::NB);
     madd28_g2<P>(acc, empty, px, py, (v >> 31) != 0);
   }
-#endif
-  flush(cur_key, end);
+#pragma nounroll
+  for (int pass = 0; pass < 2; pass++) {
+    flush();
+    if (!parked) break;
+    Park28<P>::load(park_lds, acc, empty, first_run, cur_key, run_start, run_end);
+    parked = false;
+  }
 }
 
 }  // namespace ark355

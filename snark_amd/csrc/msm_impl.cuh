@@ -1717,22 +1717,9 @@ static void msm_sort(ark355_ctx* ctx, MsmSort& s, const void* d_scalars, uint64_
 // Scratch for the bucket phase of one group type.
 struct MsmBuckets {
   DevBuf buckets, head, tail, head_key, tail_key, partials, heavy_count, heavy_list, lvl_t, lvl_w;
-  DevBuf raw28;                         // [buckets | head | tail] slots of raw 28-bit limbs (ARK_LAZY_FLUSH, msm28_impl.cuh)
   uint32_t seg_len = 32, segs = 0;      // of the last accumulation over this bucket set (G1 and G2 differ)
   bool prepared = false;                // msm_prepare_phase ran for the coming accumulation
-  bool lazy28 = false;                  // that accumulation leaves its runs in raw28; msm_reduce_phase converts them
   bool heavy_cleared = false;           // msm_prepare_phase already cleared heavy_count for the coming merge
-};
-
-template <class F>
-struct msm_slot28 {                     // Params and coordinate count of the raw slots of an XYZZ<F> bucket set
-  using P = typename F::Params;
-  static constexpr int COORDS = 4;
-};
-template <class Q>
-struct msm_slot28<Fp2<Q>> {
-  using P = Q;
-  static constexpr int COORDS = 8;
 };
 
 // Phase 1 of the bucket method over an existing sort: bucket accumulation (the chip-filling kernel).
@@ -1740,14 +1727,12 @@ struct msm_slot28<Fp2<Q>> {
 // stream right behind the sort, so that the accumulation stream carries nothing but accumulation kernels: three small
 // fill kernels in front of every accumulation launch sat behind the other proofs' workgroups and opened a gap between
 // consecutive accumulations (31 fills per proof, 2.5 ms of stream time with four proofs in flight).
-// lazy28: the accumulation will run on a radix-2^28 window table.
 template <class F>
-static void msm_prepare_phase(const TunePolicy& pol, const MsmSort& s, MsmBuckets& b, hipStream_t stream, bool lazy28 = false,
+static void msm_prepare_phase(const TunePolicy& pol, const MsmSort& s, MsmBuckets& b, hipStream_t stream, bool /*bases28*/ = false,
                               FillBatch* fb = nullptr) {
   const MsmPlan& p = s.plan;
   b.prepared = true;
   b.heavy_cleared = false;
-  b.lazy28 = lazy28 && ARK_LAZY_FLUSH;
   if (p.n == 0) return;
   const uint64_t entries = (uint64_t)p.windows * p.n;
   b.seg_len = msm_seg_len(entries, is_fp2<F>::value, pol.msm_seg);
@@ -1758,15 +1743,7 @@ static void msm_prepare_phase(const TunePolicy& pol, const MsmSort& s, MsmBucket
   b.tail.ensure((size_t)segs * sizeof(XYZZ<F>));
   b.head_key.ensure((size_t)segs * 4);
   b.tail_key.ensure((size_t)segs * 4);
-  if (b.lazy28) {
-    // the raw bucket slots are cleared instead: every canonical bucket is written by msm_unlazy28_kernel
-    using S = msm_slot28<F>;
-    const size_t slot = (size_t)S::COORDS * Fp28<typename S::P>::N * 4;
-    b.raw28.ensure(((size_t)p.total_buckets + 2 * (size_t)segs) * slot);
-    fill_bytes(fb, b.raw28.p, 0, (size_t)p.total_buckets * slot, stream);
-  } else {
-    fill_bytes(fb, b.buckets.p, 0, (size_t)p.total_buckets * sizeof(XYZZ<F>), stream);
-  }
+  fill_bytes(fb, b.buckets.p, 0, (size_t)p.total_buckets * sizeof(XYZZ<F>), stream);
   fill_bytes(fb, b.head_key.p, 0xFF, (size_t)segs * 4, stream);
   fill_bytes(fb, b.tail_key.p, 0xFF, (size_t)segs * 4, stream);
   // the heavy-bucket counter of the merge that follows the accumulation (msm_reduce_phase clears it itself otherwise)
@@ -1778,13 +1755,8 @@ static void msm_prepare_phase(const TunePolicy& pol, const MsmSort& s, MsmBucket
 // destination arrays of the 28-bit accumulation kernels: which = 0 buckets, 1 head, 2 tail
 template <class P, int COORDS>
 static Msm28Slot<P, COORDS>* msm_slots28(MsmBuckets& b, uint32_t total_buckets, int which) {
-#if ARK_LAZY_FLUSH
-  Msm28Slot<P, COORDS>* base = b.raw28.as<Msm28Slot<P, COORDS>>();
-  return which == 0 ? base : (which == 1 ? base + total_buckets : base + total_buckets + b.segs);
-#else
   (void)total_buckets;
   return (which == 0 ? b.buckets : (which == 1 ? b.head : b.tail)).as<Msm28Slot<P, COORDS>>();
-#endif
 }
 
 template <class F>
@@ -1794,7 +1766,6 @@ static void msm_accumulate_phase(ark355_ctx* ctx, const MsmSort& s, MsmBuckets& 
   const MsmPlan& p = s.plan;
   if (!b.prepared) msm_prepare_phase<F>(ctx->policy, s, b, stream, bases28);      // stand-alone MSMs: same stream
   b.prepared = false;
-  ARK_REQUIRE(b.lazy28 == (bases28 && ARK_LAZY_FLUSH), ARK355_EINVAL, "bucket set prepared for the other table format");
   if (p.n == 0) return;
   const uint32_t segs = b.segs;
   const uint32_t grid_s = (segs + MSM_THREADS - 1) / MSM_THREADS;
@@ -1873,16 +1844,6 @@ static void msm_reduce_phase(ark355_ctx* ctx, const MsmSort& s, MsmBuckets& b, X
   } else {
     const uint32_t segs = b.segs;
     const uint32_t grid_b = (p.total_buckets + MSM_THREADS - 1) / MSM_THREADS;
-    if (b.lazy28) {
-      using S = msm_slot28<F>;
-      using Fq = Fp<typename S::P>;
-      const uint64_t lanes = ((uint64_t)p.total_buckets + 2ull * segs) * S::COORDS;
-      ARK_LAUNCH((msm_unlazy28_kernel<typename S::P, S::COORDS>), dim3((uint32_t)((lanes + 255) / 256)), dim3(256), 0,
-                 stream, b.raw28.as<uint32_t>(), p.total_buckets, segs, b.head_key.as<uint32_t>(),
-                 b.tail_key.as<uint32_t>(), b.buckets.as<Fq>(), b.head.as<Fq>(), b.tail.as<Fq>());
-      ARK_CHECK_LAUNCH();
-      b.lazy28 = false;
-    }
     // at most entries / (MSM_HEAVY_SPAN * segment length) buckets can be heavy
     const uint32_t max_heavy = segs / MSM_HEAVY_SPAN + 1;
     // "heavy" is relative: twice the average span of a bucket once that exceeds the fixed threshold
@@ -2009,19 +1970,6 @@ static bool msm_reduce_phase_batch(ark355_ctx* ctx, int count, const MsmSort* co
   const uint32_t grid_b = (p0.total_buckets + MSM_THREADS - 1) / MSM_THREADS;
   const uint32_t chunks = (p0.buckets_per_window + MSM_RED_K - 1) / MSM_RED_K;
   const uint32_t blocks_per_window = (chunks + MSM_THREADS - 1) / MSM_THREADS;
-  for (int i = 0; i < count; i++) {
-    MsmBuckets& b = *bks[i];
-    if (!b.lazy28) continue;
-    // lazy-flush build (ARK_LAZY_FLUSH): the runs were stored as raw 28-bit limbs; convert them in front of the merge
-    using S = msm_slot28<F>;
-    using Fq = Fp<typename S::P>;
-    const uint64_t lanes = ((uint64_t)p0.total_buckets + 2ull * b.segs) * S::COORDS;
-    ARK_LAUNCH((msm_unlazy28_kernel<typename S::P, S::COORDS>), dim3((uint32_t)((lanes + 255) / 256)), dim3(256), 0, stream,
-               b.raw28.as<uint32_t>(), p0.total_buckets, b.segs, b.head_key.as<uint32_t>(), b.tail_key.as<uint32_t>(),
-               b.buckets.as<Fq>(), b.head.as<Fq>(), b.tail.as<Fq>());
-    ARK_CHECK_LAUNCH();
-    b.lazy28 = false;
-  }
   TailBatch<F> tb;
   memset(&tb, 0, sizeof(tb));
   uint32_t max_heavy_all = 1;

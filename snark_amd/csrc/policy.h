@@ -45,6 +45,9 @@ struct TunePolicy {
   int32_t side_g2_tails = 1;      // a one-stream proof ALONE on the device: its G2 tails on a second stream, under the G1 accumulations
   int32_t dwm_loopback = 0;       // DIAGNOSTIC (timing only, wrong proofs): ark355_prove_shard runs the distributed witness map of its
                                   // rank with the exchanges as local copies -- the per-rank cost of a G-GPU proof on one GPU
+  int32_t rccl_self = 0;          // DIAGNOSTIC / TEST (read when a key shard is loaded and per proof): at world size 1 a sharded proof runs
+                                  // the distributed witness map and the bucket ring with every exchange as a grouped ncclSend / ncclRecv to
+                                  // the rank ITSELF -- the point-to-point calls of an 8-GPU proof on the one GPU a test box has; same proof bytes
   // ---- per key load
   int32_t msm_c = 0;              // window size of resident tables (0: planner)
   int32_t msm_c_h = 0;            // window size of the h_query table alone (0: same rule as the others)
@@ -101,6 +104,7 @@ inline const TunePolicy::Field* TunePolicy::fields(int* count) {
       ARK_POLICY_FIELD64("HBM_BUDGET_MB", hbm_budget_mb),
       ARK_POLICY_FIELD32("SHARD_DIST_WM", shard_dist_wm),
       ARK_POLICY_FIELD32("DWM_LOOPBACK", dwm_loopback),
+      ARK_POLICY_FIELD32("RCCL_SELF", rccl_self),
       ARK_POLICY_FIELD32("MSM_SEG", msm_seg),
       ARK_POLICY_FIELD32("SORT_LEGACY", sort_legacy),
       ARK_POLICY_FIELD32("G2_INLINE", g2_inline),

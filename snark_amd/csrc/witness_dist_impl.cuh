@@ -147,7 +147,10 @@ dwm_gather_kernel(const Fr* __restrict__ h, Fr* __restrict__ h_loc, uint32_t mc,
   h_loc[i] = h[(uint64_t)rank * mc + j + m_local * k2];
 }
 
-static inline bool dwm_supported(uint32_t log_n, uint32_t world) {
+// self_one: policy RCCL_SELF -- world size 1 runs the same stages with 1-point "rank-crossing" transforms and the rank as its
+// own peer (the exchange code of an 8-GPU proof on the one GPU of a test box)
+static inline bool dwm_supported(uint32_t log_n, uint32_t world, bool self_one = false) {
+  if (world == 1) return self_one && log_n >= 3;
   if (world < 2 || (world & (world - 1)) != 0) return false;
   uint32_t lg = 0;
   while ((1u << lg) < world) lg++;
@@ -214,6 +217,7 @@ static void dwm_stage_b(ark355_ctx* ctx, const R1csDev& r, uint32_t world, uint3
              roots, (const Fr*)t->w_lo.as<Fr>(), (const Fr*)t->w_hi.as<Fr>(), (const Fr*)t->wi_lo.as<Fr>(),                      \
              (const Fr*)t->wi_hi.as<Fr>(), t->lo_bits, seam)
   switch (lg) {
+    case 0: ARK_DWM_SEAM(0); break;
     case 1: ARK_DWM_SEAM(1); break;
     case 2: ARK_DWM_SEAM(2); break;
     case 3: ARK_DWM_SEAM(3); break;
@@ -263,6 +267,7 @@ static void dwm_stage_d(ark355_ctx* ctx, const R1csDev& r, uint32_t world, uint3
              (const Fr*)t->wi_lo.as<Fr>(), (const Fr*)t->wi_hi.as<Fr>(), (const Fr*)t->gi_lo.as<Fr>(),                         \
              (const Fr*)t->gi_hi.as<Fr>(), t->lo_bits)
   switch (lg) {
+    case 0: ARK_DWM_FINAL(0); break;
     case 1: ARK_DWM_FINAL(1); break;
     case 2: ARK_DWM_FINAL(2); break;
     case 3: ARK_DWM_FINAL(3); break;
@@ -277,9 +282,11 @@ static void dwm_stage_d(ark355_ctx* ctx, const R1csDev& r, uint32_t world, uint3
 // all-to-all of `nvec` vectors: chunk p (mc elements) of send vector v goes to rank p, which stores it as chunk (my rank)
 // of its recv vector v.  send / recv vector strides in elements.  loopback (diagnostic policy DWM_LOOPBACK: the per-rank
 // COST of a G-rank map measured on one GPU, results meaningless): every chunk is copied locally instead.
+// self_rccl (policy RCCL_SELF): the rank's own chunk travels through ncclSend / ncclRecv as well (peer = own rank, inside the
+// same group) instead of a device-to-device copy; at world size 1 that is the whole exchange.
 template <class Fr>
 static void dwm_all_to_all(CommDev* cm, uint32_t world, uint32_t rank, const Fr* send, uint64_t send_stride, Fr* recv,
-                           uint64_t recv_stride, uint32_t nvec, uint32_t mc, hipStream_t stream, bool loopback) {
+                           uint64_t recv_stride, uint32_t nvec, uint32_t mc, hipStream_t stream, bool loopback, bool self_rccl = false) {
   const size_t bytes = (size_t)mc * sizeof(Fr);
   for (uint32_t v = 0; v < nvec; v++) {
     const Fr* s = send + (uint64_t)v * send_stride;
@@ -288,13 +295,15 @@ static void dwm_all_to_all(CommDev* cm, uint32_t world, uint32_t rank, const Fr*
       ARK_CHECK_HIP(hipMemcpyAsync(d, s, bytes * world, hipMemcpyDeviceToDevice, stream));
       continue;
     }
-    ARK_CHECK_HIP(hipMemcpyAsync(d + (uint64_t)rank * mc, s + (uint64_t)rank * mc, bytes, hipMemcpyDeviceToDevice, stream));
+    if (!self_rccl)
+      ARK_CHECK_HIP(hipMemcpyAsync(d + (uint64_t)rank * mc, s + (uint64_t)rank * mc, bytes, hipMemcpyDeviceToDevice, stream));
   }
   if (loopback) return;
   ARK_REQUIRE(cm && cm->world == (int)world && cm->rank == (int)rank, ARK355_EINVAL, "distributed witness map: communicator mismatch");
+  if (world == 1 && !self_rccl) return;
   ARK_CHECK_NCCL(ncclGroupStart());
   for (uint32_t p = 0; p < world; p++) {
-    if (p == rank) continue;
+    if (p == rank && !self_rccl) continue;
     for (uint32_t v = 0; v < nvec; v++) {
       ARK_CHECK_NCCL(ncclSend(send + (uint64_t)v * send_stride + (uint64_t)p * mc, bytes, ncclUint8, (int)p, cm->comm, stream));
       ARK_CHECK_NCCL(ncclRecv(recv + (uint64_t)v * recv_stride + (uint64_t)p * mc, bytes, ncclUint8, (int)p, cm->comm, stream));
@@ -306,19 +315,19 @@ static void dwm_all_to_all(CommDev* cm, uint32_t world, uint32_t rank, const Fr*
 // One rank's distributed witness map.  Returns h_loc (M = N / world elements, layout of the header comment).
 template <class Curve>
 static void* witness_map_dist_run(ark355_ctx* ctx, const R1csDev& r, const void* d_z, DwmScratch& sc, CommDev* cm, uint32_t world,
-                                  uint32_t rank, hipStream_t stream, bool loopback = false) {
+                                  uint32_t rank, hipStream_t stream, bool loopback = false, bool self_rccl = false) {
   using Fr = typename Curve::Fr;
-  ARK_REQUIRE(dwm_supported(r.log_n, world), ARK355_EINVAL, "distributed witness map: world size / domain not supported");
+  ARK_REQUIRE(dwm_supported(r.log_n, world, self_rccl), ARK355_EINVAL, "distributed witness map: world size / domain not supported");
   uint32_t lg = 0;
   while ((1u << lg) < world) lg++;
   const uint64_t M = r.N >> lg;
   const uint32_t mc = (uint32_t)(M >> lg);
   Fr* y = dwm_stage_a<Curve>(ctx, r, d_z, world, rank, sc, stream);
-  dwm_all_to_all<Fr>(cm, world, rank, y, 2 * M, sc.recv.as<Fr>(), M, 3, mc, stream, loopback);
+  dwm_all_to_all<Fr>(cm, world, rank, y, 2 * M, sc.recv.as<Fr>(), M, 3, mc, stream, loopback, self_rccl);
   dwm_stage_b<Curve>(ctx, r, world, rank, sc, stream);
-  dwm_all_to_all<Fr>(cm, world, rank, sc.send.as<Fr>(), M, sc.ws.buf[0].as<Fr>(), 2 * M, 3, mc, stream, loopback);
+  dwm_all_to_all<Fr>(cm, world, rank, sc.send.as<Fr>(), M, sc.ws.buf[0].as<Fr>(), 2 * M, 3, mc, stream, loopback, self_rccl);
   Fr* q = dwm_stage_c<Curve>(ctx, r, world, sc, stream);
-  dwm_all_to_all<Fr>(cm, world, rank, q, M, sc.recv.as<Fr>(), M, 1, mc, stream, loopback);
+  dwm_all_to_all<Fr>(cm, world, rank, q, M, sc.recv.as<Fr>(), M, 1, mc, stream, loopback, self_rccl);
   dwm_stage_d<Curve>(ctx, r, world, rank, sc, stream);
   return sc.h.p;
 }

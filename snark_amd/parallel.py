@@ -6,11 +6,14 @@ the channel the host already has (here `torch.distributed`'s broadcast; any IPC 
 
 The path partitions cleanly: sum_i k_i P_i splits over disjoint term ranges and the partial sums combine by
 group addition.  Each rank keeps terms [T*g/G, T*(g+1)/G) of the five (extended) query vectors resident
-(window tables included), computes the witness map h redundantly from z (7 NTTs of <= 256 MiB cost ~3 ms; an
-all-to-all transpose over point-to-point xGMI would cost more), runs its five partial MSMs and contributes ONE
-message of `ark355_partial_size()` bytes (960 B for BLS12-381) to an all-gather issued by the library on its reduction
+(window tables included).  The witness map is sharded as well (round 4, csrc/witness_dist_impl.cuh): a rank owns 1/G
+of every vector through the whole map, three all-to-all exchanges (grouped ncclSend / ncclRecv on the witness-map
+stream) move the vectors between the two layouts of the four-step transform, and the rank's share of h comes out in
+the order its shard of `h_query` was loaded in; world sizes that are not a power of two (or domains too small) keep
+the replicated map, where every rank computes h from z itself.  The rank then runs its five partial MSMs and contributes
+ONE message of `ark355_partial_size()` bytes (960 B for BLS12-381) to an all-gather issued by the library on its reduction
 stream, straight from HBM; `mode=SHARD_BUCKET_RING` selects the bucket-level ring reduce-scatter instead (the literal
-"all-reduce of partial bucket sums").  Every rank ends up with the same, byte-identical proof.
+"all-reduce of partial bucket sums"; it keeps the replicated map).  Every rank ends up with the same, byte-identical proof.
 
 Independent proofs (BASELINE.json configs[4], and bench.py's default multi-GPU mode) need no collective at all:
 one `Groth16` instance per rank.

@@ -466,8 +466,10 @@ static int run_prove(const std::string& circuit, size_t n) {
 // different seeds, K synthesis threads feeding `inflight` in-flight GPU proofs (Groth16::prove_pipelined), next to the
 // device-only figure (the same assignments already synthesised, ark355_prove_batch).  Prints constraints/s for both
 // and checks every pipelined proof against the batch proof with the same randomisers.
+// circuit "benchlc": the S3 shape (the reference's own benchmark circuit, relations/examples/bench.rs:22-83, made satisfiable:
+// BenchLc above; every instance synthesises the same system, as the reference's benchmark does) instead of the S2 mulchain.
 template <class C>
-static int run_e2e(size_t n, size_t count, uint32_t synth_threads, uint32_t inflight) {
+static int run_e2e(size_t n, size_t count, uint32_t synth_threads, uint32_t inflight, bool benchlc = false) {
   using G = ark_snark::Groth16<C>;
   using F = typename G::Fr;
   auto be = std::make_shared<ark_snark::Backend>(0);
@@ -475,7 +477,8 @@ static int run_e2e(size_t n, size_t count, uint32_t synth_threads, uint32_t infl
   uint64_t seq[] = {0x1234567, 11, 22, 33, 44};
   size_t pos = 0;
   typename G::Rng rng = [&]() { return F::from_u64(seq[pos++ % 5]); };
-  auto make = [n](size_t i) -> std::unique_ptr<ConstraintSynthesizer<F>> {
+  auto make = [n, benchlc](size_t i) -> std::unique_ptr<ConstraintSynthesizer<F>> {
+    if (benchlc) return std::unique_ptr<ConstraintSynthesizer<F>>(new BenchLc<F>(n, 0x355));
     return std::unique_ptr<ConstraintSynthesizer<F>>(new MulChain<F>(F::from_u64(0x355 + 2 * i), F::from_u64(0x356 + 2 * i), n));
   };
   auto c0 = make(0);
@@ -575,12 +578,13 @@ int main(int argc, char** argv) {
     }
   }
   if (argc >= 7 && std::string(argv[1]) == "--e2e") {
-    // --e2e <curve> <n> <count> <synth_threads> <inflight>
+    // --e2e <curve> <n> <count> <synth_threads> <inflight> [mulchain | benchlc]
     const size_t n = strtoull(argv[3], nullptr, 10), count = strtoull(argv[4], nullptr, 10);
     const uint32_t k = (uint32_t)atoi(argv[5]), inflight = (uint32_t)atoi(argv[6]);
+    const bool benchlc = argc >= 8 && std::string(argv[7]) == "benchlc";
     try {
-      if (std::string(argv[2]) == "bn254") return run_e2e<ark_snark::BnCurveTag>(n, count, k, inflight);
-      return run_e2e<ark_snark::BlsCurveTag>(n, count, k, inflight);
+      if (std::string(argv[2]) == "bn254") return run_e2e<ark_snark::BnCurveTag>(n, count, k, inflight, benchlc);
+      return run_e2e<ark_snark::BlsCurveTag>(n, count, k, inflight, benchlc);
     } catch (const std::exception& e) {
       fprintf(stderr, "error: %s\n", e.what());
       return 2;

@@ -49,15 +49,6 @@ static void run_g1(const char* name) {
     uint32_t k[2] = {(uint32_t)rng.next() | 1u, (uint32_t)rng.next()};
     pts.push_back(xyzz_to_affine(xyzz_mul_scalar(XYZZ<Fq>::from_affine(g), k, 2)));
   }
-  std::vector<Affine28<P>> rows(NP);
-  for (size_t i = 0; i < NP; i++) {
-    const F28 x = F28::from_fp(pts[i].x), y = F28::from_fp(pts[i].y);
-    for (int k = 0; k < Affine28<P>::WORDS; k++) rows[i].w[k] = 0;
-    for (int k = 0; k < F28::N; k++) {
-      rows[i].w[k] = x.l[k];
-      rows[i].w[F28::N + k] = y.l[k];
-    }
-  }
   for (int trial = 0; trial < 12; trial++) {
     XYZZ<Fq> ref = XYZZ<Fq>::inf();
     Acc28<P> acc;

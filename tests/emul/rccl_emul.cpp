@@ -113,7 +113,7 @@ ncclResult_t progress(emuNcclComm* c) {
 
 ncclResult_t enqueue(emuNcclComm* c, Op op) {
   if (!c || op.peer < 0 || op.peer >= c->world) return ncclInvalidArgument;
-  if (op.peer == c->rank) return ncclInvalidUsage;          // self send/recv is not used by the library
+  if (op.peer == c->rank && g_group_depth == 0) return ncclInvalidUsage;   // a send to self needs its receive in the same group (as in RCCL)
   c->pending.push_back(op);
   if (g_group_depth == 0) return progress(c);
   bool known = false;

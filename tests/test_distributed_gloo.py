@@ -39,6 +39,11 @@ def _make_key(n, path):
 
 def _worker(rank, world, port, n, key_path, modes, whole, q, stride_on_rank1=None):
     try:
+        if stride_on_rank1 == "rccl_self":
+            # world size 1, the rank as its own peer: every exchange of the distributed witness map and one ring step per MSM go
+            # through grouped ncclSend / ncclRecv to rank 0 itself (policy RCCL_SELF; the GPU tier runs the same on real RCCL)
+            os.environ["ARK355_RCCL_SELF"] = "1"
+            stride_on_rank1 = None
         if stride_on_rank1 and rank == 1:
             # this rank alone plans its tables differently ("2": another window stride) or lays its h_query shard out for the
             # replicated witness map ("dist_wm=0")
@@ -95,9 +100,10 @@ def _worker(rank, world, port, n, key_path, modes, whole, q, stride_on_rank1=Non
             # single-device proof of the same statement
             ok = ok and (g.prove(pk, r1, z, r=12345, s=67890) == closed)
         # the whole-key entry point must refuse a shard handle
-        refused = False
+        refused = world == 1           # (a "shard" of one is the whole key)
         try:
-            lib.prove(g.ctx, sg.load_pk_shard(pk), g.load_r1cs(r1), zb, r1.m, cv.fr_canon(1), cv.fr_canon(2), g.sizes)
+            if world > 1:
+                lib.prove(g.ctx, sg.load_pk_shard(pk), g.load_r1cs(r1), zb, r1.m, cv.fr_canon(1), cv.fr_canon(2), g.sizes)
         except Exception as e:
             refused = getattr(e, "code", None) == -1
         q.put((rank, ok, refused, proof_w.a.hex()))
@@ -141,6 +147,13 @@ def test_sharded_prove_over_the_c_abi_comm(world, n, modes, tmp_path):
 def test_sharded_prove_small_instance_all_modes(world, tmp_path):
     """Both modes, plus the single-device proof of the same statement, at a size the emulator proves in seconds."""
     _run(world, 150, tmp_path)
+
+
+def test_sharded_prove_self_exchange_world_size_1(tmp_path):
+    """Policy RCCL_SELF at world size 1: the key "shard" is loaded in the layout of the distributed witness map, its three
+    all-to-alls and one ring step per MSM run as grouped send / receive pairs of the rank with itself; same proof bytes as
+    the closed form and the single-device proof."""
+    _run(1, 150, tmp_path, stride_on_rank1="rccl_self")
 
 
 def test_sharded_prove_tiny_instance_with_empty_shards(tmp_path):

@@ -206,6 +206,9 @@ def test_sharded_prove_over_rccl():
                          timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     assert "rccl_ok 1" in out.stdout
+    # the second pass of the helper: the rank as its own RCCL peer (grouped ncclSend / ncclRecv to self in the witness map's
+    # all-to-alls and in the bucket ring), byte-identical proofs
+    assert "rccl_self 1 ok" in out.stdout
 
 
 @pytest.mark.parametrize("C", [BLS12_381, BN254], ids=lambda c: c.name)

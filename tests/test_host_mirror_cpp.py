@@ -15,19 +15,7 @@ EXE = os.path.join(CPP_DIR, "test_host_mirror")
 def exe():
     from snark_amd import build
     build.build(verbose=False)
-    src = os.path.join(CPP_DIR, "test_host_mirror.cpp")
-    deps = [src] + [os.path.join(ROOT, "host_mirror", f) for f in ("relations.hpp", "snark.hpp")]
-    # rebuild whenever the sources differ from what the binary was built from (content hash, not mtime: a stale binary
-    # from another checkout must never run in place of the current sources)
-    import hashlib
-    h = hashlib.sha256()
-    for d in deps + [os.path.join(ROOT, "include", "ark355.h")]:
-        h.update(open(d, "rb").read())
-    stamp = EXE + ".srchash"
-    if not os.path.exists(EXE) or not os.path.exists(stamp) or open(stamp).read() != h.hexdigest():
-        subprocess.check_call(["g++", "-O2", "-pthread", "-std=c++17", src, "-o", EXE, "-L" + os.path.join(ROOT, "snark_amd"),
-                               "-lark355", "-Wl,-rpath," + os.path.join(ROOT, "snark_amd")])
-        open(stamp, "w").write(h.hexdigest())
+    assert build.build_host_mirror_exe() == EXE
     return EXE
 
 

@@ -19,13 +19,13 @@ using namespace ark355;
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
 
 enum { OP_MAD_U64, OP_MAD_I64, OP_LSHL_ADD_U64, OP_LSHR_B64, OP_AND, OP_SUB, OP_MUL_LO, OP_MUL_HI, OP_CNDMASK, OP_DPP, OP_FMA64,
-       OP_ADD64_PAIR, OP_ALIGNBIT, OP_MAD_U24, OP_MIX_MAD_AND, OP_MIX_MAD_ADD64, OP_MAD_DEP, OP_ADD3, OP_XAD, OP_COUNT };
+       OP_ADD64_PAIR, OP_ALIGNBIT, OP_MAD_U24, OP_MIX_MAD_AND, OP_MIX_MAD_ADD64, OP_MAD_DEP, OP_ADD3, OP_XAD, OP_CNDMASK_SGPR, OP_BFI, OP_DS_WRITE, OP_COUNT };
 static const char* OP_NAME[OP_COUNT] = {"v_mad_u64_u32", "v_mad_i64_i32", "v_lshl_add_u64", "v_lshrrev_b64", "v_and_b32", "v_sub_u32",
   "v_mul_lo_u32", "v_mul_hi_u32", "v_cndmask_b32", "v_mov_b32_dpp", "v_fma_f64", "v_add_co+v_addc_co (pair)", "v_alignbit_b32",
   "v_mad_u32_u24", "mix 3 mad_u64 : 1 and (4)", "mix 1 mad_u64 : 1 lshl_add_u64 (2)", "v_mad_u64_u32 ONE dependent chain", "v_add3_u32",
-  "v_xad_u32"};
+  "v_xad_u32", "v_cndmask_b32_e64 (SGPR-pair mask)", "v_bfi_b32", "ds_write_b32 (stride 1 KiB, own lane)"};
 // instructions per unrolled group of 8 chains
-static const int OP_PER_GROUP[OP_COUNT] = {8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 16, 8, 8, 32, 16, 8, 8, 8};
+static const int OP_PER_GROUP[OP_COUNT] = {8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 16, 8, 8, 32, 16, 8, 8, 8, 8, 8, 8};
 
 template <int OP, int WAVES>
 __global__ void __launch_bounds__(256, WAVES) k_instr(uint64_t* out, uint64_t* cyc, uint32_t a0, int iters) {
@@ -36,6 +36,10 @@ __global__ void __launch_bounds__(256, WAVES) k_instr(uint64_t* out, uint64_t* c
 #pragma unroll
   for (int i = 0; i < 8; i++) { acc[i] = (uint64_t)(i * 77 + a) << 7; f[i] = 1.0 + i + a * 1e-9; w[i] = a * (i + 3); w2[i] = b + i; }
   const double fc = 1.0000001, fd = 0.5;
+  const uint64_t smask = __ballot((threadIdx.x & 1) != 0);       // lane-parity mask in an SGPR pair (what Pair28::sel selects on)
+  __shared__ uint32_t lds_buf[OP == OP_DS_WRITE ? 256 : 1];
+  const uint32_t lds_addr = (uint32_t)(threadIdx.x * 4);
+  (void)lds_buf;
   const uint64_t t0 = __builtin_readcyclecounter();
   for (int it = 0; it < iters; it++) {
 #pragma unroll
@@ -70,6 +74,9 @@ __global__ void __launch_bounds__(256, WAVES) k_instr(uint64_t* out, uint64_t* c
         if (OP == OP_MAD_DEP) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc[0]) : "v"(a), "v"(b) : "vcc");
         if (OP == OP_ADD3) asm volatile("v_add3_u32 %0, %1, %2, %0" : "+v"(w[i]) : "v"(a), "v"(b));
         if (OP == OP_XAD) asm volatile("v_xad_u32 %0, %1, %2, %0" : "+v"(w[i]) : "v"(a), "v"(b));
+        if (OP == OP_CNDMASK_SGPR) asm volatile("v_cndmask_b32_e64 %0, %1, %0, %2" : "+v"(w[i]) : "v"(b), "s"(smask));
+        if (OP == OP_BFI) asm volatile("v_bfi_b32 %0, %1, %2, %0" : "+v"(w[i]) : "v"(a), "v"(b));
+        if (OP == OP_DS_WRITE) asm volatile("ds_write_b32 %0, %1 offset:%2" : : "v"(lds_addr), "v"(w[i]), "n"(1024 * 0) : "memory");
       }
     }
   }
@@ -136,9 +143,7 @@ __global__ void __launch_bounds__(256, 2) k_madd28(Acc28<P>* out, uint64_t* cyc,
   const uint64_t t0 = __builtin_readcyclecounter();
   for (int it = 0; it < iters; it++) {
     const Affine28<P>& row = in[(t * 7 + it * 13) & 1023];
-    F px, py;
-#pragma unroll
-    for (int k = 0; k < F::N; k++) { px.l[k] = row.w[k]; py.l[k] = row.w[F::N + k]; }
+    const F px = Affine28<P>::unpack(row.w), py = Affine28<P>::unpack(row.w + Affine28<P>::NB);
     madd28<P>(acc, empty, px, py, (it & 1) != 0);
   }
   const uint64_t t1 = __builtin_readcyclecounter();
@@ -156,9 +161,7 @@ __global__ void __launch_bounds__(256, ARK_G2L28_WAVES) k_madd28_g2(Acc28<P>* ou
   const uint64_t t0 = __builtin_readcyclecounter();
   for (int it = 0; it < iters; it++) {
     const Affine28<P>& row = in[(seg * 7 + it * 13) & 511].half[par];
-    F px, py;
-#pragma unroll
-    for (int k = 0; k < F::N; k++) { px.l[k] = row.w[k]; py.l[k] = row.w[F::N + k]; }
+    const F px = Affine28<P>::unpack(row.w), py = Affine28<P>::unpack(row.w + Affine28<P>::NB);
     madd28_g2<P>(acc, empty, px, py, (it & 1) != 0);
   }
   const uint64_t t1 = __builtin_readcyclecounter();
@@ -215,7 +218,8 @@ int main() {
   run_instr_both<OP_MUL_HI>(r, cus); run_instr_both<OP_CNDMASK>(r, cus); run_instr_both<OP_DPP>(r, cus); run_instr_both<OP_FMA64>(r, cus);
   run_instr_both<OP_ADD64_PAIR>(r, cus); run_instr_both<OP_ALIGNBIT>(r, cus); run_instr_both<OP_MAD_U24>(r, cus);
   run_instr_both<OP_MIX_MAD_AND>(r, cus); run_instr_both<OP_MIX_MAD_ADD64>(r, cus); run_instr_both<OP_MAD_DEP>(r, cus);
-  run_instr_both<OP_ADD3>(r, cus); run_instr_both<OP_XAD>(r, cus);
+  run_instr_both<OP_ADD3>(r, cus); run_instr_both<OP_XAD>(r, cus); run_instr_both<OP_CNDMASK_SGPR>(r, cus);
+  run_instr_both<OP_BFI>(r, cus); run_instr_both<OP_DS_WRITE>(r, cus);
   {   // counter rate: a kernel of known duration
     Run q = r; q.blocks = cus * 2;
     const float ms = time_it([&] { hipLaunchKernelGGL((k_instr<OP_MAD_U64, 2>), dim3(q.blocks), dim3(256), 0, 0, (uint64_t*)q.out, q.cyc, 1u, q.iters); }, 1);
@@ -236,8 +240,8 @@ int main() {
   printf("--- part 3: Fp28 product and mixed additions ---\n");
   {   // valid-ish inputs: small canonical limbs
     uint32_t* h = (uint32_t*)calloc(1024 * 512 / 4, 4);
-    for (int i = 0; i < 1024 * 128; i++) h[i] = ((uint32_t)i * 2654435761u) >> 4;
-    for (int i = 0; i < 1024 * 128; i += 32) { h[i + 13] &= 0xFFFFF; h[i + 27] &= 0xFFFFF; h[i + 28] = h[i + 29] = h[i + 30] = h[i + 31] = 0; }
+    for (int i = 0; i < 1024 * 128; i++) h[i] = ((uint32_t)i * 2654435761u);
+    for (int i = 0; i < 1024 * 128; i += 4) h[i + 3] &= 0xFFFFF;      // every coordinate (8 or 12 words) stays below its modulus
     hipMemcpy(r.in, h, 1024 * 512, hipMemcpyHostToDevice); free(h);
   }
   {
