@@ -115,11 +115,12 @@ def cpu_baseline(curve_name, log_n_sample=None):
 
 
 def e2e_reading(curve, n, inflight, device_value):
-    """SURVEY 8f-4, outside the timed region: SNARK::prove WITH synthesis in the loop on the reference's own benchmark shape
-    (relations/examples/bench.rs:22-83 made satisfiable: S3 / BenchLc).  K witness-only synthesis threads (one constraint
-    system each -- the reference's ConstraintSystemRef is Rc<RefCell>, so a thread per proof is its parallel unit) hand
-    assignments in page-locked buffers to `inflight` proving threads (Groth16::prove_pipelined of host_mirror/snark.hpp, the
-    C++ stand-in for a Rust host; tests/cpp/test_host_mirror --e2e).  Runs in its own process with its own key."""
+    """SURVEY 8f-4, outside the timed region: SNARK::prove WITH synthesis in the loop.  K witness-only synthesis threads (one
+    constraint system each -- the reference's ConstraintSystemRef is Rc<RefCell>, so a thread per proof is its parallel unit)
+    hand assignments in page-locked buffers to `inflight` proving threads (Groth16::prove_pipelined of host_mirror/snark.hpp,
+    the C++ stand-in for a Rust host; tests/cpp/test_host_mirror --e2e), in its own process with its own key.  Two circuits:
+    S3 = the reference's own benchmark shape (relations/examples/bench.rs:22-83 made satisfiable: up to ten terms per linear
+    combination, ~45 field multiplications of host work per constraint) and S2 = the bench's own mulchain (one)."""
     import subprocess
     try:
         from snark_amd import build as B
@@ -132,28 +133,35 @@ def e2e_reading(curve, n, inflight, device_value):
         except (OSError, ValueError, IndexError):
             pass
         threads = max(2, min(12, quota - 2 - inflight // 2))
-        count = 6 * inflight
         env = dict(os.environ)
         env.pop("ARK355_E2E_SWEEP", None)
-        t0 = time.perf_counter()
-        r = subprocess.run([exe, "--e2e", curve, str(n), str(count), str(threads), str(inflight), "benchlc"],
-                           capture_output=True, text=True, timeout=240, env=env)
-        kv = dict(l.split("=", 1) for l in r.stdout.splitlines() if "=" in l and not l.startswith("sweep"))
-        if r.returncode != 0 or "e2e_constraints_per_s" not in kv:
-            return {"error": "rc=%d %s" % (r.returncode, (r.stderr or r.stdout)[-200:])}
-        val = float(kv["e2e_constraints_per_s"])
-        dev = float(kv.get("device_only_pinned_constraints_per_s", kv.get("device_only_constraints_per_s", 0)))
-        synth_cpu = float(kv["e2e_synth_cpu_s"])
-        wall = float(kv["e2e_wall_s"])
-        out = {"value": val, "unit": "constraints/s", "circuit": "S3 bench-LC (relations/examples/bench.rs shape), n=%d" % n,
-               "proofs": count, "synthesis_threads": threads, "inflight": inflight, "host_cpu_quota_cores": quota,
-               "synthesis_cpu_cores_used": synth_cpu / wall if wall > 0 else None,
-               "device_only_same_process": dev, "ratio_to_device_only_same_process": val / dev if dev else None,
-               "ratio_to_value": val / device_value if device_value else None,
-               "seconds": round(time.perf_counter() - t0, 2),
+        out = {"unit": "constraints/s", "synthesis_threads": threads, "inflight": inflight, "host_cpu_quota_cores": quota,
                "host": "C++ mirror of ark-relations (host_mirror/), witness-only synthesis; a Rust host runs the real crate"}
-        out["bound"] = ("device" if out["ratio_to_device_only_same_process"] and out["ratio_to_device_only_same_process"] >= 0.9
-                        else "host synthesis (%d threads of a %d-core quota)" % (threads, quota))
+        for tag, circuit, count, extra in (("s3_bench_lc", "benchlc", 2 * inflight, ["e2e-only"]), ("s2_mulchain", "mulchain", 6 * inflight, [])):
+            t0 = time.perf_counter()
+            try:
+                r = subprocess.run([exe, "--e2e", curve, str(n), str(count), str(threads), str(inflight), circuit] + extra,
+                                   capture_output=True, text=True, timeout=150, env=env)
+            except subprocess.TimeoutExpired:
+                out[tag] = {"error": "timed out after 150 s"}
+                continue
+            kv = dict(l.split("=", 1) for l in r.stdout.splitlines() if "=" in l and not l.startswith("sweep"))
+            if r.returncode != 0 or "e2e_constraints_per_s" not in kv:
+                out[tag] = {"error": "rc=%d %s" % (r.returncode, (r.stderr or r.stdout)[-200:])}
+                continue
+            val, wall = float(kv["e2e_constraints_per_s"]), float(kv["e2e_wall_s"])
+            rec = {"value": val, "proofs": count, "n": n, "ratio_to_value": val / device_value if device_value else None,
+                   "synthesis_cpu_cores_used": float(kv["e2e_synth_cpu_s"]) / wall if wall > 0 else None,
+                   "seconds": round(time.perf_counter() - t0, 2)}
+            dev = float(kv.get("device_only_pinned_constraints_per_s", 0))
+            if dev:
+                rec["device_only_same_process"] = dev
+                rec["ratio_to_device_only_same_process"] = val / dev
+            best = max(rec["ratio_to_value"] or 0, rec.get("ratio_to_device_only_same_process") or 0)
+            rec["bound"] = "device" if best >= 0.9 else "host synthesis (%d threads of a %d-core quota)" % (threads, quota)
+            out[tag] = rec
+        if "value" in out.get("s3_bench_lc", {}):
+            out["value"] = out["s3_bench_lc"]["value"]
         return out
     except Exception as e:                                    # noqa: BLE001
         return {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
@@ -179,11 +187,17 @@ def thread_cpu_times():
 
 def pmc_traffic(n, curve):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (FETCH_SIZE and
-    WRITE_SIZE, separate runs; profiles/README.md).  None when no profile of this workload is on file."""
+    WRITE_SIZE, separate runs; profiles/README.md).  profiles/pmc_latest.json holds one record per workload
+    ("workloads": {"<curve>:n=<constraints>": {...}}; the single-record layout of rounds 3-4 is still read).  None when
+    no profile of this workload is on file."""
     path = os.path.join(ROOT, "profiles", "pmc_latest.json")
     try:
-        rec = json.load(open(path))
-        if rec.get("workload") != "%s:n=%d" % (curve, n):
+        top = json.load(open(path))
+        key = "%s:n=%d" % (curve, n)
+        rec = (top.get("workloads") or {}).get(key)
+        if rec is None and top.get("workload") == key:
+            rec = top
+        if rec is None:
             return None, None
         k = rec["msm_accumulate_kernel"]
         note = ("static: FETCH_SIZE + WRITE_SIZE of rocprofv3 --pmc passes recorded in profiles/pmc_latest.json (%s), "

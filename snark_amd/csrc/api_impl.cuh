@@ -64,7 +64,6 @@ fixed_base_mul_kernel(const Affine<F>* __restrict__ table, const Fr* __restrict_
 struct GenericScratch {
   MsmSort sort;
   MsmBuckets bk;
-  BaScratch ba;
   DevBuf a, b, c;
 };
 
@@ -177,13 +176,8 @@ struct Api {
     ARK_CHECK_HIP(hipEventCreate(&e1));
     try {
       msm_sort<Fr>(ctx, g.sort, d_scalars, n, mont, st, tab);
-      if (tab != nullptr && tab->batch_affine) {
-        const MsmSort& tail = msm_ba_accumulate_phase<F>(ctx, g.sort, g.bk, g.ba, d_bases, st, n ? e0 : nullptr, n ? e1 : nullptr);
-        msm_reduce_phase<F>(ctx, tail, g.bk, d_res, 0, st);
-      } else {
-        msm_buckets<F>(ctx, g.sort, g.bk, d_bases, d_res, 0, st, n ? e0 : nullptr, n ? e1 : nullptr,
-                       tab != nullptr && tab->limb28);
-      }
+      msm_buckets<F>(ctx, g.sort, g.bk, d_bases, d_res, 0, st, n ? e0 : nullptr, n ? e1 : nullptr,
+                     tab != nullptr ? tab->fmt() : 0);
       // the one inversion of the normalisation runs in the library's host-compiled field code (tens of microseconds);
       // a single device lane took ~1 ms for it, a third of a stand-alone 2^16-term MSM
       XYZZ<F> h_res;
@@ -232,10 +226,11 @@ struct Api {
       if (n) ARK_CHECK_HIP(hipMemcpy(stage.p, bases, n * psz, hipMemcpyHostToDevice));
       const TableNeed need{n, 0, group == 2};
       std::string why;
-      const uint32_t ws = table_stride_plan<Fq, Fq2, Fr>(pol, &need, 1, table_budget_bytes(pol, (size_t)2 * 16 * 17 * n, true), &why);
+      bool packed = false;
+      const uint32_t ws = table_stride_plan<Fq, Fq2, Fr>(pol, &need, 1, table_budget_bytes(pol, (size_t)2 * 16 * 17 * n, true), &why, &packed);
       if (ws == 0) throw HipError{ARK355_ENOMEM, "base set: " + why};
-      if (group == 1) precomp_build<Fq, Fr>(pol, b->tab, stage.p, n, st, 0, ws);
-      else precomp_build<Fq2, Fr>(pol, b->tab, stage.p, n, st, 0, ws);
+      if (group == 1) precomp_build<Fq, Fr>(pol, b->tab, stage.p, n, st, 0, ws, 0, packed ? 1 : 0);
+      else precomp_build<Fq2, Fr>(pol, b->tab, stage.p, n, st, 0, ws, 0, packed ? 1 : 0);
     } catch (...) {
       delete b;
       throw;

@@ -8,6 +8,7 @@
 #include <initializer_list>
 #include <map>
 #include <memory>
+#include <atomic>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -110,7 +111,7 @@ struct ark355_ctx {
   float acc_ms = 0.f;           // bucket-accumulation kernel time of the last MSM/prove
   uint64_t acc_launches = 0;
   uint64_t acc_points = 0;
-  int last_sched = -1;          // schedule the last prove on this context ran as (ark355::Sched)
+  std::atomic<int> last_sched{-1};   // schedule the last prove on this context ran as (ark355::Sched); read without the lock by ark355_sched_info
   // NTT twiddle tables keyed by (curve << 8 | log_n)
   std::map<uint32_t, std::shared_ptr<ark355::NttTables>> ntt_tables;   // shared with the other contexts of the device
   // grow-only scratch buffers reused across calls (sized for 288 GB HBM: never shrunk)

@@ -128,7 +128,6 @@ struct ProverScratch {
   // a proof are in flight together on separate streams (sized for 288 GB of HBM, not for reuse)
   MsmSort sortZ, sortH;
   MsmBuckets bkA, bkB1, bkB2, bkL, bkH;
-  BaScratch baA, baB1, baB2, baL, baH;      // batch-affine tree levels (msm_ba_impl.cuh), used when a table asks for them
   // feeder streams of the five-stream pipeline (witness map, sorts, reductions); the accumulations run on the
   // context's own stream.  Created in ONE block under a process-wide lock (ensure_streams): the runtime hands out its
   // few hardware queues per priority class round-robin in creation order, so three streams created back to back land
@@ -386,6 +385,7 @@ static PkDev* pk_upload(const TunePolicy& pol, const ark355_pk_desc* d, hipStrea
     // every shard of a key uses the window size of the largest shard (see precomp_build)
     const uint64_t z_plan = shard_count > 1 ? (m + 4 + shard_count - 1) / shard_count : 0;
     const uint64_t h_plan = shard_count > 1 ? (pk->h_dist ? pk->h_cnt : (hn + shard_count - 1) / shard_count) : 0;
+    bool packed_rows = false;
     {
       // Window stride of the five tables: 1 (a table per window) whenever that fits next to the scratch of the proving
       // contexts that will work on this key (four of them: two sort areas of 16 B per (term, window), nine N-element NTT
@@ -398,16 +398,17 @@ static PkDev* pk_upload(const TunePolicy& pol, const ark355_pk_desc* d, hipStrea
                                  {hn_, h_plan, false, pol.msm_c_h}, {zn, z_plan, false}};
       const size_t scratch = 4 * ((size_t)16 * 17 * (zn + hn_) + (size_t)9 * 32 * pk->N);
       std::string why;
-      pk->wstride = table_stride_plan<Fq, Fq2, Fr>(pol, need, 5, table_budget_bytes(pol, scratch, shard_count == 1), &why);
+      pk->wstride = table_stride_plan<Fq, Fq2, Fr>(pol, need, 5, table_budget_bytes(pol, scratch, shard_count == 1), &why, &packed_rows);
       if (pk->wstride == 0) throw HipError{ARK355_ENOMEM, "proving key: " + why};
     }
     const uint32_t ws = pk->wstride;
+    const int pkd = packed_rows ? 1 : 0;           // one row format for the five tables of a key (table_pack_default)
     ext(d->a_query, G1, d->alpha_g1, d->delta_g1, nullptr);
-    precomp_build<Fq, Fr>(pol, pk->a_ext, (uint8_t*)stage.p + pk->z_lo * G1, pk->z_cnt, stream, z_plan, ws);
+    precomp_build<Fq, Fr>(pol, pk->a_ext, (uint8_t*)stage.p + pk->z_lo * G1, pk->z_cnt, stream, z_plan, ws, 0, pkd);
     ext(d->b_g1_query, G1, d->beta_g1, nullptr, d->delta_g1);
-    precomp_build<Fq, Fr>(pol, pk->b1_ext, (uint8_t*)stage.p + pk->z_lo * G1, pk->z_cnt, stream, z_plan, ws);
+    precomp_build<Fq, Fr>(pol, pk->b1_ext, (uint8_t*)stage.p + pk->z_lo * G1, pk->z_cnt, stream, z_plan, ws, 0, pkd);
     ext(d->b_g2_query, G2, d->beta_g2, nullptr, d->delta_g2);
-    precomp_build<Fq2, Fr>(pol, pk->b2_ext, (uint8_t*)stage.p + pk->z_lo * G2, pk->z_cnt, stream, z_plan, ws);
+    precomp_build<Fq2, Fr>(pol, pk->b2_ext, (uint8_t*)stage.p + pk->z_lo * G2, pk->z_cnt, stream, z_plan, ws, 0, pkd);
     stage.ensure((pk->h_cnt ? pk->h_cnt : 1) * G1);
     if (pk->h_dist) {
       const uint64_t M = pk->h_cnt, mc = M / shard_count;
@@ -421,14 +422,14 @@ static PkDev* pk_upload(const TunePolicy& pol, const ark355_pk_desc* d, hipStrea
     } else if (pk->h_cnt) {
       ARK_CHECK_HIP(hipMemcpy(stage.p, d->h_query + pk->h_lo * G1, pk->h_cnt * G1, hipMemcpyDefault));
     }
-    precomp_build<Fq, Fr>(pol, pk->h_query, stage.p, pk->h_cnt, stream, h_plan, ws, pol.msm_c_h);
+    precomp_build<Fq, Fr>(pol, pk->h_query, stage.p, pk->h_cnt, stream, h_plan, ws, pol.msm_c_h, pkd);
     // l_ext aligned with zx: ell leading infinities (instance variables carry no l term), l_query, delta_1 at
     // the -rs slot, three trailing infinities
     stage.ensure((m + 4) * G1);
     ARK_CHECK_HIP(hipMemset(stage.p, 0, (m + 4) * G1));
     if (pk->w) ARK_CHECK_HIP(hipMemcpy((uint8_t*)stage.p + pk->ell * G1, d->l_query, pk->w * G1, hipMemcpyDefault));
     ARK_CHECK_HIP(hipMemcpy((uint8_t*)stage.p + m * G1, d->delta_g1, G1, hipMemcpyHostToDevice));
-    precomp_build<Fq, Fr>(pol, pk->l_ext, (uint8_t*)stage.p + pk->z_lo * G1, pk->z_cnt, stream, z_plan, ws);
+    precomp_build<Fq, Fr>(pol, pk->l_ext, (uint8_t*)stage.p + pk->z_lo * G1, pk->z_cnt, stream, z_plan, ws, 0, pkd);
     stage.release();
   } catch (...) {
     delete pk;
@@ -506,6 +507,16 @@ static void prove_run(ark355_ctx* ctx, ProverScratch& sc, const PkDev& pk, const
   }
   sc.warm_shape = shape;
   ctx->last_sched = sched;
+  // an exploring proof that leaves by exception must hand its sample slot back, or the class never latches
+  struct ExploreGuard {
+    int device;
+    uint64_t key;
+    int sched;
+    bool armed;
+    ~ExploreGuard() {
+      if (armed) SchedTuner::of(device).unstart(key, sched);
+    }
+  } explore_guard{ctx->device, tune_key, sched, exploring};
   const bool one_stream = sched == SCHED_ONE_STREAM || sched == SCHED_ONE_STREAM_SPIN;
   const bool spin = pol.wait_spin != 0 || sched == SCHED_ONE_STREAM_SPIN;
   // The short kernels that feed the accumulations (witness map, sorts) and the latency-bound reductions outrank the
@@ -639,13 +650,12 @@ static void prove_run(ark355_ctx* ctx, ProverScratch& sc, const PkDev& pk, const
       FillBatch fb(sS);
       msm_sort_plan<Fr>(ctx, sc.sortZ, pk.z_cnt, sS, &pk.a_ext, &fb);
       // bucket sets are sized and cleared here as well (msm_prepare_phase)
-      // (a batch-affine MSM sizes its bucket set later, for the nodes its tree levels leave over)
-      if (!pk.b2_ext.batch_affine) msm_prepare_phase<Fq2>(pol, sc.sortZ, sc.bkB2, sS, pk.b2_ext.limb28, &fb);
-      if (!pk.a_ext.batch_affine) msm_prepare_phase<Fq>(pol, sc.sortZ, sc.bkA, sS, pk.a_ext.limb28, &fb);
-      if (!pk.b1_ext.batch_affine) msm_prepare_phase<Fq>(pol, sc.sortZ, sc.bkB1, sS, pk.b1_ext.limb28, &fb);
-      if (!pk.l_ext.batch_affine) msm_prepare_phase<Fq>(pol, sc.sortZ, sc.bkL, sS, pk.l_ext.limb28, &fb);
+      msm_prepare_phase<Fq2>(pol, sc.sortZ, sc.bkB2, sS, pk.b2_ext.fmt(), &fb);
+      msm_prepare_phase<Fq>(pol, sc.sortZ, sc.bkA, sS, pk.a_ext.fmt(), &fb);
+      msm_prepare_phase<Fq>(pol, sc.sortZ, sc.bkB1, sS, pk.b1_ext.fmt(), &fb);
+      msm_prepare_phase<Fq>(pol, sc.sortZ, sc.bkL, sS, pk.l_ext.fmt(), &fb);
       msm_sort_plan<Fr>(ctx, sc.sortH, pk.h_cnt, sS, &pk.h_query, &fb);
-      if (!pk.h_query.batch_affine) msm_prepare_phase<Fq>(pol, sc.sortH, sc.bkH, sS, pk.h_query.limb28, &fb);
+      msm_prepare_phase<Fq>(pol, sc.sortH, sc.bkH, sS, pk.h_query.fmt(), &fb);
       fb.flush();
     }
     ARK_CHECK_HIP(hipStreamWaitEvent(sS, ev[E_ZS], 0));
@@ -664,39 +674,30 @@ static void prove_run(ark355_ctx* ctx, ProverScratch& sc, const PkDev& pk, const
       bool g2;
       const PrecompTable* tab;
       int res;
-      BaScratch* ba;
     } jobs[5] = {
         // G2 first: its bucket reduction is the longest latency-bound tail (~4-6 ms on a few workgroups) and
         // hides under the four G1 accumulations that follow
-        {E_SORT0, &sc.sortZ, &sc.bkB2, true, &pk.b2_ext, 0, &sc.baB2},
-        {E_SORT0, &sc.sortZ, &sc.bkA, false, &pk.a_ext, 0, &sc.baA},
-        {E_SORT0, &sc.sortZ, &sc.bkB1, false, &pk.b1_ext, 1, &sc.baB1},
-        {E_SORT0, &sc.sortZ, &sc.bkL, false, &pk.l_ext, 2, &sc.baL},
-        {E_SORT2, &sc.sortH, &sc.bkH, false, &pk.h_query, 3, &sc.baH},
+        {E_SORT0, &sc.sortZ, &sc.bkB2, true, &pk.b2_ext, 0},
+        {E_SORT0, &sc.sortZ, &sc.bkA, false, &pk.a_ext, 0},
+        {E_SORT0, &sc.sortZ, &sc.bkB1, false, &pk.b1_ext, 1},
+        {E_SORT0, &sc.sortZ, &sc.bkL, false, &pk.l_ext, 2},
+        {E_SORT2, &sc.sortH, &sc.bkH, false, &pk.h_query, 3},
     };
     uint64_t pts = 0;
     // One-stream proofs: the five accumulations first, then the G2 tails and the tails of the four G1 MSMs as ONE launch
     // per step (msm_reduce_phase_batch) -- 8 tail dispatches instead of 20, and the four latency-bound G1 chains side by
     // side instead of one after the other.  (The pipeline hides each MSM's tails under the next accumulation instead.)
-    const bool batch_tails = one_stream && !cm && pol.batch_tails != 0 && !pk.a_ext.batch_affine && !pk.b1_ext.batch_affine &&
-                             !pk.b2_ext.batch_affine && !pk.l_ext.batch_affine && !pk.h_query.batch_affine;
+    const bool batch_tails = one_stream && !cm && pol.batch_tails != 0;
     for (int j = 0; j < 5; j++) {
       const Job& jb = jobs[j];
       ARK_CHECK_HIP(hipStreamWaitEvent(sA, ev[jb.sort_ev], 0));
       const MsmSort* red_sort = jb.sort;          // what the reduction reads offsets / counts from
-      if (jb.tab->batch_affine) {
-        if (jb.g2)
-          red_sort = &msm_ba_accumulate_phase<Fq2>(ctx, *jb.sort, *jb.bk, *jb.ba, jb.tab->table.template as<Affine<Fq2>>(), sA,
-                                                   acc0[j], acc1[j]);
-        else
-          red_sort = &msm_ba_accumulate_phase<Fq>(ctx, *jb.sort, *jb.bk, *jb.ba, jb.tab->table.template as<Affine<Fq>>(), sA,
-                                                  acc0[j], acc1[j]);
-      } else if (jb.g2) {
+      if (jb.g2) {
         msm_accumulate_phase<Fq2>(ctx, *jb.sort, *jb.bk, jb.tab->table.template as<Affine<Fq2>>(), sA, acc0[j], acc1[j],
-                                  jb.tab->limb28);
+                                  jb.tab->fmt());
       } else {
         msm_accumulate_phase<Fq>(ctx, *jb.sort, *jb.bk, jb.tab->table.template as<Affine<Fq>>(), sA, acc0[j], acc1[j],
-                                 jb.tab->limb28);
+                                 jb.tab->fmt());
       }
       ARK_CHECK_HIP(hipEventRecord(ev[E_ACC_DONE0 + j], sA));
       pts += (uint64_t)jb.sort->plan.windows * jb.sort->plan.n;
@@ -812,6 +813,7 @@ static void prove_run(ark355_ctx* ctx, ProverScratch& sc, const PkDev& pk, const
       }
     }
     if (exploring) {
+      explore_guard.armed = false;
       const int now_in_flight = inflight.c.load();
       if (!concurrent && now_in_flight > 1) {
         SchedTuner::of(ctx->device).unstart(tune_key, sched);

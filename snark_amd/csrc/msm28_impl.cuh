@@ -12,8 +12,8 @@ namespace ark355 {
 
 // One table row: x, y in the canonical 28-bit Montgomery form (value < p, radix R' = 2^(28 N)), BIT-PACKED: each
 // coordinate is the plain little-endian binary image of its value in NB 32-bit words (48 B for BLS12-381, 32 B for
-// BN254), so a row is 96 B / 64 B instead of the 128 B / 80 B of one word per limb (round 5: -25 % / -20 % table
-// bytes; a BN254 row is exactly one 64-byte sector).  The accumulation kernels cut the words into 28-bit limbs in
+// BN254), so a G1 row is 96 B / 64 B instead of the 128 B / 80 B of one word per limb (round 5: -25 % / -20 % of the
+// G1 table bytes; a BN254 row is exactly one 64-byte sector).  The accumulation kernels cut the words into 28-bit limbs in
 // registers (one v_alignbit_b32 + one v_and_b32 per limb: ~50 of ~4 500 instructions per addition).  Infinity is the
 // all-zero row.
 template <class P>
@@ -52,6 +52,21 @@ struct alignas(16) Affine28 {
   }
 };
 
+// The UNPACKED row of rounds 2-4: one word per limb, padded to a multiple of 16 B (128 B for BLS12-381, 80 B for BN254).
+// Which of the two a table uses is decided per key (PrecompTable::packed, msm_impl.cuh): packed rows when they are whole
+// 64-byte sectors (BN254: faster AND smaller) or when the key would not fit HBM otherwise; unpacked rows else -- a 96-byte
+// row straddles 128-byte lines, which costs BLS12-381 proofs 1.5 % of throughput with other proofs in flight (runs B, F)
+// and the lane-pair kernel its spill-free hot loop.
+template <class P>
+struct alignas(16) Affine28U {
+  using F = Fp28<P>;
+  static constexpr int USED = 2 * F::N;
+  static constexpr int WORDS = (USED * 4 > 96) ? 32 : ((USED + 3) / 4) * 4;
+  static constexpr int Q = USED / 4;                 // 16-byte loads that carry data
+  static_assert(USED % 4 == 0, "limb count must be even");
+  uint32_t w[WORDS];
+};
+
 template <class P>
 struct Acc28 {
   Fp28<P> x, y, zz, zzz;
@@ -63,19 +78,32 @@ struct Acc28 {
 template <class P, int COORDS>
 using Msm28Slot = typename std::conditional<COORDS == 4, XYZZ<Fp<P>>, XYZZ<Fp2<P>>>::type;
 
-template <class P>
+template <class P, bool PACKED>
+using Row28 = typename std::conditional<PACKED, Affine28<P>, Affine28U<P>>::type;
+
+template <class P, bool PACKED>
 __global__ void __launch_bounds__(256)
-table_to28_kernel(const Affine<Fp<P>>* __restrict__ src, Affine28<P>* __restrict__ dst, uint64_t rows) {
+table_to28_kernel(const Affine<Fp<P>>* __restrict__ src, Row28<P, PACKED>* __restrict__ dst, uint64_t rows) {
   using F = Fp28<P>;
+  using Row = Row28<P, PACKED>;
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= rows) return;
   const Affine<Fp<P>> a = src[i];
-  Affine28<P> o;
+  Row o;
 #pragma unroll
-  for (int k = 0; k < Affine28<P>::WORDS; k++) o.w[k] = 0;
+  for (int k = 0; k < Row::WORDS; k++) o.w[k] = 0;
   if (!a.is_inf()) {
-    Affine28<P>::pack(F::from_fp(a.x), o.w);
-    Affine28<P>::pack(F::from_fp(a.y), o.w + Affine28<P>::NB);
+    const F x = F::from_fp(a.x), y = F::from_fp(a.y);
+    if constexpr (PACKED) {
+      Affine28<P>::pack(x, o.w);
+      Affine28<P>::pack(y, o.w + Affine28<P>::NB);
+    } else {
+#pragma unroll
+      for (int k = 0; k < F::N; k++) {
+        o.w[k] = x.l[k];
+        o.w[F::N + k] = y.l[k];
+      }
+    }
   }
   dst[i] = o;
 }
@@ -162,14 +190,111 @@ ARK_D void madd28(Acc28<P>& acc, bool& empty, const Fp28<P>& px, const Fp28<P>& 
   acc.x = X3;
 }
 
-// ---- the segment walk shared by the G1 and the lane-pair G2 kernel -----------------------------------------------------
+// Same contract as msm_accumulate_kernel<Fp<P>, false>; `bases` holds UNPACKED rows (Affine28U): the plain segment walk of
+// rounds 2-4 -- the row of the next entry prefetched into registers, a finished run flushed where it ends.
+//
+// What bounds this kernel (round 5; tools/ubench5, tools/acc_trace.py on a tracing build, rocprofv3 --pmc; DESIGN.md
+// section 11): VALU issue.  A lane executes ~4 560 VALU instructions per addition (3 155 multiply-adds); the SIMD
+// arbitrates its two waves oldest-first, the older one runs at the pace of a wave alone (one instruction per ~5.3 cycles:
+// 10.9 us per addition), the younger one advances ~20 % as fast in the slots the older leaves, and takes over when the
+// older one retires -- a launch is a relay of waves, 1.2 additions per 24 k cycles and SIMD against the 17.6 k cycles of
+// VALU time they need.  The instruction cache holds the 36 KB loop (2 725 misses in 281 M fetches), waits for memory are
+// 8 % of a wave's cycles, and neither the bucket flushes (run C: -2 % without any), nor bucket boundaries (-4 %), nor the
+// table gathers (-3 % with every row in cache) explain the rest: what moves the kernel is the instruction count.
+template <class P>
+__global__ void __launch_bounds__(MSM_THREADS)
+msm_accumulate28_kernel(const Affine28U<P>* __restrict__ bases, const uint32_t* __restrict__ sorted_keys,
+                        const uint32_t* __restrict__ sorted_vals, const uint32_t* __restrict__ total_ptr,
+                        const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ counts,
+                        Msm28Slot<P, 4>* __restrict__ buckets, Msm28Slot<P, 4>* __restrict__ head,
+                        uint32_t* __restrict__ head_key, Msm28Slot<P, 4>* __restrict__ tail,
+                        uint32_t* __restrict__ tail_key, uint32_t seg_len) {
+  using F = Fp28<P>;
+  using Fq = Fp<P>;
+  using Row = Affine28U<P>;
+  constexpr int Q = Row::Q;
+  const uint32_t seg = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t total = *total_ptr;
+  const uint64_t start64 = (uint64_t)seg * seg_len;
+  if (start64 >= total) return;
+  const uint32_t start = (uint32_t)start64;
+  const uint32_t end = (start + seg_len < total) ? start + seg_len : total;
+  uint32_t cur_key = sorted_keys[start];
+  uint32_t run_start = start;
+  bool first_run = true;
+  bool empty = true;
+  Acc28<P> acc;
+  acc.x = F::zero();
+  acc.y = F::zero();
+  acc.zz = F::zero();
+  acc.zzz = F::zero();
+  // always_inline: a closure that is inlined late keeps every captured variable (the accumulator!) in scratch memory
+  auto flush = [&](uint32_t key, uint32_t run_end) __attribute__((always_inline)) {
+    XYZZ<Fq> out = XYZZ<Fq>::inf();
+    if (!empty) {
+      out.x = F::to_fp_lt8(acc.x);
+      out.y = F::to_fp_lt8(acc.y);
+      out.zz = F::to_fp_lt8(acc.zz);
+      out.zzz = F::to_fp_lt8(acc.zzz);
+    }
+    msm_flush_run<Fq>(key, out, first_run, run_start, run_end, seg, offsets, counts, buckets, head, head_key, tail,
+                      tail_key);
+  };
+  // software prefetch of the next row into explicit 16-byte registers (see msm_accumulate_kernel)
+  uint4 nx[Q];
+  uint32_t v_next = sorted_vals[start];
+  {
+    const uint4* src = reinterpret_cast<const uint4*>(bases + (v_next & ARK_TBL_MASK));
+#pragma unroll
+    for (int k = 0; k < Q; k++) nx[k] = src[k];
+  }
+  for (uint32_t e = start; e < end; e++) {
+    const uint32_t key = sorted_keys[e];
+    const uint32_t v = v_next;
+    uint32_t d[4 * Q];
+#pragma unroll
+    for (int k = 0; k < Q; k++) {
+      d[4 * k + 0] = nx[k].x;
+      d[4 * k + 1] = nx[k].y;
+      d[4 * k + 2] = nx[k].z;
+      d[4 * k + 3] = nx[k].w;
+    }
+    const uint32_t en = (e + 1 < end) ? e + 1 : e;       // clamp: the last iteration re-reads its own entry
+    v_next = sorted_vals[en];
+    {
+      const uint4* src = reinterpret_cast<const uint4*>(bases + (v_next & ARK_TBL_MASK));
+#pragma unroll
+      for (int k = 0; k < Q; k++) nx[k] = src[k];
+    }
+    if (key != cur_key) {
+      flush(cur_key, e);
+      cur_key = key;
+      run_start = e;
+      first_run = false;
+      empty = true;
+    }
+    F px, py;
+#pragma unroll
+    for (int k = 0; k < F::N; k++) {
+      px.l[k] = d[k];
+      py.l[k] = d[F::N + k];
+    }
+    uint32_t any = 0;
+#pragma unroll
+    for (int k = 0; k < F::N; k++) any |= px.l[k] | py.l[k];
+    if (any == 0) continue;                              // base at infinity
+    madd28<P>(acc, empty, px, py, (v >> 31) != 0);
+  }
+  flush(cur_key, end);
+}
+
+
+// ---- the segment walk of the kernels over PACKED rows (msm_accumulate28p_kernel, msm_accumulate_g2l28p_kernel) ------------
 // Run / flush protocol as in msm_accumulate_kernel (msm_impl.cuh): a lane walks ONE segment of the sorted entry list; a
 // maximal stretch of equal keys is a run; a finished run goes to buckets[key] when it is the bucket's only run, to
 // head[seg] when it opened the segment, to tail[seg] otherwise.
 //
-// Round 5, two changes that keep the multiplier busy (tools/ubench5: the register-resident mixed addition runs at 96 % of
-// the chip's multiply-add rate because the two waves of a SIMD hide each other's other instructions -- the kernels of
-// rounds 2-4 reached 72 %, i.e. a quarter of the time at least one of the two waves was NOT issuing multiply-adds):
+// Two differences to the plain walk above, built in round 5 (runs B, E, F):
 //   * deferred flush.  Converting a finished run to the canonical form (4 x to_fp_lt8 + stores, ~2 000 instructions) used
 //     to happen where the run ended: in ~23 % of a wave's iterations SOME lane met a bucket boundary and all 64 waited
 //     for it.  The first run a lane finishes inside its segment is now PARKED in LDS (4 N words per lane, word-major:
@@ -220,10 +345,10 @@ struct Park28 {
   }
 };
 
-// Same contract as msm_accumulate_kernel<Fp<P>, false>; `bases` holds Affine28 rows.
+// Same contract as msm_accumulate28_kernel; `bases` holds PACKED rows (Affine28).
 template <class P>
 __global__ void __launch_bounds__(MSM_THREADS)
-msm_accumulate28_kernel(const Affine28<P>* __restrict__ bases, const uint32_t* __restrict__ sorted_keys,
+msm_accumulate28p_kernel(const Affine28<P>* __restrict__ bases, const uint32_t* __restrict__ sorted_keys,
                         const uint32_t* __restrict__ sorted_vals, const uint32_t* __restrict__ total_ptr,
                         const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ counts,
                         Msm28Slot<P, 4>* __restrict__ buckets, Msm28Slot<P, 4>* __restrict__ head,
@@ -334,39 +459,48 @@ msm_accumulate28_kernel(const Affine28<P>* __restrict__ bases, const uint32_t* _
 // kernel only tied: its flush picked the destination with a select among captured pointers, hipcc turned that into an
 // indexed load from the lambda's closure object, the closure could not be scalarised, and EVERY captured variable (the
 // accumulator included) stayed in scratch memory: 28 x 16-byte scratch accesses per mixed addition.
-template <class P>
+template <class P, bool PACKED>
 struct Affine28G2 {
-  Affine28<P> half[2];
+  Row28<P, PACKED> half[2];
 };
 
-template <class P>
+template <class P, bool PACKED>
 __global__ void __launch_bounds__(256)
-table_to28_g2_kernel(const Affine<Fp2<P>>* __restrict__ src, Affine28G2<P>* __restrict__ dst, uint64_t rows) {
+table_to28_g2_kernel(const Affine<Fp2<P>>* __restrict__ src, Affine28G2<P, PACKED>* __restrict__ dst, uint64_t rows) {
   using F = Fp28<P>;
+  using Row = Row28<P, PACKED>;
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= rows) return;
   const Affine<Fp2<P>> a = src[i];
-  Affine28G2<P> o;
+  Affine28G2<P, PACKED> o;
 #pragma unroll
   for (int h = 0; h < 2; h++) {
 #pragma unroll
-    for (int k = 0; k < Affine28<P>::WORDS; k++) o.half[h].w[k] = 0;
+    for (int k = 0; k < Row::WORDS; k++) o.half[h].w[k] = 0;
   }
   if (!a.is_inf()) {
-    constexpr int NB = Affine28<P>::NB;
-    Affine28<P>::pack(F::from_fp(a.x.c0), o.half[0].w);
-    Affine28<P>::pack(F::from_fp(a.y.c0), o.half[0].w + NB);
-    Affine28<P>::pack(F::from_fp(a.x.c1), o.half[1].w);
-    Affine28<P>::pack(F::from_fp(a.y.c1), o.half[1].w + NB);
+    const F x0 = F::from_fp(a.x.c0), x1 = F::from_fp(a.x.c1), y0 = F::from_fp(a.y.c0), y1 = F::from_fp(a.y.c1);
+    if constexpr (PACKED) {
+      constexpr int NB = Affine28<P>::NB;
+      Affine28<P>::pack(x0, o.half[0].w);
+      Affine28<P>::pack(y0, o.half[0].w + NB);
+      Affine28<P>::pack(x1, o.half[1].w);
+      Affine28<P>::pack(y1, o.half[1].w + NB);
+    } else {
+#pragma unroll
+      for (int k = 0; k < F::N; k++) {
+        o.half[0].w[k] = x0.l[k];
+        o.half[0].w[F::N + k] = y0.l[k];
+        o.half[1].w[k] = x1.l[k];
+        o.half[1].w[F::N + k] = y1.l[k];
+      }
+    }
   }
   dst[i] = o;
 }
 
 // Fq2 arithmetic of a lane pair on Fp28 components.  KA / BETA describe the PARTNER component of the first
 // operand (value < (KA-1) p, limbs <= BETA (2^28 - 1)): it is negated lazily on the even lane.
-#ifndef ARK_PAIR_SEL_BFI
-#define ARK_PAIR_SEL_BFI 0
-#endif
 template <class P>
 struct Pair28 {
   using F = Fp28<P>;
@@ -385,43 +519,30 @@ struct Pair28 {
     for (int i = 0; i < N; i++) r.l[i] = c ? a.l[i] : b.l[i];
     return r;
   }
-  // odd lane ? a : b.  ARK_PAIR_SEL_BFI: as (m & a) | (~m & b) with the lane-parity mask m = 0 - (lane & 1) in a VGPR:
-  // one v_bfi_b32 per limb instead of one v_cndmask_b32_e64 on an SGPR pair (A/B switch; tools/ubench5 prices both).
-  ARK_D static F sel_odd(const F& a, const F& b) {
-#if ARK_PAIR_SEL_BFI
-    F r;
-    uint32_t m = 0u - (threadIdx.x & 1u);
-#if defined(__HIP_DEVICE_COMPILE__)
-    asm("" : "+v"(m));          // opaque: hipcc otherwise recognises the sign splat and folds the expression back into selects
-#endif
-#pragma unroll
-    for (int i = 0; i < N; i++) r.l[i] = (m & a.l[i]) | (~m & b.l[i]);
-    return r;
-#else
-    return sel(odd(), a, b);
-#endif
-  }
   //   even: a0 b0 + (-a1) b1          odd: a0 b1 + a1 b0
   template <uint32_t KA, uint32_t BETA>
   ARK_D static F mul(const F& a, const F& b) {
     const F pa = xchg(a), pb = xchg(b);
     const F npa = F::template neg<KA, BETA>(pa);
-    return F::mul2sum(sel_odd(pa, a), b, sel_odd(a, npa), pb);
+    const bool o = odd();
+    return F::mul2sum(sel(o, pa, a), b, sel(o, a, npa), pb);
   }
   //   even: (a0 + a1)(a0 - a1)        odd: (2 a0) a1            (a normalised, components < (KA-1) p)
   template <uint32_t KA>
   ARK_D static F sqr(const F& a) {
     const F pa = xchg(a);
-    const F u = F::add(pa, sel_odd(pa, a));
+    const bool o = odd();
+    const F u = F::add(pa, sel(o, pa, a));
     const F d = F::template sub<KA, 1>(a, pa);
-    return F::mul(u, sel_odd(a, d));
+    return F::mul(u, sel(o, a, d));
   }
   // a b + c d, four products and one reduction per lane
   template <uint32_t KA, uint32_t BA, uint32_t KC, uint32_t BC>
   ARK_D static F mul2(const F& a, const F& b, const F& c, const F& d) {
     const F pa = xchg(a), pb = xchg(b), pc = xchg(c), pd = xchg(d);
     const F npa = F::template neg<KA, BA>(pa), npc = F::template neg<KC, BC>(pc);
-    return F::mul4sum(sel_odd(pa, a), b, sel_odd(a, npa), pb, sel_odd(pc, c), d, sel_odd(c, npc), pd);
+    const bool o = odd();
+    return F::mul4sum(sel(o, pa, a), b, sel(o, a, npa), pb, sel(o, pc, c), d, sel(o, c, npc), pd);
   }
 };
 
@@ -520,9 +641,110 @@ ARK_D void madd28_g2(Acc28<P>& acc, bool& empty, const Fp28<P>& px, const Fp28<P
                               // 10.5 vs 9.2 ms per 2^20-term MSM (round 2); 1 (512 registers): 23.2-23.5 vs 22.1-22.5 ms per
                               // proof (round 5, profiles/r05_runA_karatsuba_ab.txt) -- the hot loop has no scratch access at 2
 #endif
+// Key, row index and this lane's half row are loaded at the top of every iteration: held in registers across the lane-pair
+// addition the half row (28 VGPRs) pushes the hot loop into scratch memory, and loading ahead was measured neutral in
+// round 2 (an addition is 2.2x as long as in G1; waits for memory are a few percent of a wave's cycles).
 template <class P>
 __global__ void __launch_bounds__(MSM_THREADS, ARK_G2L28_WAVES)
-msm_accumulate_g2l28_kernel(const Affine28G2<P>* __restrict__ bases, const uint32_t* __restrict__ sorted_keys,
+msm_accumulate_g2l28_kernel(const Affine28G2<P, false>* __restrict__ bases, const uint32_t* __restrict__ sorted_keys,
+                            const uint32_t* __restrict__ sorted_vals, const uint32_t* __restrict__ total_ptr,
+                            const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ counts,
+                            Msm28Slot<P, 8>* __restrict__ buckets, Msm28Slot<P, 8>* __restrict__ head,
+                            uint32_t* __restrict__ head_key, Msm28Slot<P, 8>* __restrict__ tail,
+                            uint32_t* __restrict__ tail_key, uint32_t seg_len) {
+  using F = Fp28<P>;
+  using Fq = Fp<P>;
+  constexpr int Q = Affine28U<P>::Q;
+  const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t seg = gid >> 1, par = gid & 1u;       // blockDim is even: par == lane parity
+  const uint32_t total = *total_ptr;
+  const uint64_t start64 = (uint64_t)seg * seg_len;
+  if (start64 >= total) return;                        // both lanes of a pair leave together
+  const uint32_t start = (uint32_t)start64;
+  const uint32_t end = (start + seg_len < total) ? start + seg_len : total;
+  uint32_t cur_key = sorted_keys[start];
+  uint32_t run_start = start;
+  bool first_run = true;
+  bool empty = true;
+  Acc28<P> acc;
+  acc.x = F::zero();
+  acc.y = F::zero();
+  acc.zz = F::zero();
+  acc.zzz = F::zero();
+  // always_inline: a closure that is inlined late keeps every captured variable (the accumulator!) in scratch memory
+  auto flush = [&](uint32_t key, uint32_t run_end) __attribute__((always_inline)) {
+    // this lane's halves of the four Fq2 coordinates, canonical 32-bit form
+    XYZZ<Fq> mine = XYZZ<Fq>::inf();
+    if (!empty) {
+      mine.x = F::to_fp_lt8(acc.x);
+      mine.y = F::to_fp_lt8(acc.y);
+      mine.zz = F::to_fp_lt8(acc.zz);
+      mine.zzz = F::to_fp_lt8(acc.zzz);
+    }
+    const uint32_t o = offsets[key], cnt = counts[key];
+    const bool complete = (run_start == o) && (run_end == o + cnt);
+    // three explicit branches, NOT a select among the captured pointers: hipcc turns such a select into an indexed
+    // load from the closure object, which then cannot be scalarised -- and every captured variable, the accumulator
+    // included, lives in scratch memory for the whole loop (28 x 16-byte scratch accesses per mixed addition)
+    auto store = [&](XYZZ<Fp2<P>>* dst) __attribute__((always_inline)) {
+      Fq* d = reinterpret_cast<Fq*>(dst);
+      d[0 + par] = mine.x;
+      d[2 + par] = mine.y;
+      d[4 + par] = mine.zz;
+      d[6 + par] = mine.zzz;
+    };
+    if (complete) {
+      store(&buckets[key]);
+    } else if (first_run) {
+      store(&head[seg]);
+      if (par == 0) head_key[seg] = key;
+    } else {
+      store(&tail[seg]);
+      if (par == 0) tail_key[seg] = key;
+    }
+  };
+  for (uint32_t e = start; e < end; e++) {
+    const uint32_t key = sorted_keys[e];
+    const uint32_t v = sorted_vals[e];
+    F px, py;
+    {
+      const uint4* src = reinterpret_cast<const uint4*>(&bases[v & ARK_TBL_MASK].half[par]);
+      uint32_t d[4 * Q];
+#pragma unroll
+      for (int k = 0; k < Q; k++) {
+        const uint4 t = src[k];
+        d[4 * k + 0] = t.x;
+        d[4 * k + 1] = t.y;
+        d[4 * k + 2] = t.z;
+        d[4 * k + 3] = t.w;
+      }
+#pragma unroll
+      for (int k = 0; k < F::N; k++) {
+        px.l[k] = d[k];
+        py.l[k] = d[F::N + k];
+      }
+    }
+    if (key != cur_key) {
+      flush(cur_key, e);
+      cur_key = key;
+      run_start = e;
+      first_run = false;
+      empty = true;
+    }
+    uint32_t any = 0;
+#pragma unroll
+    for (int k = 0; k < F::N; k++) any |= px.l[k] | py.l[k];
+    if ((any | ark_pair_xchg(any)) == 0) continue;       // base at infinity (pair-wide)
+    madd28_g2<P>(acc, empty, px, py, (v >> 31) != 0);
+  }
+  flush(cur_key, end);
+}
+
+// The same over PACKED halves, with the parked flush of msm_accumulate28p_kernel (its hot loop spills one Fp28 value: 26 scratch
+// stores + 28 loads per addition in the listing; BN254, whose halves are whole sectors, still gains 5 % per launch).
+template <class P>
+__global__ void __launch_bounds__(MSM_THREADS, ARK_G2L28_WAVES)
+msm_accumulate_g2l28p_kernel(const Affine28G2<P, true>* __restrict__ bases, const uint32_t* __restrict__ sorted_keys,
                             const uint32_t* __restrict__ sorted_vals, const uint32_t* __restrict__ total_ptr,
                             const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ counts,
                             Msm28Slot<P, 8>* __restrict__ buckets, Msm28Slot<P, 8>* __restrict__ head,

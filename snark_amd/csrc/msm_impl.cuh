@@ -25,7 +25,6 @@
 //   The merge / reduce / combine tails are latency-bound (a few dozen dependent group operations on 32-128 workgroups).
 //   G1: the out-of-line group addition inlines its multiplications (curve.cuh); G2: the *_pair_kernel flavours give every
 //   bucket / chunk to a LANE PAIR (Fp2L: one component of each Fq2 coordinate per lane).
-//   msm_ba_impl.cuh (included at the end) holds the batch-affine alternative to K4, off by default.
 //
 // Algorithmic bytes per term: 32 B scalar + affine base (G1 96 B / G2 192 B BLS12-381).
 #pragma once
@@ -1376,16 +1375,12 @@ struct PrecompTable {
   DevBuf table;          // windows * n rows: Affine<F>, or Affine28 rows when limb28 is set
   uint64_t n = 0;
   bool limb28 = false;   // rows are stored in the radix-2^28 form of field28.cuh (msm28_impl.cuh)
-  bool batch_affine = false;   // canonical affine rows, accumulated by msm_ba_impl.cuh (ARK355_G1/G2_BATCH_AFFINE=1)
+  bool packed = false;   // ... bit-packed (Affine28: 96 / 64 B per G1 row) instead of one word per limb (Affine28U: 128 / 80 B)
+  int fmt() const { return limb28 ? (packed ? 2 : 1) : 0; }       // what msm_accumulate_phase is told
 };
 
 // policy LIMB28=0|1 / G2_LIMB28=0|1 (both default 1): window tables and bucket accumulation of G1 / G2 in the
 // radix-2^28 form (msm28_impl.cuh); 0 keeps the 32-bit kernels (A/B switches, exercised by the tests).
-// policy G2_BATCH_AFFINE=1 / G1_BATCH_AFFINE=1: the window table of that group stays in the canonical affine
-// form and its bucket accumulation runs as batch-affine tree levels (msm_ba_impl.cuh).  Read when a table is built.
-static inline bool msm_use_batch_affine(const TunePolicy& pol, bool g2) {
-  return (g2 ? pol.g2_batch_affine : pol.g1_batch_affine) != 0;
-}
 static inline bool msm_use_limb28(const TunePolicy& pol, bool g2) {       // read when a table is built
   return (g2 ? pol.g2_limb28 : pol.limb28) != 0;
 }
@@ -1396,10 +1391,24 @@ static inline bool msm_use_limb28(const TunePolicy& pol, bool g2) {       // rea
 // below pick the smallest window stride (MsmPlan::wstride) whose tables fit the budget, so that such a key still loads
 // -- with every second (third, ...) window's table and that many bucket sets -- instead of failing in hipMalloc.
 template <class F>
-static inline size_t table_row_bytes(bool limb28) {
+static inline size_t table_row_bytes(bool limb28, bool packed = false) {
   if (!limb28) return sizeof(Affine<F>);
-  if constexpr (is_fp2<F>::value) return sizeof(Affine28G2<typename F::Base::Params>);
-  else return sizeof(Affine28<typename F::Params>);
+  if constexpr (is_fp2<F>::value) {
+    using P = typename F::Base::Params;
+    return packed ? sizeof(Affine28G2<P, true>) : sizeof(Affine28G2<P, false>);
+  } else {
+    using P = typename F::Params;
+    return packed ? sizeof(Affine28<P>) : sizeof(Affine28U<P>);
+  }
+}
+// Row format of the 28-bit tables of one key (policy PACK_ROWS, read when a key / base set is loaded): 1 = packed, 0 = one word
+// per limb, -1 (default) = packed when a packed G1 row is a whole number of 64-byte sectors (BN254: 64 B -- faster and
+// smaller), else unpacked UNLESS the key's tables would not fit HBM at stride 1 that way (table_stride_plan packs them
+// before it gives up windows).  One decision per key: all five tables use the same format.
+template <class Fq>
+static inline bool table_pack_default(const TunePolicy& pol) {
+  if (pol.pack_rows >= 0) return pol.pack_rows != 0;
+  return sizeof(Affine28<typename Fq::Params>) % 64 == 0;
 }
 
 struct TableNeed {          // one base vector of a key
@@ -1430,20 +1439,28 @@ static inline size_t table_budget_bytes(const TunePolicy& pol, size_t scratch_by
 
 // smallest stride whose tables (all vectors resident + the two-window staging area of the one being built) fit `budget`;
 // 0 when not even the bare base vectors do
+// *packed (out): the row format of the key's 28-bit tables (table_pack_default, or packed when that is what makes stride 1 fit)
 template <class Fq, class Fq2, class Fr>
-static inline uint32_t table_stride_plan(const TunePolicy& pol, const TableNeed* need, int count, size_t budget, std::string* why) {
+static inline uint32_t table_stride_plan(const TunePolicy& pol, const TableNeed* need, int count, size_t budget, std::string* why,
+                                         bool* packed_out = nullptr) {
+  bool pk = table_pack_default<Fq>(pol);
+  if (packed_out) *packed_out = pk;
   if (pol.table_stride >= 1 && pol.table_stride <= 64) return (uint32_t)pol.table_stride;       // tests / A/B: force a stride
   uint32_t max_windows = 1;
   for (uint32_t s = 1;; s++) {
+    if (s == 2 && !pk && pol.pack_rows < 0) {       // stride 1 did not fit with unpacked rows: pack them and try again
+      pk = true;
+      if (packed_out) *packed_out = true;
+      s = 1;
+    }
     size_t resident = 0, stage = 0;
     for (int i = 0; i < count; i++) {
       const int pc = need[i].pref_c ? need[i].pref_c : pol.msm_c;
       const MsmPlan p = msm_plan(need[i].n, Fr::Params::BITS, true,
                                  need[i].plan_n ? (int)msm_plan(need[i].plan_n, Fr::Params::BITS, true, 0, 0, pc).c : 0, s, pc);
       if (p.windows > max_windows) max_windows = p.windows;
-      // (precomp_build drops batch-affine when the stride is > 1)
-      const bool l28 = msm_use_limb28(pol, need[i].g2) && !(msm_use_batch_affine(pol, need[i].g2) && s == 1);
-      const size_t row = need[i].g2 ? table_row_bytes<Fq2>(l28) : table_row_bytes<Fq>(l28);
+      const bool l28 = msm_use_limb28(pol, need[i].g2);
+      const size_t row = need[i].g2 ? table_row_bytes<Fq2>(l28, pk) : table_row_bytes<Fq>(l28, pk);
       const size_t aff = need[i].g2 ? sizeof(Affine<Fq2>) : sizeof(Affine<Fq>);
       const size_t xyzz = need[i].g2 ? sizeof(XYZZ<Fq2>) : sizeof(XYZZ<Fq>);
       resident += (size_t)p.table_windows * need[i].n * row;
@@ -1465,8 +1482,9 @@ static inline uint32_t table_stride_plan(const TunePolicy& pol, const TableNeed*
 // wstride: MsmPlan::wstride (from table_stride_plan).
 // pref_c: window size asked for this table alone (0: policy MSM_C).
 template <class F, class Fr>
+// packed: row format of a 28-bit table (-1: table_pack_default; a key passes what table_stride_plan decided for all its tables)
 static void precomp_build(const TunePolicy& pol, PrecompTable& t, const void* d_bases, uint64_t n, hipStream_t stream,
-                          uint64_t plan_n = 0, uint32_t wstride = 1, int pref_c = 0) {
+                          uint64_t plan_n = 0, uint32_t wstride = 1, int pref_c = 0, int packed = -1) {
   t.n = n;
   const int pc = pref_c ? pref_c : pol.msm_c;
   t.plan = msm_plan(n, Fr::Params::BITS, /*precomp=*/true,
@@ -1477,8 +1495,7 @@ static void precomp_build(const TunePolicy& pol, PrecompTable& t, const void* d_
   if (pol.trace_host)
     fprintf(stderr, "[ark355] window table: %llu bases, c = %u, %u windows (%u table blocks, %u bucket sets)%s\n",
             (unsigned long long)n, p.c, p.windows, TW, p.key_windows, p.negate_high ? ", scalars above (r - 1) / 2 negated" : "");
-  const bool ba = msm_use_batch_affine(pol, is_fp2<F>::value) && p.wstride == 1;
-  const bool l28 = !ba && msm_use_limb28(pol, is_fp2<F>::value);
+  const bool l28 = msm_use_limb28(pol, is_fp2<F>::value);
   const uint32_t grid = (uint32_t)((n + MSM_THREADS - 1) / MSM_THREADS);
   const uint32_t gridb = (uint32_t)(((n + PRE_K - 1) / PRE_K + MSM_THREADS - 1) / MSM_THREADS);
   const uint32_t shift = p.c * p.wstride;              // consecutive table blocks differ by 2^(c * wstride)
@@ -1498,16 +1515,19 @@ static void precomp_build(const TunePolicy& pol, PrecompTable& t, const void* d_
       ARK_CHECK_LAUNCH();
     }
     ARK_CHECK_HIP(hipStreamSynchronize(stream));     // tmp is freed on return
-    t.batch_affine = ba;
     return;
   }
   // radix-2^28 rows (msm28_impl.cuh): the canonical form of a block only lives in a two-block staging area while the
   // next block is derived from it; each finished block is re-encoded straight into the final table.  (The first version
   // built the whole canonical table first: 75 % more HBM at the peak than the key keeps -- what a 2^23-constraint key
   // cannot spare.)
-  const size_t row = table_row_bytes<F>(true);
+  bool pack;
+  if constexpr (is_fp2<F>::value) pack = packed >= 0 ? packed != 0 : table_pack_default<typename F::Base>(pol);
+  else pack = packed >= 0 ? packed != 0 : table_pack_default<F>(pol);
+  const size_t row = table_row_bytes<F>(true, pack);
   t.table.alloc((size_t)TW * (n ? n : 1) * row);
   t.limb28 = true;
+  t.packed = pack;
   if (n == 0) return;
   DevBuf stage[2] = {DevBuf(n * sizeof(Affine<F>)), DevBuf(n * sizeof(Affine<F>))};
   DevBuf tmp(n * sizeof(XYZZ<F>));
@@ -1516,12 +1536,20 @@ static void precomp_build(const TunePolicy& pol, PrecompTable& t, const void* d_
     uint8_t* dst = t.table.as<uint8_t>() + (size_t)w * n * row;
     if constexpr (is_fp2<F>::value) {
       using P = typename F::Base::Params;
-      ARK_LAUNCH((table_to28_g2_kernel<P>), grid28, dim3(256), 0, stream, (const Affine<F>*)src.as<Affine<F>>(),
-                 reinterpret_cast<Affine28G2<P>*>(dst), n);
+      if (pack)
+        ARK_LAUNCH((table_to28_g2_kernel<P, true>), grid28, dim3(256), 0, stream, (const Affine<F>*)src.as<Affine<F>>(),
+                   reinterpret_cast<Affine28G2<P, true>*>(dst), n);
+      else
+        ARK_LAUNCH((table_to28_g2_kernel<P, false>), grid28, dim3(256), 0, stream, (const Affine<F>*)src.as<Affine<F>>(),
+                   reinterpret_cast<Affine28G2<P, false>*>(dst), n);
     } else {
       using P = typename F::Params;
-      ARK_LAUNCH((table_to28_kernel<P>), grid28, dim3(256), 0, stream, (const Affine<F>*)src.as<Affine<F>>(),
-                 reinterpret_cast<Affine28<P>*>(dst), n);
+      if (pack)
+        ARK_LAUNCH((table_to28_kernel<P, true>), grid28, dim3(256), 0, stream, (const Affine<F>*)src.as<Affine<F>>(),
+                   reinterpret_cast<Affine28<P>*>(dst), n);
+      else
+        ARK_LAUNCH((table_to28_kernel<P, false>), grid28, dim3(256), 0, stream, (const Affine<F>*)src.as<Affine<F>>(),
+                   reinterpret_cast<Affine28U<P>*>(dst), n);
     }
     ARK_CHECK_LAUNCH();
   };
@@ -1656,10 +1684,8 @@ static void msm_sort_run(ark355_ctx* ctx, MsmSort& s, const void* d_scalars, uin
   const uint32_t stride = tab ? (uint32_t)tab->n : 0;
   const uint64_t entries = (uint64_t)p.windows * n;
   const uint32_t bins = (p.total_buckets + SORT_LO - 1) / SORT_LO;
-  // policy SORT_LEGACY=1 (env ARK355_SORT=legacy): the one-pass counting sort (A/B switch; also taken when level 1
-  // would not fit LDS)
-  const bool legacy = ctx->policy.sort_legacy != 0;
-  if (legacy || bins > SORT_MAX_BINS) {
+  // the one-pass counting sort of round 1 when level 1 would not fit LDS
+  if (bins > SORT_MAX_BINS) {
     const uint32_t grid_n = (uint32_t)((n + MSM_THREADS - 1) / MSM_THREADS);
     ARK_LAUNCH((msm_digits_kernel<Fr>), dim3(grid_n), dim3(MSM_THREADS), 0, stream, (const Fr*)d_scalars, (uint32_t)n,
                mont, p.c, p.windows, msm_digit_flags(p), stride, s.keys.as<uint32_t>(), s.vals.as<uint32_t>(),
@@ -1728,7 +1754,7 @@ struct MsmBuckets {
 // fill kernels in front of every accumulation launch sat behind the other proofs' workgroups and opened a gap between
 // consecutive accumulations (31 fills per proof, 2.5 ms of stream time with four proofs in flight).
 template <class F>
-static void msm_prepare_phase(const TunePolicy& pol, const MsmSort& s, MsmBuckets& b, hipStream_t stream, bool /*bases28*/ = false,
+static void msm_prepare_phase(const TunePolicy& pol, const MsmSort& s, MsmBuckets& b, hipStream_t stream, int /*fmt*/ = 0,
                               FillBatch* fb = nullptr) {
   const MsmPlan& p = s.plan;
   b.prepared = true;
@@ -1762,65 +1788,64 @@ static Msm28Slot<P, COORDS>* msm_slots28(MsmBuckets& b, uint32_t total_buckets, 
 template <class F>
 static void msm_accumulate_phase(ark355_ctx* ctx, const MsmSort& s, MsmBuckets& b, const Affine<F>* d_bases,
                                  hipStream_t stream, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr,
-                                 bool bases28 = false) {
+                                 int fmt = 0) {
+  // fmt: PrecompTable::fmt() of the table d_bases points to -- 0 canonical Affine<F> rows, 1 unpacked, 2 packed 28-bit rows
   const MsmPlan& p = s.plan;
-  if (!b.prepared) msm_prepare_phase<F>(ctx->policy, s, b, stream, bases28);      // stand-alone MSMs: same stream
+  if (!b.prepared) msm_prepare_phase<F>(ctx->policy, s, b, stream, fmt);      // stand-alone MSMs: same stream
   b.prepared = false;
   if (p.n == 0) return;
   const uint32_t segs = b.segs;
   const uint32_t grid_s = (segs + MSM_THREADS - 1) / MSM_THREADS;
   if (ev0) ARK_CHECK_HIP(hipEventRecord(ev0, stream));
-  // G2 (Fq2): inlining 30 Fq multiplications costs registers (256 VGPR + 256 AGPR, 1 wave/SIMD), the
-  // out-of-line flavour keeps acc in scratch across calls; measured on MI355X with the asm multiplier the
-  // inlined one wins (1.04 vs 0.85 Gadd/s).  Policy G2_INLINE=0|1 overrides.  G1 always inlines.
-  const int g2_inline = ctx->policy.g2_inline;
-  auto launch = [&](auto ni_tag) {
-    constexpr bool NI = decltype(ni_tag)::value;
-    ARK_LAUNCH((msm_accumulate_kernel<F, NI>), dim3(grid_s), dim3(MSM_THREADS), 0, stream, d_bases,
-               s.sorted_keys.as<uint32_t>(), s.sorted_vals.as<uint32_t>(), s.total.as<uint32_t>(),
-               s.offsets.as<uint32_t>(), s.counts.as<uint32_t>(), b.buckets.as<XYZZ<F>>(), b.head.as<XYZZ<F>>(),
-               b.head_key.as<uint32_t>(), b.tail.as<XYZZ<F>>(), b.tail_key.as<uint32_t>(), b.seg_len);
-  };
   if constexpr (is_fp2<F>::value) {
-    // G2: lane-split kernel (two lanes per segment).  Policy G2_WHOLE=1 selects the whole-element kernel
-    // (inlined or, with G2_INLINE=0, out-of-line) for A/B comparison.
-    const int g2_whole = ctx->policy.g2_whole;
-    if (bases28) {
-      using P = typename F::Base::Params;
-      const uint32_t grid_l = (2 * segs + MSM_THREADS - 1) / MSM_THREADS;
-      ARK_LAUNCH((msm_accumulate_g2l28_kernel<P>), dim3(grid_l), dim3(MSM_THREADS), 0, stream,
-                 reinterpret_cast<const Affine28G2<P>*>(d_bases), s.sorted_keys.as<uint32_t>(),
+    // G2: lane-split kernels (two lanes per segment; the whole-element kernels of round 1 lost to them by 2x and are gone)
+    using P = typename F::Base::Params;
+    const uint32_t grid_l = (2 * segs + MSM_THREADS - 1) / MSM_THREADS;
+    if (fmt == 2) {
+      ARK_LAUNCH((msm_accumulate_g2l28p_kernel<P>), dim3(grid_l), dim3(MSM_THREADS), 0, stream,
+                 reinterpret_cast<const Affine28G2<P, true>*>(d_bases), s.sorted_keys.as<uint32_t>(),
                  s.sorted_vals.as<uint32_t>(), s.total.as<uint32_t>(), s.offsets.as<uint32_t>(),
                  s.counts.as<uint32_t>(), msm_slots28<P, 8>(b, p.total_buckets, 0), msm_slots28<P, 8>(b, p.total_buckets, 1),
                  b.head_key.as<uint32_t>(), msm_slots28<P, 8>(b, p.total_buckets, 2), b.tail_key.as<uint32_t>(), b.seg_len);
-    } else if (!g2_whole) {
-      using P = typename F::Base::Params;
-      const uint32_t grid_l = (2 * segs + MSM_THREADS - 1) / MSM_THREADS;
+    } else if (fmt == 1) {
+      ARK_LAUNCH((msm_accumulate_g2l28_kernel<P>), dim3(grid_l), dim3(MSM_THREADS), 0, stream,
+                 reinterpret_cast<const Affine28G2<P, false>*>(d_bases), s.sorted_keys.as<uint32_t>(),
+                 s.sorted_vals.as<uint32_t>(), s.total.as<uint32_t>(), s.offsets.as<uint32_t>(),
+                 s.counts.as<uint32_t>(), msm_slots28<P, 8>(b, p.total_buckets, 0), msm_slots28<P, 8>(b, p.total_buckets, 1),
+                 b.head_key.as<uint32_t>(), msm_slots28<P, 8>(b, p.total_buckets, 2), b.tail_key.as<uint32_t>(), b.seg_len);
+    } else {
       ARK_LAUNCH((msm_accumulate_g2l_kernel<P>), dim3(grid_l), dim3(MSM_THREADS), 0, stream, d_bases,
                  s.sorted_keys.as<uint32_t>(), s.sorted_vals.as<uint32_t>(), s.total.as<uint32_t>(),
                  s.offsets.as<uint32_t>(), s.counts.as<uint32_t>(), b.buckets.as<XYZZ<F>>(), b.head.as<XYZZ<F>>(),
                  b.head_key.as<uint32_t>(), b.tail.as<XYZZ<F>>(), b.tail_key.as<uint32_t>(), b.seg_len);
-    } else if (g2_inline) {
-      launch(std::false_type{});
-    } else {
-      launch(std::true_type{});
     }
-  } else if (bases28) {
+  } else if (fmt == 2) {
     using P = typename F::Params;
-    ARK_LAUNCH((msm_accumulate28_kernel<P>), dim3(grid_s), dim3(MSM_THREADS), 0, stream,
+    ARK_LAUNCH((msm_accumulate28p_kernel<P>), dim3(grid_s), dim3(MSM_THREADS), 0, stream,
                reinterpret_cast<const Affine28<P>*>(d_bases), s.sorted_keys.as<uint32_t>(),
                s.sorted_vals.as<uint32_t>(), s.total.as<uint32_t>(), s.offsets.as<uint32_t>(),
                s.counts.as<uint32_t>(), msm_slots28<P, 4>(b, p.total_buckets, 0), msm_slots28<P, 4>(b, p.total_buckets, 1),
                b.head_key.as<uint32_t>(), msm_slots28<P, 4>(b, p.total_buckets, 2), b.tail_key.as<uint32_t>(), b.seg_len);
+  } else if (fmt == 1) {
+    using P = typename F::Params;
+    ARK_LAUNCH((msm_accumulate28_kernel<P>), dim3(grid_s), dim3(MSM_THREADS), 0, stream,
+               reinterpret_cast<const Affine28U<P>*>(d_bases), s.sorted_keys.as<uint32_t>(),
+               s.sorted_vals.as<uint32_t>(), s.total.as<uint32_t>(), s.offsets.as<uint32_t>(),
+               s.counts.as<uint32_t>(), msm_slots28<P, 4>(b, p.total_buckets, 0), msm_slots28<P, 4>(b, p.total_buckets, 1),
+               b.head_key.as<uint32_t>(), msm_slots28<P, 4>(b, p.total_buckets, 2), b.tail_key.as<uint32_t>(), b.seg_len);
   } else {
-    launch(std::false_type{});
+    ARK_LAUNCH((msm_accumulate_kernel<F, false>), dim3(grid_s), dim3(MSM_THREADS), 0, stream, d_bases,
+               s.sorted_keys.as<uint32_t>(), s.sorted_vals.as<uint32_t>(), s.total.as<uint32_t>(),
+               s.offsets.as<uint32_t>(), s.counts.as<uint32_t>(), b.buckets.as<XYZZ<F>>(), b.head.as<XYZZ<F>>(),
+               b.head_key.as<uint32_t>(), b.tail.as<XYZZ<F>>(), b.tail_key.as<uint32_t>(), b.seg_len);
   }
   ARK_CHECK_LAUNCH();
   if (ev1) ARK_CHECK_HIP(hipEventRecord(ev1, stream));
 }
 
-// policy G2_PAIR_TAILS=0: keep the one-lane-per-bucket tail kernels for G2 (A/B; default: the lane-pair kernels)
-static inline bool msm_g2_pair_tails(const ark355_ctx* ctx) { return ctx->policy.g2_pair_tails != 0; }
+// G2 tails run on lane pairs (round 2; the one-lane-per-bucket kernels with out-of-line Fq2 arithmetic they replaced took
+// 2.5x as long and are gone -- profiles/r02_g2_pair_tails_ab.txt)
+static inline bool msm_g2_pair_tails(const ark355_ctx*) { return true; }
 
 // Phase 2: straddling-run merge, weighted bucket reduction, window combination; writes/accumulates the XYZZ
 // result into d_out.  Only a handful of workgroups and latency-bound, so the prover runs it on its own stream
@@ -2019,10 +2044,9 @@ static bool msm_reduce_phase_batch(ark355_ctx* ctx, int count, const MsmSort* co
 template <class F>
 static void msm_buckets(ark355_ctx* ctx, const MsmSort& s, MsmBuckets& b, const Affine<F>* d_bases, XYZZ<F>* d_out,
                         int accumulate, hipStream_t stream, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr,
-                        bool bases28 = false) {
-  msm_accumulate_phase<F>(ctx, s, b, d_bases, stream, ev0, ev1, bases28);
+                        int fmt = 0) {
+  msm_accumulate_phase<F>(ctx, s, b, d_bases, stream, ev0, ev1, fmt);
   msm_reduce_phase<F>(ctx, s, b, d_out, accumulate, stream);
 }
 
 }  // namespace ark355
-#include "msm_ba_impl.cuh"

@@ -52,15 +52,12 @@ struct TunePolicy {
   int32_t msm_c = 0;              // window size of resident tables (0: planner)
   int32_t msm_c_h = 0;            // window size of the h_query table alone (0: same rule as the others)
   int32_t limb28 = 1, g2_limb28 = 1;
-  int32_t g1_batch_affine = 0, g2_batch_affine = 0;
-  int32_t ba_levels = 5;
+  int32_t pack_rows = -1;         // rows of the 28-bit tables: 1 bit-packed, 0 one word per limb, -1 (default) see table_pack_default (msm_impl.cuh)
   int32_t table_stride = 0;       // 0: planner
   int64_t hbm_budget_mb = 0;      // 0: 80 % of the device
   int32_t shard_dist_wm = 1;      // key shards: h_query in the layout of the distributed witness map when the world size allows it
   // ---- per call
   int32_t msm_seg = 0;            // entries per accumulation lane (0: msm_seg_len)
-  int32_t sort_legacy = 0;
-  int32_t g2_inline = 1, g2_whole = 0, g2_pair_tails = 1;
   int64_t msm_two_level_min = -1; // bucket count from which the two-level reduction runs (-1: ARK_MSM_TWO_LEVEL_MIN)
   int32_t ntt_rmax = 0;           // 0: NTT_RMAX_LOG
   int32_t ntt_direct_max = -1;    // -1: NTT_DIRECT_MAX_LOG
@@ -97,19 +94,13 @@ inline const TunePolicy::Field* TunePolicy::fields(int* count) {
       ARK_POLICY_FIELD32("MSM_C_H", msm_c_h),
       ARK_POLICY_FIELD32("LIMB28", limb28),
       ARK_POLICY_FIELD32("G2_LIMB28", g2_limb28),
-      ARK_POLICY_FIELD32("G1_BATCH_AFFINE", g1_batch_affine),
-      ARK_POLICY_FIELD32("G2_BATCH_AFFINE", g2_batch_affine),
-      ARK_POLICY_FIELD32("BA_LEVELS", ba_levels),
+      ARK_POLICY_FIELD32("PACK_ROWS", pack_rows),
       ARK_POLICY_FIELD32("TABLE_STRIDE", table_stride),
       ARK_POLICY_FIELD64("HBM_BUDGET_MB", hbm_budget_mb),
       ARK_POLICY_FIELD32("SHARD_DIST_WM", shard_dist_wm),
       ARK_POLICY_FIELD32("DWM_LOOPBACK", dwm_loopback),
       ARK_POLICY_FIELD32("RCCL_SELF", rccl_self),
       ARK_POLICY_FIELD32("MSM_SEG", msm_seg),
-      ARK_POLICY_FIELD32("SORT_LEGACY", sort_legacy),
-      ARK_POLICY_FIELD32("G2_INLINE", g2_inline),
-      ARK_POLICY_FIELD32("G2_WHOLE", g2_whole),
-      ARK_POLICY_FIELD32("G2_PAIR_TAILS", g2_pair_tails),
       ARK_POLICY_FIELD64("MSM_TWO_LEVEL_MIN", msm_two_level_min),
       ARK_POLICY_FIELD32("NTT_RMAX", ntt_rmax),
       ARK_POLICY_FIELD32("NTT_DIRECT_MAX", ntt_direct_max),
@@ -166,15 +157,12 @@ inline TunePolicy TunePolicy::from_env() {
       if (e[0]) p.set(f[i].name, strtoll(e, nullptr, 10));
     }
   }
-  // legacy spellings (rounds 1-3): ARK355_SERIAL=1|0, ARK355_EPILOGUE_SYNC=0|1, ARK355_SORT=legacy
+  // legacy spellings (rounds 1-3): ARK355_SERIAL=1|0, ARK355_EPILOGUE_SYNC=0|1
   if (const char* e = getenv("ARK355_SERIAL")) {
     if (e[0]) p.set("SERIAL", e[0] == '1' ? 1 : 0);
   }
   if (const char* e = getenv("ARK355_EPILOGUE_SYNC")) {
     if (e[0]) p.set("EPILOGUE_SYNC", e[0] == '1' ? 1 : 0);
-  }
-  if (const char* e = getenv("ARK355_SORT")) {
-    if (e[0] == 'l') p.sort_legacy = 1;
   }
   return p;
 }

@@ -55,6 +55,24 @@ def test_resident_tables_alternate_limb_forms(emul_lib, emul_ctx, emul_policy, e
     pc.resident_msm_edge_case(emul_lib, emul_ctx, BN254, group, 24, to_dev)
 
 
+@pytest.mark.parametrize("pack", ["1", "0"], ids=["packed", "unpacked"])
+def test_resident_tables_both_row_formats(emul_lib, emul_ctx, emul_policy, pack):
+    """Policy PACK_ROWS: the 28-bit window tables as bit-packed rows (96 / 64 B; msm_accumulate28p_kernel and its lane-pair
+    twin: parked flush, two-deep index prefetch) and as one word per limb (128 / 80 B; the plain walk) -- each forced on BOTH
+    curves and groups (the default packs BN254 only), MSMs with P + P / P - P / infinity inside buckets, then whole proofs."""
+    import numpy as np
+    emul_policy.setenv("ARK355_PACK_ROWS", pack)
+
+    def to_dev(b):
+        a = np.frombuffer(b, dtype=np.uint8).copy()
+        return a.ctypes.data, a
+    for C in (BLS12_381, BN254):
+        for group in (1, 2):
+            pc.resident_msm_edge_case(emul_lib, emul_ctx, C, group, 24, to_dev)
+        A, B, Cm, z, ell = S.mulchain_direct(C.r, 13)
+        pc.prove_case(emul_lib, emul_ctx, C, A, B, Cm, z, ell, rs=((0x1234567890abcdef, 0xfedcba0987654321aabbccdd),))
+
+
 @pytest.mark.parametrize("skew", ["equal", "boolean"])
 def test_msm_skewed_scalars(emul_lib, emul_ctx, skew):
     # all-equal scalars: every term of a window lands in ONE bucket (long straddling runs);
@@ -279,35 +297,6 @@ def test_fixed_base_mul_vs_oracle(emul_lib, emul_ctx, C, group):
 def test_batch_verification_vs_oracle_pairing(emul_lib, emul_ctx, C):
     # the oracle's (slow, pure-Python) pairing is consulted for BLS12-381 here and for both curves in the GPU tier
     pc.verify_batch_case(emul_lib, emul_ctx, C, oracle_pairing=C is BLS12_381, light=True)
-
-
-@pytest.mark.parametrize("group", [2, 1])
-@pytest.mark.parametrize("levels", ["5", "1", "9"])
-def test_batch_affine_accumulation_edge_cases(emul_lib, emul_ctx, emul_policy, group, levels):
-    """ARK355_G2_BATCH_AFFINE / ARK355_G1_BATCH_AFFINE (msm_ba_impl.cuh): the first tree levels of every bucket as affine
-    additions with shared inversions.  P + P, P + (-P), infinity and runs of equal points inside buckets, for 1, 5 and 9
-    tree levels (9 leaves a single node per bucket), against the oracle's naive MSM."""
-    import numpy as np
-    emul_policy.setenv("ARK355_G2_BATCH_AFFINE" if group == 2 else "ARK355_G1_BATCH_AFFINE", "1")
-    emul_policy.setenv("ARK355_BA_LEVELS", levels)
-
-    def to_dev(b):
-        a = np.frombuffer(b, dtype=np.uint8).copy()
-        return a.ctypes.data, a
-    pc.resident_msm_edge_case(emul_lib, emul_ctx, BLS12_381, group, 24, to_dev)
-    if levels == "5":
-        pc.resident_msm_edge_case(emul_lib, emul_ctx, BN254, group, 40, to_dev, seed=5)
-
-
-@pytest.mark.parametrize("C", [BLS12_381, BN254], ids=lambda c: c.name)
-def test_prove_with_batch_affine_accumulation(emul_lib, emul_ctx, emul_policy, C):
-    """Whole proofs with the G2 MSM (and, second pass, all five MSMs) on the batch-affine path: same bytes as the oracle."""
-    A, B, Cm, z, ell = S.mulchain_direct(C.r, 13)
-    emul_policy.setenv("ARK355_G2_BATCH_AFFINE", "1")
-    pc.prove_case(emul_lib, emul_ctx, C, A, B, Cm, z, ell, rs=((0x1234567890abcdef, 0xfedcba0987654321aabbccdd),))
-    if C is BLS12_381:
-        emul_policy.setenv("ARK355_G1_BATCH_AFFINE", "1")
-        pc.prove_case(emul_lib, emul_ctx, C, A, B, Cm, z, ell, rs=((7, 9),))
 
 
 def test_setup_scalars_vs_oracle_incl_tau_in_the_domain_and_bad_csr(emul_lib):

@@ -81,6 +81,29 @@ def test_resident_tables_alternate_limb_forms(gpu_lib, gpu_ctx, gpu_policy, env)
         pc.resident_msm_edge_case(gpu_lib, gpu_ctx, C, group, 200, to_dev)
 
 
+@pytest.mark.parametrize("pack", ["1", "0"], ids=["packed", "unpacked"])
+def test_resident_tables_both_row_formats(gpu_lib, gpu_ctx, gpu_policy, pack):
+    """Policy PACK_ROWS: bit-packed 28-bit table rows (parked-flush kernels) and one word per limb (plain walk), each forced on
+    both curves and groups: exceptional additions inside buckets against the oracle's naive MSM, a 2^16-term MSM with the three
+    scalar distributions against the C oracle, a whole proof."""
+    import numpy as np
+    import torch
+    import o3_cases as O
+    gpu_policy.setenv("ARK355_PACK_ROWS", pack)
+
+    def to_dev(b):
+        t = torch.from_numpy(np.frombuffer(b, dtype=np.uint8).copy()).cuda()
+        torch.cuda.synchronize()
+        return t.data_ptr(), t
+    for C in CURVES:
+        for group in (1, 2):
+            pc.resident_msm_edge_case(gpu_lib, gpu_ctx, C, group, 200, to_dev)
+        A, B, Cm, z, ell = S.mulchain_direct(C.r, 300)
+        pc.prove_case(gpu_lib, gpu_ctx, C, A, B, Cm, z, ell, rs=((0x1234567890abcdef, 0xfedcba0987654321aabbccdd),))
+    for group in (1, 2):
+        O.check_resident_msm(gpu_lib, gpu_ctx, BLS12_381, group, 1 << 16, to_dev, seed=3 + int(pack))
+
+
 @pytest.mark.parametrize("C,group,n,skew", [
     (BLS12_381, 1, 1 << 14, None), (BLS12_381, 1, 1 << 14, "equal"), (BLS12_381, 1, 1 << 14, "boolean"),
     (BLS12_381, 2, 1 << 12, None), (BN254, 1, 1 << 14, None), (BN254, 2, 1 << 12, "boolean"),
@@ -220,36 +243,6 @@ def test_fixed_base_mul_vs_oracle(gpu_lib, gpu_ctx, C, group):
 @pytest.mark.parametrize("C", [BLS12_381, BN254], ids=lambda c: c.name)
 def test_batch_verification_vs_oracle_pairing(gpu_lib, gpu_ctx, C):
     pc.verify_batch_case(gpu_lib, gpu_ctx, C, count=6)
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("group", [2, 1])
-def test_batch_affine_accumulation(gpu_lib, gpu_ctx, gpu_policy, group):
-    """ARK355_G2_BATCH_AFFINE / ARK355_G1_BATCH_AFFINE (msm_ba_impl.cuh): tree levels of affine additions with shared
-    inversions in front of the XYZZ path.  Exceptional additions inside buckets on both curves (oracle's naive MSM), then
-    a 2^16-term MSM with uniform / all-equal / boolean scalars against the independent C oracle."""
-    import numpy as np
-    import torch
-    import o3_cases as O
-    gpu_policy.setenv("ARK355_G2_BATCH_AFFINE" if group == 2 else "ARK355_G1_BATCH_AFFINE", "1")
-
-    def to_dev(b):
-        t = torch.from_numpy(np.frombuffer(b, dtype=np.uint8).copy()).cuda()
-        torch.cuda.synchronize()
-        return t.data_ptr(), t
-    for C in CURVES:
-        pc.resident_msm_edge_case(gpu_lib, gpu_ctx, C, group, 200, to_dev)
-    for levels in ("2", "5"):
-        gpu_policy.setenv("ARK355_BA_LEVELS", levels)
-        O.check_resident_msm(gpu_lib, gpu_ctx, BLS12_381, group, 1 << 16, to_dev, seed=int(levels))
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("C", CURVES, ids=lambda c: c.name)
-def test_prove_with_batch_affine_g2(gpu_lib, gpu_ctx, gpu_policy, C):
-    gpu_policy.setenv("ARK355_G2_BATCH_AFFINE", "1")
-    A, B, Cm, z, ell = S.mulchain_direct(C.r, 300)
-    pc.prove_case(gpu_lib, gpu_ctx, C, A, B, Cm, z, ell, rs=((0x1234567890abcdef, 0xfedcba0987654321aabbccdd), (0, 5)))
 
 
 @pytest.mark.gpu

@@ -84,7 +84,36 @@ def main():
     print("alive waves per 50 us: " + " ".join(str(v) for v in alive))
     cu = (hw >> 8) & 0xF
     se = (hw >> 13) & 0x7
+    sh = (hw >> 12) & 1
+    simd = (hw >> 4) & 3
+    slot = hw & 0xF
     print("distinct (xcc, se, cu) seen: %d" % len(set(zip(xcc.tolist(), se.tolist(), cu.tolist()))))
+    # the two first-round waves of every SIMD: who finishes first?
+    first = st < 20
+    groups = {}
+    for i in np.nonzero(first)[0]:
+        groups.setdefault((int(xcc[i]), int(se[i]), int(sh[i]), int(cu[i]), int(simd[i])), []).append(i)
+    pairs = [g for g in groups.values() if len(g) == 2]
+    if pairs:
+        lo = np.array([min(dur[g[0]], dur[g[1]]) for g in pairs])
+        hi = np.array([max(dur[g[0]], dur[g[1]]) for g in pairs])
+        older_first = np.mean([1.0 if (dur[g[0]] < dur[g[1]]) == (g[0] < g[1]) else 0.0 for g in pairs])
+        print("first round, per SIMD (%d pairs; group sizes %s): faster wave mean %.1f us (p5 %.1f, p95 %.1f), slower wave mean %.1f us (p5 %.1f, p95 %.1f);"
+              " the wave of the LOWER workgroup index is the faster one in %.0f %% of the pairs" % (
+                  len(pairs), sorted(set(len(g) for g in groups.values())), lo.mean(), np.percentile(lo, 5), np.percentile(lo, 95), hi.mean(),
+                  np.percentile(hi, 5), np.percentile(hi, 95), 100 * older_first))
+        # per CU: sum over its 8 first-round waves
+        cus = {}
+        for k, g in groups.items():
+            cus.setdefault(k[:4], []).extend(g)
+        cu_mean = np.array([dur[g].mean() for g in cus.values()])
+        print("first round, mean wave duration per CU: min %.1f  median %.1f  max %.1f us" % (cu_mean.min(), np.median(cu_mean), cu_mean.max()))
+    for name, sel in (("wave slot id", slot), ("simd", simd)):
+        vals = sorted(set(sel[first].tolist()))
+        print("first round, mean duration by %s: " % name + "  ".join("%d: %.0f (%d)" % (v, dur[first & (sel == v)].mean(), int((first & (sel == v)).sum())) for v in vals))
+    out = os.environ.get("ARK355_TRACE_NPZ")
+    if out:
+        np.savez_compressed(out, trace=a)
     L.dll.ark355_bases_free(h)
     L.ctx_destroy(ctx)
 

@@ -2,7 +2,8 @@
 """Aggregate rocprofv3 --pmc counter_collection CSVs per kernel (dev tool; run on the GPU box).
 
 usage: pmc_summary.py [--json OUT.json] [--workload TEXT] [--recorded TEXT]
-Reads gpurun_out/prof_fetch and gpurun_out/prof_write (two separate passes: FETCH_SIZE, WRITE_SIZE).
+Reads <dir>/prof_fetch and <dir>/prof_write (two separate passes: FETCH_SIZE, WRITE_SIZE; --dir, default gpurun_out).
+With --merge the record is added to the "workloads" map of an existing JSON (one record per workload; bench.py's pmc_traffic).
 Counter unit: KiB.  With --json also writes the per-launch figures of the dominant kernel
 (msm_accumulate_kernel) that bench.py reports as `roofline.traffic`."""
 import collections
@@ -12,9 +13,10 @@ import json
 import re
 import sys
 
+BASE = sys.argv[sys.argv.index("--dir") + 1] if "--dir" in sys.argv else "gpurun_out"
 agg = collections.defaultdict(lambda: [0, 0.0])
 for kind in ("fetch", "write"):
-    for f in glob.glob("gpurun_out/prof_%s/**/*counter_collection.csv" % kind, recursive=True):
+    for f in glob.glob("%s/prof_%s/**/*counter_collection.csv" % (BASE, kind), recursive=True):
         for row in csv.DictReader(open(f)):
             k = re.sub(r"\(.*", "", row.get("Kernel_Name", ""))
             k = k.replace("ark355::", "")[:70]
@@ -39,7 +41,16 @@ if "--json" in sys.argv:
         "launches": acc["FETCH_SIZE"][0],
         "fetch_bytes_per_launch": acc["FETCH_SIZE"][1] * 1024 / max(1, acc["FETCH_SIZE"][0]),
         "write_bytes_per_launch": acc["WRITE_SIZE"][1] * 1024 / max(1, acc["WRITE_SIZE"][0]),
-        "note": "FETCH_SIZE/WRITE_SIZE as counted (KiB->B); random 128-B (G1, Affine28 rows) / 2x96-B (G2) gathers: no gfx950 doubling applied "
-                "(calibration in DESIGN.md section 3)",
+        "note": "FETCH_SIZE/WRITE_SIZE as counted (KiB->B); random 96-B (G1, packed Affine28 rows) / 2x128-B (G2 halves) gathers: no gfx950 "
+                "doubling applied (calibration in DESIGN.md section 3)",
     }
-    json.dump(rec, open(out, "w"), indent=1)
+    if "--merge" in sys.argv:
+        import os
+        top = json.load(open(out)) if os.path.exists(out) else {}
+        if "workloads" not in top:
+            top = {"workloads": ({top["workload"]: top} if top.get("workload") else {})}
+        rec.pop("kernels", None)          # the per-kernel table of every workload would be megabytes; the accumulation rows are what bench.py reads
+        top["workloads"][wl] = rec
+        json.dump(top, open(out, "w"), indent=1)
+    else:
+        json.dump(rec, open(out, "w"), indent=1)

@@ -160,8 +160,10 @@ __global__ void __launch_bounds__(256, ARK_G2L28_WAVES) k_madd28_g2(Acc28<P>* ou
   bool empty = true;
   const uint64_t t0 = __builtin_readcyclecounter();
   for (int it = 0; it < iters; it++) {
-    const Affine28<P>& row = in[(seg * 7 + it * 13) & 511].half[par];
-    const F px = Affine28<P>::unpack(row.w), py = Affine28<P>::unpack(row.w + Affine28<P>::NB);
+    const Affine28U<P>& row = in[(seg * 7 + it * 13) & 511].half[par];
+    F px, py;
+#pragma unroll
+    for (int k = 0; k < F::N; k++) { px.l[k] = row.w[k] & F::MASK; py.l[k] = row.w[F::N + k] & F::MASK; }
     madd28_g2<P>(acc, empty, px, py, (it & 1) != 0);
   }
   const uint64_t t1 = __builtin_readcyclecounter();
