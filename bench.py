@@ -583,12 +583,18 @@ def main():
     isolated = None
     if not shard and not emul and rank == 0 and not args.profile_run:
         g.lib.ctx_set_policy(g.ctx, "SCHED", 0)
+        # (a lone one-stream proof normally runs its witness map and its G2 tails on side streams: not here -- ONE stream)
+        side = {k: g.lib.ctx_get_policy(g.ctx, k) for k in ("SIDE_WM", "SIDE_G2_TAILS")}
+        for k in side:
+            g.lib.ctx_set_policy(g.ctx, k, 0)
         acc, tms = [], []
         for _ in range(3):
             prove_on(g.ctx, rnd.randrange(cv.r), rnd.randrange(cv.r))
             acc.append(g.lib.kernel_stats(g.ctx)["accumulate_ms"])
             tms.append(g.lib.timings(g.ctx))
         g.lib.ctx_set_policy(g.ctx, "SCHED", -1)
+        for k, v in side.items():
+            g.lib.ctx_set_policy(g.ctx, k, v)
         dev_sync()
         tmed = {k: sorted(t[k] for t in tms)[1] for k in tms[0]}
         N_ = r1.domain_size
@@ -614,11 +620,14 @@ def main():
             prove_on(g.ctx, rnd.randrange(cv.r), rnd.randrange(cv.r))
     if not shard and len(ctxs) > 1 and not args.profile_run:
         solo_rec = [0.0, 0, 0]
+        wm_side = g.lib.ctx_get_policy(g.ctx, "SIDE_WM")        # the accumulation launches ALONE: no witness map beside the first ones
+        g.lib.ctx_set_policy(g.ctx, "SIDE_WM", 0)
         for _ in range(3):
             prove_on(g.ctx, rnd.randrange(cv.r), rnd.randrange(cv.r))
             ks = g.lib.kernel_stats(g.ctx)
             solo_rec[0] += ks["accumulate_ms"]
             solo_rec[1] += ks["launches"]
+        g.lib.ctx_set_policy(g.ctx, "SIDE_WM", wm_side)
         dev_sync()
         solo = solo_rec[0] / max(1, solo_rec[1])
         tim = g.lib.timings(g.ctx)

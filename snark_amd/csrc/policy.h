@@ -43,6 +43,7 @@ struct TunePolicy {
   int32_t sched_explore = 3;      // samples per candidate before SCHED_AUTO latches (0: static default, no exploration)
   int32_t batch_tails = 1;        // one-stream proofs: merge / reduce / combine of the four G1 MSMs as ONE launch each
   int32_t side_g2_tails = 1;      // a one-stream proof ALONE on the device: its G2 tails on a second stream, under the G1 accumulations
+  int32_t side_wm = 1;            // ... and its witness map + the sort of h on a second stream, beside the sort of z and the first four accumulations
   int32_t dwm_loopback = 0;       // DIAGNOSTIC (timing only, wrong proofs): ark355_prove_shard runs the distributed witness map of its
                                   // rank with the exchanges as local copies -- the per-rank cost of a G-GPU proof on one GPU
   int32_t rccl_self = 0;          // DIAGNOSTIC / TEST (read when a key shard is loaded and per proof): at world size 1 a sharded proof runs
@@ -90,6 +91,7 @@ inline const TunePolicy::Field* TunePolicy::fields(int* count) {
       ARK_POLICY_FIELD32("SCHED_EXPLORE", sched_explore),
       ARK_POLICY_FIELD32("BATCH_TAILS", batch_tails),
       ARK_POLICY_FIELD32("SIDE_G2_TAILS", side_g2_tails),
+      ARK_POLICY_FIELD32("SIDE_WM", side_wm),
       ARK_POLICY_FIELD32("MSM_C", msm_c),
       ARK_POLICY_FIELD32("MSM_C_H", msm_c_h),
       ARK_POLICY_FIELD32("LIMB28", limb28),
