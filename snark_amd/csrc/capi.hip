@@ -1,7 +1,9 @@
 // extern "C" surface of libark355.so (include/ark355.h).  No C++ exception crosses this boundary:
 // every entry point catches and maps to an error code (the reference builds with panic='abort' for
 // exactly that reason, /root/reference/Cargo.toml:33,45).
+#include <algorithm>
 #include <atomic>
+#include <mutex>
 #include <new>
 #include <thread>
 #include "api_impl.cuh"
@@ -203,6 +205,19 @@ int32_t ark355_diag_streams(ark355_ctx** ctxs, uint32_t count, int8_t* serialise
   if (!ctxs || !serialised || count == 0 || count > 16) return ARK355_EINVAL;
   for (uint32_t i = 0; i < count; i++)
     if (!ctxs[i]) return ARK355_EINVAL;
+  // The probe synchronises and launches on EVERY passed context's stream: the other contexts are locked too (in address order:
+  // two callers with overlapping sets cannot deadlock), and a context that is proving right now makes the call fail instead of
+  // racing with it.
+  std::vector<ark355_ctx*> others;
+  for (uint32_t i = 1; i < count; i++)
+    if (ctxs[i] != ctxs[0] && std::find(others.begin(), others.end(), ctxs[i]) == others.end()) others.push_back(ctxs[i]);
+  std::sort(others.begin(), others.end());
+  std::vector<std::unique_lock<std::mutex>> held;
+  for (ark355_ctx* c : others) {
+    std::unique_lock<std::mutex> lk(c->mu, std::try_to_lock);
+    if (!lk.owns_lock()) return ARK355_EINVAL;          // busy: the diagnostic wants an idle device
+    held.push_back(std::move(lk));
+  }
   // streams probed: every context's own stream, then the three feeder streams of ctxs[0] (created if need be)
   return guarded(ctxs[0], [&] {
     CtxExtra& ex = extra(ctxs[0]);
