@@ -70,8 +70,8 @@ int32_t ark355_sizes(int32_t curve, uint32_t what[4]);
  *                 measured choice latches; 0 = static defaults), WAIT_SPIN, WAIT_ADAPT, STREAM_PRIO, DEVICE_FINALIZE, BATCH_TAILS,
  *                 SIDE_G2_TAILS, SIDE_WM (a proof alone on the device: G2 tails / witness map on side streams),
  *                 TRACE_HOST; legacy spellings SERIAL (1 -> SCHED 0, 0 -> SCHED 1) and EPILOGUE_SYNC (on a pipeline: 1 -> 2);
- *   per key load  MSM_C, MSM_C_H (window size of all tables / of the h_query table; 0 = planner), LIMB28, G2_LIMB28,
- *                 TABLE_STRIDE, HBM_BUDGET_MB, SHARD_DIST_WM, RCCL_SELF (diagnostic: a rank at world size 1 exchanges with
+ *   per key load  MSM_C, MSM_C_H (window size of all tables / of the h_query table; 0 = planner), PACK_ROWS
+ *                 (table rows bit-packed 1 / one word per limb 0 / per curve -1), TABLE_STRIDE, HBM_BUDGET_MB, SHARD_DIST_WM, RCCL_SELF (diagnostic: a rank at world size 1 exchanges with
  *                 itself) -- read when a key or base set is loaded THROUGH this context;
  *   per call      MSM_SEG, MSM_TWO_LEVEL_MIN, NTT_RMAX, NTT_DIRECT_MAX, NTT_NOFUSE (A/B and test knobs).
  * ARK355_EINVAL for an unknown name.  ark355_prove_batch runs its worker contexts under the caller's policy.

@@ -1379,12 +1379,6 @@ struct PrecompTable {
   int fmt() const { return limb28 ? (packed ? 2 : 1) : 0; }       // what msm_accumulate_phase is told
 };
 
-// policy LIMB28=0|1 / G2_LIMB28=0|1 (both default 1): window tables and bucket accumulation of G1 / G2 in the
-// radix-2^28 form (msm28_impl.cuh); 0 keeps the 32-bit kernels (A/B switches, exercised by the tests).
-static inline bool msm_use_limb28(const TunePolicy& pol, bool g2) {       // read when a table is built
-  return (g2 ? pol.g2_limb28 : pol.limb28) != 0;
-}
-
 // ---- HBM footprint of window tables -------------------------------------------------------------------------------------
 // Full tables (every window) are W x the key: 16 x 128-byte rows per G1 base at c = 16, i.e. 15 GB for a 2^20-constraint
 // BLS12-381 key, 60 GB at 2^22, ~120 GB at 2^23 and more than one MI355X holds at 2^24.  table_row_bytes / the planner
@@ -1459,8 +1453,7 @@ static inline uint32_t table_stride_plan(const TunePolicy& pol, const TableNeed*
       const MsmPlan p = msm_plan(need[i].n, Fr::Params::BITS, true,
                                  need[i].plan_n ? (int)msm_plan(need[i].plan_n, Fr::Params::BITS, true, 0, 0, pc).c : 0, s, pc);
       if (p.windows > max_windows) max_windows = p.windows;
-      const bool l28 = msm_use_limb28(pol, need[i].g2);
-      const size_t row = need[i].g2 ? table_row_bytes<Fq2>(l28, pk) : table_row_bytes<Fq>(l28, pk);
+      const size_t row = need[i].g2 ? table_row_bytes<Fq2>(true, pk) : table_row_bytes<Fq>(true, pk);
       const size_t aff = need[i].g2 ? sizeof(Affine<Fq2>) : sizeof(Affine<Fq>);
       const size_t xyzz = need[i].g2 ? sizeof(XYZZ<Fq2>) : sizeof(XYZZ<Fq>);
       resident += (size_t)p.table_windows * need[i].n * row;
@@ -1495,28 +1488,9 @@ static void precomp_build(const TunePolicy& pol, PrecompTable& t, const void* d_
   if (pol.trace_host)
     fprintf(stderr, "[ark355] window table: %llu bases, c = %u, %u windows (%u table blocks, %u bucket sets)%s\n",
             (unsigned long long)n, p.c, p.windows, TW, p.key_windows, p.negate_high ? ", scalars above (r - 1) / 2 negated" : "");
-  const bool l28 = msm_use_limb28(pol, is_fp2<F>::value);
   const uint32_t grid = (uint32_t)((n + MSM_THREADS - 1) / MSM_THREADS);
   const uint32_t gridb = (uint32_t)(((n + PRE_K - 1) / PRE_K + MSM_THREADS - 1) / MSM_THREADS);
   const uint32_t shift = p.c * p.wstride;              // consecutive table blocks differ by 2^(c * wstride)
-  if (!l28) {
-    // canonical affine rows are the final form: blocks are built in place, one after the other
-    t.table.alloc((size_t)TW * (n ? n : 1) * sizeof(Affine<F>));
-    if (n == 0) return;
-    ARK_CHECK_HIP(hipMemcpyAsync(t.table.p, d_bases, n * sizeof(Affine<F>), hipMemcpyDeviceToDevice, stream));
-    DevBuf tmp(n * sizeof(XYZZ<F>));
-    Affine<F>* T = t.table.as<Affine<F>>();
-    for (uint32_t w = 1; w < TW; w++) {
-      ARK_LAUNCH((precomp_shift_kernel<F>), dim3(grid), dim3(MSM_THREADS), 0, stream, (const Affine<F>*)(T + (size_t)(w - 1) * n),
-                 tmp.as<XYZZ<F>>(), (uint32_t)n, shift);
-      ARK_CHECK_LAUNCH();
-      ARK_LAUNCH((batch_to_affine_kernel<F>), dim3(gridb), dim3(MSM_THREADS), 0, stream, (const XYZZ<F>*)tmp.as<XYZZ<F>>(),
-                 T + (size_t)w * n, (uint32_t)n);
-      ARK_CHECK_LAUNCH();
-    }
-    ARK_CHECK_HIP(hipStreamSynchronize(stream));     // tmp is freed on return
-    return;
-  }
   // radix-2^28 rows (msm28_impl.cuh): the canonical form of a block only lives in a two-block staging area while the
   // next block is derived from it; each finished block is re-encoded straight into the final table.  (The first version
   // built the whole canonical table first: 75 % more HBM at the peak than the key keeps -- what a 2^23-constraint key

@@ -6,12 +6,14 @@
 // ark355_prove_batch inherit the parent's policy at every call.
 //
 // Three groups:
-//   per proof      SCHED, WAIT_SPIN, WAIT_ADAPT, STREAM_PRIO, DEVICE_FINALIZE, TRACE_HOST (+ the legacy spellings SERIAL
-//                  and EPILOGUE_SYNC, which map onto SCHED)
-//   per key load   MSM_C, LIMB28, G2_LIMB28, G1_BATCH_AFFINE, G2_BATCH_AFFINE, BA_LEVELS, TABLE_STRIDE, HBM_BUDGET_MB
+//   per proof      SCHED, SCHED_EXPLORE, WAIT_SPIN, WAIT_ADAPT, STREAM_PRIO, DEVICE_FINALIZE, BATCH_TAILS, SIDE_G2_TAILS,
+//                  SIDE_WM, TRACE_HOST (+ the legacy spellings SERIAL and EPILOGUE_SYNC, which map onto SCHED);
+//                  sharded proofs: DWM_LOOPBACK, RCCL_SELF (window / bucket-ring combining is the `mode` argument of
+//                  ark355_prove_sharded, not a policy)
+//   per key load   MSM_C, MSM_C_H, PACK_ROWS, TABLE_STRIDE, HBM_BUDGET_MB, SHARD_DIST_WM
 //                  (read when a key / base set is loaded through the context: the tables are built for them)
-//   per call       MSM_SEG, SORT_LEGACY, G2_INLINE, G2_WHOLE, G2_PAIR_TAILS, MSM_TWO_LEVEL_MIN, NTT_RMAX, NTT_DIRECT_MAX,
-//                  NTT_NOFUSE (A/B and test knobs of the kernels' host drivers)
+//   per call       MSM_SEG, MSM_TWO_LEVEL_MIN, NTT_RMAX, NTT_DIRECT_MAX, NTT_NOFUSE (A/B and test knobs of the kernels'
+//                  host drivers)
 #pragma once
 #include <stddef.h>
 #include <stdint.h>
@@ -52,7 +54,6 @@ struct TunePolicy {
   // ---- per key load
   int32_t msm_c = 0;              // window size of resident tables (0: planner)
   int32_t msm_c_h = 0;            // window size of the h_query table alone (0: same rule as the others)
-  int32_t limb28 = 1, g2_limb28 = 1;
   int32_t pack_rows = -1;         // rows of the 28-bit tables: 1 bit-packed, 0 one word per limb, -1 (default) see table_pack_default (msm_impl.cuh)
   int32_t table_stride = 0;       // 0: planner
   int64_t hbm_budget_mb = 0;      // 0: 80 % of the device
@@ -94,8 +95,6 @@ inline const TunePolicy::Field* TunePolicy::fields(int* count) {
       ARK_POLICY_FIELD32("SIDE_WM", side_wm),
       ARK_POLICY_FIELD32("MSM_C", msm_c),
       ARK_POLICY_FIELD32("MSM_C_H", msm_c_h),
-      ARK_POLICY_FIELD32("LIMB28", limb28),
-      ARK_POLICY_FIELD32("G2_LIMB28", g2_limb28),
       ARK_POLICY_FIELD32("PACK_ROWS", pack_rows),
       ARK_POLICY_FIELD32("TABLE_STRIDE", table_stride),
       ARK_POLICY_FIELD64("HBM_BUDGET_MB", hbm_budget_mb),

@@ -39,22 +39,6 @@ def test_resident_tables_exceptional_additions(emul_lib, emul_ctx, C, group):
     pc.resident_msm_edge_case(emul_lib, emul_ctx, C, group, 24, to_dev)
 
 
-@pytest.mark.parametrize("env", [{"ARK355_G2_LIMB28": "0"}, {"ARK355_LIMB28": "0"}], ids=["g2-32bit", "g1-32bit"])
-def test_resident_tables_alternate_limb_forms(emul_lib, emul_ctx, emul_policy, env):
-    """The 32-bit lane-split G2 kernel and the 32-bit G1 kernel over window tables (the A/B switches; the defaults
-    are the radix-2^28 kernels)."""
-    import numpy as np
-    for k, v in env.items():
-        emul_policy.setenv(k, v)
-
-    def to_dev(b):
-        a = np.frombuffer(b, dtype=np.uint8).copy()
-        return a.ctypes.data, a
-    group = 2 if "ARK355_G2_LIMB28" in env else 1
-    pc.resident_msm_edge_case(emul_lib, emul_ctx, BLS12_381, group, 24, to_dev)
-    pc.resident_msm_edge_case(emul_lib, emul_ctx, BN254, group, 24, to_dev)
-
-
 @pytest.mark.parametrize("pack", ["1", "0"], ids=["packed", "unpacked"])
 def test_resident_tables_both_row_formats(emul_lib, emul_ctx, emul_policy, pack):
     """Policy PACK_ROWS: the 28-bit window tables as bit-packed rows (96 / 64 B; msm_accumulate28p_kernel and its lane-pair

@@ -64,23 +64,6 @@ def test_resident_tables_exceptional_additions(gpu_lib, gpu_ctx, C, group, n):
     pc.resident_msm_edge_case(gpu_lib, gpu_ctx, C, group, n, to_dev)
 
 
-@pytest.mark.parametrize("env", [{"ARK355_G2_LIMB28": "0"}, {"ARK355_LIMB28": "0"}], ids=["g2-32bit", "g1-32bit"])
-def test_resident_tables_alternate_limb_forms(gpu_lib, gpu_ctx, gpu_policy, env):
-    """The 32-bit lane-split G2 kernel and the 32-bit G1 kernel over window tables (the A/B switches; the defaults
-    are the radix-2^28 kernels)."""
-    import numpy as np
-    import torch
-    for k, v in env.items():
-        gpu_policy.setenv(k, v)
-
-    def to_dev(b):
-        t = torch.from_numpy(np.frombuffer(b, dtype=np.uint8).copy()).cuda()
-        return t.data_ptr(), t
-    group = 2 if "ARK355_G2_LIMB28" in env else 1
-    for C in CURVES:
-        pc.resident_msm_edge_case(gpu_lib, gpu_ctx, C, group, 200, to_dev)
-
-
 @pytest.mark.parametrize("pack", ["1", "0"], ids=["packed", "unpacked"])
 def test_resident_tables_both_row_formats(gpu_lib, gpu_ctx, gpu_policy, pack):
     """Policy PACK_ROWS: bit-packed 28-bit table rows (parked-flush kernels) and one word per limb (plain walk), each forced on
