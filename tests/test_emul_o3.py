@@ -56,11 +56,11 @@ def test_window_sizes_that_negate_high_scalars(emul_lib, emul_ctx, emul_policy, 
         a = np.frombuffer(b, dtype=np.uint8).copy()
         return a.ctypes.data, a
 
-    pc.resident_known_dlog_case(emul_lib, emul_ctx, BLS12_381, 1, 1024, to_dev)
+    pc.resident_known_dlog_case(emul_lib, emul_ctx, BLS12_381, 1, 320, to_dev)
     if c == "5":
-        pc.resident_known_dlog_case(emul_lib, emul_ctx, BLS12_381, 2, 1024, to_dev)
-        O.check_resident_msm(emul_lib, emul_ctx, BLS12_381, 1, 1024, to_dev, seed=9)
-        A, B, Cm, z, ell = S.mulchain_direct(BLS12_381.r, 1030)
+        pc.resident_known_dlog_case(emul_lib, emul_ctx, BLS12_381, 2, 256, to_dev)
+        O.check_resident_msm(emul_lib, emul_ctx, BLS12_381, 1, 512, to_dev, seed=9)
+        A, B, Cm, z, ell = S.mulchain_direct(BLS12_381.r, 300)
         pc.prove_case(emul_lib, emul_ctx, BLS12_381, A, B, Cm, z, ell, rs=((5, 7),))
 
 
