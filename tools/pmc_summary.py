@@ -41,7 +41,7 @@ if "--json" in sys.argv:
         "launches": acc["FETCH_SIZE"][0],
         "fetch_bytes_per_launch": acc["FETCH_SIZE"][1] * 1024 / max(1, acc["FETCH_SIZE"][0]),
         "write_bytes_per_launch": acc["WRITE_SIZE"][1] * 1024 / max(1, acc["WRITE_SIZE"][0]),
-        "note": "FETCH_SIZE/WRITE_SIZE as counted (KiB->B); random 96-B (G1, packed Affine28 rows) / 2x128-B (G2 halves) gathers: no gfx950 "
+        "note": "FETCH_SIZE/WRITE_SIZE as counted (KiB->B); random row gathers (BLS12-381: 128-B G1 rows / 2x128-B G2 halves, one word per limb; BN254: 64-B packed G1 rows / 2x64-B halves): no gfx950 "
                 "doubling applied (calibration in DESIGN.md section 3)",
     }
     if "--merge" in sys.argv:
