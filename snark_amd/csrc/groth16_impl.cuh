@@ -567,12 +567,13 @@ static void prove_run(ark355_ctx* ctx, ProverScratch& sc, const PkDev& pk, const
         ARK_REQUIRE(all[4 * (size_t)g + k] == mine[k], ARK355_EINVAL,
                     "key shards of different ranks were planned with different window sizes / table strides / witness-map layouts");
   }
-  enum { E_START, E_Z, E_ZS, E_H, E_SORT0, E_SORT1, E_SORT2, E_G2T, E_FILL, E_ACC_DONE0, E_END = E_ACC_DONE0 + 5, E_COUNT };
+  enum { E_START, E_Z, E_ZS, E_H, E_SORT0, E_SORT1, E_SORT2, E_G2T, E_FILL, E_HT, E_ACC_DONE0, E_END = E_ACC_DONE0 + 5, E_COUNT };
   static_assert(E_COUNT + 10 <= ProverScratch::N_EVENTS, "event pool too small");
   sc.ensure_events();
   hipEvent_t* ev = sc.events;
   hipEvent_t* acc0 = sc.events + E_COUNT;
   hipEvent_t* acc1 = sc.events + E_COUNT + 5;
+  bool h_tails_aside = false;       // the tails of the H MSM were queued on the sort stream (E_HT is its last event then)
   {
     // r, s -> Montgomery on the host (the library's own field code); tail = [-rs, 1, r, s]
     Fr rc, scn;
@@ -711,21 +712,34 @@ static void prove_run(ark355_ctx* ctx, ProverScratch& sc, const PkDev& pk, const
       ARK_CHECK_HIP(hipEventRecord(ev[E_ACC_DONE0 + j], sA));
       pts += (uint64_t)jb.sort->plan.windows * jb.sort->plan.n;
       if (batch_tails) continue;
-      ARK_CHECK_HIP(hipStreamWaitEvent(sR, ev[E_ACC_DONE0 + j], 0));
-      if (cm && shard_mode == ARK355_SHARD_BUCKET_RING) {
+      // Multi-stream schedules: the tails of the LAST MSM (H) go to the sort stream, which has been idle since the sort of h,
+      // instead of queueing behind the tails of L' on the reduction stream.  The tails run starved under the accumulations
+      // (2.4 ms per MSM instead of 1.2), so with short accumulations -- a rank of a sharded proof: 2 ms each -- the reduction
+      // stream falls behind and the tails of H, the end of the proof's critical path, started 0.8 ms after its accumulation had
+      // ended (kernel trace of run M).  Not with the bucket ring: its grouped sends must be queued in one order on every rank.
+      const bool ring = cm && shard_mode == ARK355_SHARD_BUCKET_RING;
+      const bool side_tail = j == 4 && !one_stream && !ring && sS != sR && pol.side_h_tails != 0;
+      hipStream_t sT = side_tail ? sS : sR;
+      ARK_CHECK_HIP(hipStreamWaitEvent(sT, ev[E_ACC_DONE0 + j], 0));
+      if (ring) {
         // bucket-level exchange: the ranks run their MSMs in the same order, so the ring steps pair up
         if (jb.g2)
-          msm_reduce_phase<Fq2>(ctx, *red_sort, *jb.bk, g2res, 0, sR, [&](XYZZ<Fq2>* bk, uint32_t nb, hipStream_t st) {
+          msm_reduce_phase<Fq2>(ctx, *red_sort, *jb.bk, g2res, 0, sT, [&](XYZZ<Fq2>* bk, uint32_t nb, hipStream_t st) {
             ring_reduce_scatter_buckets<Fq2>(*cm, bk, nb, st, pol.rccl_self != 0);
           });
         else
-          msm_reduce_phase<Fq>(ctx, *red_sort, *jb.bk, g1res + jb.res, 0, sR, [&](XYZZ<Fq>* bk, uint32_t nb, hipStream_t st) {
+          msm_reduce_phase<Fq>(ctx, *red_sort, *jb.bk, g1res + jb.res, 0, sT, [&](XYZZ<Fq>* bk, uint32_t nb, hipStream_t st) {
             ring_reduce_scatter_buckets<Fq>(*cm, bk, nb, st, pol.rccl_self != 0);
           });
       } else if (jb.g2) {
-        msm_reduce_phase<Fq2>(ctx, *red_sort, *jb.bk, g2res, 0, sR);
+        msm_reduce_phase<Fq2>(ctx, *red_sort, *jb.bk, g2res, 0, sT);
       } else {
-        msm_reduce_phase<Fq>(ctx, *red_sort, *jb.bk, g1res + jb.res, 0, sR);
+        msm_reduce_phase<Fq>(ctx, *red_sort, *jb.bk, g1res + jb.res, 0, sT);
+      }
+      if (side_tail) {
+        h_tails_aside = true;
+        ARK_CHECK_HIP(hipEventRecord(ev[E_HT], sT));
+        ARK_CHECK_HIP(hipStreamWaitEvent(sR, ev[E_HT], 0));      // everything still drains into sR
       }
     }
     if (batch_tails) {
@@ -815,7 +829,7 @@ static void prove_run(ark355_ctx* ctx, ProverScratch& sc, const PkDev& pk, const
       ARK_CHECK_HIP(hipStreamSynchronize(sS));
       ARK_CHECK_HIP(hipStreamSynchronize(sW));
     } else if (!one_stream) {
-      for (hipEvent_t last : {ev[E_ACC_DONE0 + 4], ev[E_SORT2], ev[E_H]}) {
+      for (hipEvent_t last : {ev[E_ACC_DONE0 + 4], h_tails_aside ? ev[E_HT] : ev[E_SORT2], ev[E_H]}) {
         const hipError_t q = hipEventQuery(last);
         if (q == hipErrorNotReady) wait_event_polite(last, spin);
         else if (q != hipSuccess) ARK_CHECK_HIP(q);

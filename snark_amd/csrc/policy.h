@@ -7,7 +7,7 @@
 //
 // Three groups:
 //   per proof      SCHED, SCHED_EXPLORE, WAIT_SPIN, WAIT_ADAPT, STREAM_PRIO, DEVICE_FINALIZE, BATCH_TAILS, SIDE_G2_TAILS,
-//                  SIDE_WM, TRACE_HOST (+ the legacy spellings SERIAL and EPILOGUE_SYNC, which map onto SCHED);
+//                  SIDE_WM, SIDE_H_TAILS, TRACE_HOST (+ the legacy spellings SERIAL and EPILOGUE_SYNC, which map onto SCHED);
 //                  sharded proofs: DWM_LOOPBACK, RCCL_SELF (window / bucket-ring combining is the `mode` argument of
 //                  ark355_prove_sharded, not a policy)
 //   per key load   MSM_C, MSM_C_H, PACK_ROWS, TABLE_STRIDE, HBM_BUDGET_MB, SHARD_DIST_WM
@@ -46,6 +46,7 @@ struct TunePolicy {
   int32_t batch_tails = 1;        // one-stream proofs: merge / reduce / combine of the four G1 MSMs as ONE launch each
   int32_t side_g2_tails = 1;      // a one-stream proof ALONE on the device: its G2 tails on a second stream, under the G1 accumulations
   int32_t side_wm = 1;            // ... and its witness map + the sort of h on a second stream, beside the sort of z and the first four accumulations
+  int32_t side_h_tails = 1;       // multi-stream schedules: the tails of the last MSM (H) on the sort stream instead of behind the tails of L'
   int32_t dwm_loopback = 0;       // DIAGNOSTIC (timing only, wrong proofs): ark355_prove_shard runs the distributed witness map of its
                                   // rank with the exchanges as local copies -- the per-rank cost of a G-GPU proof on one GPU
   int32_t rccl_self = 0;          // DIAGNOSTIC / TEST (read when a key shard is loaded and per proof): at world size 1 a sharded proof runs
@@ -93,6 +94,7 @@ inline const TunePolicy::Field* TunePolicy::fields(int* count) {
       ARK_POLICY_FIELD32("BATCH_TAILS", batch_tails),
       ARK_POLICY_FIELD32("SIDE_G2_TAILS", side_g2_tails),
       ARK_POLICY_FIELD32("SIDE_WM", side_wm),
+      ARK_POLICY_FIELD32("SIDE_H_TAILS", side_h_tails),
       ARK_POLICY_FIELD32("MSM_C", msm_c),
       ARK_POLICY_FIELD32("MSM_C_H", msm_c_h),
       ARK_POLICY_FIELD32("PACK_ROWS", pack_rows),
