@@ -137,7 +137,7 @@ def e2e_reading(curve, n, inflight, device_value):
         env.pop("ARK355_E2E_SWEEP", None)
         out = {"unit": "constraints/s", "synthesis_threads": threads, "inflight": inflight, "host_cpu_quota_cores": quota,
                "host": "C++ mirror of ark-relations (host_mirror/), witness-only synthesis; a Rust host runs the real crate"}
-        for tag, circuit, count, extra in (("s3_bench_lc", "benchlc", inflight, ["e2e-only"]), ("s2_mulchain", "mulchain", 6 * inflight, [])):
+        for tag, circuit, count, extra in (("s3_bench_lc", "benchlc", max(inflight, threads), ["e2e-only"]), ("s2_mulchain", "mulchain", 6 * inflight, [])):
             t0 = time.perf_counter()
             try:
                 r = subprocess.run([exe, "--e2e", curve, str(n), str(count), str(threads), str(inflight), circuit] + extra,
