@@ -118,6 +118,15 @@ def test_one_stream_batched_g1_tails(emul_lib, emul_ctx, emul_policy, circuit, b
     pc.prove_case(emul_lib, emul_ctx, C, *inst, rs=((3, 0x1234567), ))
 
 
+@pytest.mark.parametrize("side", ["1", "0"])
+def test_pipeline_last_msm_tails_on_either_stream(emul_lib, emul_ctx, emul_policy, side):
+    """Five-stream pipeline: the tails of the H MSM on the sort stream (policy SIDE_H_TAILS, default) / on the reduction stream."""
+    emul_policy.setenv("ARK355_SCHED", "1")
+    emul_policy.setenv("ARK355_SIDE_H_TAILS", side)
+    C = BLS12_381
+    pc.prove_case(emul_lib, emul_ctx, C, *S.mulchain_direct(C.r, 37), rs=((5, 0x7654321), ))
+
+
 def test_measured_schedule_choice_explores_then_latches(emul_lib):
     """Policy SCHED = -1 (default): the first warm proofs of a class run the candidate schedules in turn (SCHED_EXPLORE samples
     each), every one of them gives the oracle's bytes, and the class then keeps one schedule (ark355_sched_info)."""

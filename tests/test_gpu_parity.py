@@ -252,6 +252,17 @@ def test_one_stream_tail_variants(gpu_lib, gpu_ctx, gpu_policy, circuit, batch, 
     pc.prove_case(gpu_lib, gpu_ctx, C, *inst, rs=((11, 0xABCDEF),))
 
 
+@pytest.mark.parametrize("side", ["1", "0"], ids=["h-tails-on-sort-stream", "h-tails-on-reduction-stream"])
+def test_pipeline_last_msm_tails_on_either_stream(gpu_lib, gpu_ctx, gpu_policy, side):
+    """Five-stream pipeline (SCHED=1): the tails of the H MSM on the sort stream (policy SIDE_H_TAILS, the default) and behind
+    the tails of L' on the reduction stream -- uniform scalars and the all-equal DummyCircuit; proof bytes == oracle both ways."""
+    gpu_policy.setenv("ARK355_SCHED", "1")
+    gpu_policy.setenv("ARK355_SIDE_H_TAILS", side)
+    C = BLS12_381
+    pc.prove_case(gpu_lib, gpu_ctx, C, *S.mulchain_direct(C.r, 700), rs=((13, 0xFEDCBA),))
+    pc.prove_case(gpu_lib, gpu_ctx, C, *S.cs_to_instance(S.dummy_cs(C.r, 900)), rs=((0, 1),))
+
+
 @pytest.mark.parametrize("serial", ["1", "0"])
 def test_prove_one_stream_schedule(gpu_lib, gpu_ctx, gpu_policy, serial):
     """The schedule prove_run picks with other proofs in flight (one stream) and the one it picks for a proof alone (five
