@@ -1770,6 +1770,11 @@ static void msm_accumulate_phase(ark355_ctx* ctx, const MsmSort& s, MsmBuckets& 
   if (p.n == 0) return;
   const uint32_t segs = b.segs;
   const uint32_t grid_s = (segs + MSM_THREADS - 1) / MSM_THREADS;
+  // Workgroup size of the two kernels without LDS (unpacked 28-bit rows), policy ACC_THREADS: ONE wave per workgroup by default.
+  // A 256-lane workgroup needs a free register slot on four SIMDs at once and gives its slots back only when its slowest wave
+  // is done; with 64 lanes every SIMD refills by itself.  Same box, interleaved (run T): a lone 2^20 proof 24.4-24.6 -> 23.8 ms
+  // device-resident, four in flight 21.8-22.0 ms either way.
+  const uint32_t acc_t = (ctx->policy.acc_threads == 128 || ctx->policy.acc_threads == 256) ? (uint32_t)ctx->policy.acc_threads : 64u;
   if (ev0) ARK_CHECK_HIP(hipEventRecord(ev0, stream));
   if constexpr (is_fp2<F>::value) {
     // G2: lane-split kernels (two lanes per segment; the whole-element kernels of round 1 lost to them by 2x and are gone)
@@ -1782,7 +1787,7 @@ static void msm_accumulate_phase(ark355_ctx* ctx, const MsmSort& s, MsmBuckets& 
                  s.counts.as<uint32_t>(), msm_slots28<P, 8>(b, p.total_buckets, 0), msm_slots28<P, 8>(b, p.total_buckets, 1),
                  b.head_key.as<uint32_t>(), msm_slots28<P, 8>(b, p.total_buckets, 2), b.tail_key.as<uint32_t>(), b.seg_len);
     } else if (fmt == 1) {
-      ARK_LAUNCH((msm_accumulate_g2l28_kernel<P>), dim3(grid_l), dim3(MSM_THREADS), 0, stream,
+      ARK_LAUNCH((msm_accumulate_g2l28_kernel<P>), dim3((2 * segs + acc_t - 1) / acc_t), dim3(acc_t), 0, stream,
                  reinterpret_cast<const Affine28G2<P, false>*>(d_bases), s.sorted_keys.as<uint32_t>(),
                  s.sorted_vals.as<uint32_t>(), s.total.as<uint32_t>(), s.offsets.as<uint32_t>(),
                  s.counts.as<uint32_t>(), msm_slots28<P, 8>(b, p.total_buckets, 0), msm_slots28<P, 8>(b, p.total_buckets, 1),
@@ -1802,7 +1807,7 @@ static void msm_accumulate_phase(ark355_ctx* ctx, const MsmSort& s, MsmBuckets& 
                b.head_key.as<uint32_t>(), msm_slots28<P, 4>(b, p.total_buckets, 2), b.tail_key.as<uint32_t>(), b.seg_len);
   } else if (fmt == 1) {
     using P = typename F::Params;
-    ARK_LAUNCH((msm_accumulate28_kernel<P>), dim3(grid_s), dim3(MSM_THREADS), 0, stream,
+    ARK_LAUNCH((msm_accumulate28_kernel<P>), dim3((segs + acc_t - 1) / acc_t), dim3(acc_t), 0, stream,
                reinterpret_cast<const Affine28U<P>*>(d_bases), s.sorted_keys.as<uint32_t>(),
                s.sorted_vals.as<uint32_t>(), s.total.as<uint32_t>(), s.offsets.as<uint32_t>(),
                s.counts.as<uint32_t>(), msm_slots28<P, 4>(b, p.total_buckets, 0), msm_slots28<P, 4>(b, p.total_buckets, 1),

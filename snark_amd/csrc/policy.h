@@ -12,7 +12,7 @@
 //                  ark355_prove_sharded, not a policy)
 //   per key load   MSM_C, MSM_C_H, PACK_ROWS, TABLE_STRIDE, HBM_BUDGET_MB, SHARD_DIST_WM
 //                  (read when a key / base set is loaded through the context: the tables are built for them)
-//   per call       MSM_SEG, MSM_TWO_LEVEL_MIN, NTT_RMAX, NTT_DIRECT_MAX, NTT_NOFUSE (A/B and test knobs of the kernels'
+//   per call       MSM_SEG, ACC_THREADS, MSM_TWO_LEVEL_MIN, NTT_RMAX, NTT_DIRECT_MAX, NTT_NOFUSE (A/B and test knobs of the kernels'
 //                  host drivers)
 #pragma once
 #include <stddef.h>
@@ -61,6 +61,8 @@ struct TunePolicy {
   int32_t shard_dist_wm = 1;      // key shards: h_query in the layout of the distributed witness map when the world size allows it
   // ---- per call
   int32_t msm_seg = 0;            // entries per accumulation lane (0: msm_seg_len)
+  int32_t acc_threads = 64;       // workgroup size of the accumulation kernels without LDS (64 / 128 / 256): one wave per workgroup lets
+                                  // every SIMD take its next wave by itself (a lone 2^20 proof: -0.6 ms against 256; in flight: equal)
   int64_t msm_two_level_min = -1; // bucket count from which the two-level reduction runs (-1: ARK_MSM_TWO_LEVEL_MIN)
   int32_t ntt_rmax = 0;           // 0: NTT_RMAX_LOG
   int32_t ntt_direct_max = -1;    // -1: NTT_DIRECT_MAX_LOG
@@ -104,6 +106,7 @@ inline const TunePolicy::Field* TunePolicy::fields(int* count) {
       ARK_POLICY_FIELD32("DWM_LOOPBACK", dwm_loopback),
       ARK_POLICY_FIELD32("RCCL_SELF", rccl_self),
       ARK_POLICY_FIELD32("MSM_SEG", msm_seg),
+      ARK_POLICY_FIELD32("ACC_THREADS", acc_threads),
       ARK_POLICY_FIELD64("MSM_TWO_LEVEL_MIN", msm_two_level_min),
       ARK_POLICY_FIELD32("NTT_RMAX", ntt_rmax),
       ARK_POLICY_FIELD32("NTT_DIRECT_MAX", ntt_direct_max),
