@@ -74,7 +74,8 @@ int32_t ark355_sizes(int32_t curve, uint32_t what[4]);
  *   per key load  MSM_C, MSM_C_H (window size of all tables / of the h_query table; 0 = planner), PACK_ROWS
  *                 (table rows bit-packed 1 / one word per limb 0 / per curve -1), TABLE_STRIDE, HBM_BUDGET_MB, SHARD_DIST_WM, RCCL_SELF (diagnostic: a rank at world size 1 exchanges with
  *                 itself) -- read when a key or base set is loaded THROUGH this context;
- *   per call      MSM_SEG, ACC_THREADS (workgroup size of the LDS-free accumulation kernels: 64 [default] / 128 / 256), MSM_TWO_LEVEL_MIN, NTT_RMAX, NTT_DIRECT_MAX, NTT_NOFUSE (A/B and test knobs).
+ *   per call      MSM_SEG, ACC_THREADS (workgroup size of the LDS-free accumulation kernels: 64 / 128 / 256; 0 [default]: 64 for a
+ *                 proof alone on one stream, else 256), MSM_TWO_LEVEL_MIN, NTT_RMAX, NTT_DIRECT_MAX, NTT_NOFUSE (A/B and test knobs).
  * ARK355_EINVAL for an unknown name.  ark355_prove_batch runs its worker contexts under the caller's policy.
  * (No counterpart in the reference: ark-groth16 has no runtime knobs; rayon's thread count is its only one.) */
 int32_t ark355_ctx_set_policy(ark355_ctx* ctx, const char* name, int64_t value);

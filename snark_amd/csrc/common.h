@@ -111,6 +111,7 @@ struct ark355_ctx {
   float acc_ms = 0.f;           // bucket-accumulation kernel time of the last MSM/prove
   uint64_t acc_launches = 0;
   uint64_t acc_points = 0;
+  int acc_threads_hint = 0;     // workgroup size the running call wants for the LDS-free accumulation kernels (policy ACC_THREADS = 0); 0: 256
   std::atomic<int> last_sched{-1};   // schedule the last prove on this context ran as (ark355::Sched); read without the lock by ark355_sched_info
   // NTT twiddle tables keyed by (curve << 8 | log_n)
   std::map<uint32_t, std::shared_ptr<ark355::NttTables>> ntt_tables;   // shared with the other contexts of the device

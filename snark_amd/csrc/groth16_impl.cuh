@@ -694,6 +694,12 @@ static void prove_run(ark355_ctx* ctx, ProverScratch& sc, const PkDev& pk, const
         {E_SORT2, &sc.sortH, &sc.bkH, false, &pk.h_query, 3},
     };
     uint64_t pts = 0;
+    // one wave per workgroup for a proof alone on one stream, 256 lanes otherwise (msm_accumulate_phase; policy ACC_THREADS)
+    struct HintGuard {
+      ark355_ctx* c;
+      ~HintGuard() { c->acc_threads_hint = 0; }
+    } hint_guard{ctx};
+    ctx->acc_threads_hint = (one_stream && !concurrent) ? 64 : 256;
     // One-stream proofs: the five accumulations first, then the G2 tails and the tails of the four G1 MSMs as ONE launch
     // per step (msm_reduce_phase_batch) -- 8 tail dispatches instead of 20, and the four latency-bound G1 chains side by
     // side instead of one after the other.  (The pipeline hides each MSM's tails under the next accumulation instead.)

@@ -1770,11 +1770,15 @@ static void msm_accumulate_phase(ark355_ctx* ctx, const MsmSort& s, MsmBuckets& 
   if (p.n == 0) return;
   const uint32_t segs = b.segs;
   const uint32_t grid_s = (segs + MSM_THREADS - 1) / MSM_THREADS;
-  // Workgroup size of the two kernels without LDS (unpacked 28-bit rows), policy ACC_THREADS: ONE wave per workgroup by default.
-  // A 256-lane workgroup needs a free register slot on four SIMDs at once and gives its slots back only when its slowest wave
-  // is done; with 64 lanes every SIMD refills by itself.  Same box, interleaved (run T): a lone 2^20 proof 24.4-24.6 -> 23.8 ms
-  // device-resident, four in flight 21.8-22.0 ms either way.
-  const uint32_t acc_t = (ctx->policy.acc_threads == 128 || ctx->policy.acc_threads == 256) ? (uint32_t)ctx->policy.acc_threads : 64u;
+  // Workgroup size of the two kernels without LDS (unpacked 28-bit rows).  A 256-lane workgroup needs a free register slot on
+  // four SIMDs at once and gives its slots back only when its slowest wave is done; with 64 lanes every SIMD refills by itself.
+  // Measured, same box, interleaved (runs T, V): a LONE one-stream 2^20 proof 24.4-24.6 -> 23.8 ms device-resident with 64; four
+  // proofs in flight 21.8-22.0 ms either way; the five-stream pipeline of a sharded proof's rank 15.9-16.0 -> 16.4-16.5 ms, i.e.
+  // worse (its feeder kernels then compete with four times as many workgroups for the dispatcher).  So the CALL says what it
+  // wants (ark355_ctx::acc_threads_hint: prove_run asks for 64 for a proof alone on one stream) and policy ACC_THREADS = 64 / 128 /
+  // 256 overrides it (0, the default: the hint, else 256).
+  const int acc_want = ctx->policy.acc_threads ? ctx->policy.acc_threads : ctx->acc_threads_hint;
+  const uint32_t acc_t = (acc_want == 64 || acc_want == 128) ? (uint32_t)acc_want : MSM_THREADS;
   if (ev0) ARK_CHECK_HIP(hipEventRecord(ev0, stream));
   if constexpr (is_fp2<F>::value) {
     // G2: lane-split kernels (two lanes per segment; the whole-element kernels of round 1 lost to them by 2x and are gone)

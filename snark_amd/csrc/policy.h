@@ -61,8 +61,8 @@ struct TunePolicy {
   int32_t shard_dist_wm = 1;      // key shards: h_query in the layout of the distributed witness map when the world size allows it
   // ---- per call
   int32_t msm_seg = 0;            // entries per accumulation lane (0: msm_seg_len)
-  int32_t acc_threads = 64;       // workgroup size of the accumulation kernels without LDS (64 / 128 / 256): one wave per workgroup lets
-                                  // every SIMD take its next wave by itself (a lone 2^20 proof: -0.6 ms against 256; in flight: equal)
+  int32_t acc_threads = 0;        // workgroup size of the accumulation kernels without LDS: 64 / 128 / 256; 0: the call's own choice (a proof alone
+                                  // on one stream: 64, everything else: 256; msm_accumulate_phase)
   int64_t msm_two_level_min = -1; // bucket count from which the two-level reduction runs (-1: ARK_MSM_TWO_LEVEL_MIN)
   int32_t ntt_rmax = 0;           // 0: NTT_RMAX_LOG
   int32_t ntt_direct_max = -1;    // -1: NTT_DIRECT_MAX_LOG
