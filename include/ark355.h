@@ -67,7 +67,7 @@ int32_t ark355_sizes(int32_t curve, uint32_t what[4]);
  * (A/B measurements inside one process).  Names (value = integer):
  *   per proof     SCHED (-1 measured choice [default], 0 one stream, 1 five-stream pipeline, 2 pipeline + epilogue stream
  *                 synchronises, 3 one stream + wait inside the HIP runtime), SCHED_EXPLORE (samples per schedule before the
- *                 measured choice latches; 0 = static defaults), WAIT_SPIN, WAIT_ADAPT, STREAM_PRIO, DEVICE_FINALIZE, BATCH_TAILS,
+ *                 measured choice latches; 0 = static defaults), WAIT_SPIN, WAIT_ADAPT, STREAM_PRIO, BATCH_TAILS,
  *                 SIDE_G2_TAILS, SIDE_WM (a proof alone on the device: G2 tails / witness map on side streams), SIDE_H_TAILS (pipeline:
  *                 the last MSM's tails on the sort stream),
  *                 TRACE_HOST; legacy spellings SERIAL (1 -> SCHED 0, 0 -> SCHED 1) and EPILOGUE_SYNC (on a pipeline: 1 -> 2);

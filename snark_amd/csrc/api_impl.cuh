@@ -169,23 +169,29 @@ struct Api {
   static void msm_generic(ark355_ctx* ctx, GenericScratch& g, const Affine<F>* d_bases, const void* d_scalars,
                           uint64_t n, int mont, uint8_t* out, bool want_affine, const PrecompTable* tab = nullptr) {
     hipStream_t st = ctx->stream;
-    g.c.ensure(sizeof(XYZZ<F>) + sizeof(Affine<F>));
-    XYZZ<F>* d_res = g.c.as<XYZZ<F>>();
     hipEvent_t e0, e1;
     ARK_CHECK_HIP(hipEventCreate(&e0));
     ARK_CHECK_HIP(hipEventCreate(&e1));
     try {
+      const int fmt = tab != nullptr ? tab->fmt() : 0;
       msm_sort<Fr>(ctx, g.sort, d_scalars, n, mont, st, tab);
-      msm_buckets<F>(ctx, g.sort, g.bk, d_bases, d_res, 0, st, n ? e0 : nullptr, n ? e1 : nullptr,
-                     tab != nullptr ? tab->fmt() : 0);
-      // the one inversion of the normalisation runs in the library's host-compiled field code (tens of microseconds);
-      // a single device lane took ~1 ms for it, a third of a stand-alone 2^16-term MSM
-      XYZZ<F> h_res;
-      ARK_CHECK_HIP(hipMemcpyAsync(want_affine ? (void*)&h_res : (void*)out, d_res, sizeof(XYZZ<F>), hipMemcpyDeviceToHost, st));
+      // what the tails leave on the device: one sum (32-bit tails) or c partial sums per bucket set (28-bit tails)
+      const uint32_t parts = msm_parts_count(g.sort.plan, fmt);
+      g.c.ensure((size_t)parts * sizeof(XYZZ<F>));
+      XYZZ<F>* d_res = g.c.as<XYZZ<F>>();
+      msm_buckets<F>(ctx, g.sort, g.bk, d_bases, d_res, 0, st, n ? e0 : nullptr, n ? e1 : nullptr, fmt);
+      // The last 2c group operations of the bucket reduction (Horner over the bit sums) and the one inversion of the
+      // normalisation run in the library's host-compiled field code: ~1 us per group operation against ~12 us for a device
+      // lane, tens of microseconds for the inversion against ~1 ms.
+      std::vector<XYZZ<F>> h_parts(parts);
+      ARK_CHECK_HIP(hipMemcpyAsync(h_parts.data(), d_res, (size_t)parts * sizeof(XYZZ<F>), hipMemcpyDeviceToHost, st));
       ARK_CHECK_HIP(hipStreamSynchronize(st));
+      const XYZZ<F> h_res = msm_parts_finish<F>(h_parts.data(), g.sort.plan, fmt);
       if (want_affine) {
         const Affine<F> a = xyzz_to_affine(h_res);
         memcpy(out, &a, sizeof(a));
+      } else {
+        memcpy(out, &h_res, sizeof(h_res));
       }
       float ms = 0;
       if (n) (void)hipEventElapsedTime(&ms, e0, e1);

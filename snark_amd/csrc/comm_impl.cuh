@@ -19,6 +19,7 @@
 #pragma once
 #include "common.h"
 #include "curve.cuh"
+#include "msm_impl.cuh"
 #if defined(ARK_EMUL)
 #include "rccl_emul.h"
 #else
@@ -44,12 +45,29 @@ struct CommDev {
   }
 };
 
-// dst[i] += src[i]
+// dst[i] += src[i] over canonical XYZZ points (buckets of the 32-bit accumulation kernels)
 template <class F>
 __global__ void __launch_bounds__(256)
 xyzz_add_inplace_kernel(XYZZ<F>* __restrict__ dst, const XYZZ<F>* __restrict__ src, uint32_t count) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < count) dst[i] = xyzz_add(dst[i], src[i]);
+}
+// ... and over 28-bit bucket slots (every MSM over resident tables; a lane pair per G2 slot): tails28_impl.cuh
+template <class P, bool G2>
+__global__ void __launch_bounds__(256, ARK_TAIL28_WAVES)
+slot28_add_inplace_kernel(void* __restrict__ dst_, const void* __restrict__ src_, uint32_t count) {
+  using T = Tail28<P, G2>;
+  using Slot = typename T::Slot;
+  const uint32_t i = (blockIdx.x * blockDim.x + threadIdx.x) / T::LPI;
+  if (i >= count) return;
+  Slot* dst = static_cast<Slot*>(dst_);
+  const Slot* src = static_cast<const Slot*>(src_);
+  Acc28<P> a, b;
+  bool ae, be;
+  T::load(&dst[i], a, ae);
+  T::load(&src[i], b, be);
+  T::add(a, ae, b, be);
+  T::store(&dst[i], a, ae);
 }
 
 static inline void ring_chunk(uint32_t total, int world, int c, uint32_t* lo, uint32_t* n) {
@@ -58,27 +76,42 @@ static inline void ring_chunk(uint32_t total, int world, int c, uint32_t* lo, ui
   *n = (uint32_t)(b - a);
 }
 
-// Ring reduce-scatter of `total` XYZZ buckets; afterwards rank g's range (g+1) mod G holds the sum over all ranks and
-// every other range is zeroed (= infinity), so the ordinary bucket reduction over the whole array yields this rank's
-// share of sum_b (b+1) B_b.
+// Ring reduce-scatter of `total` buckets (fmt: the slot format of the bucket array, MsmBuckets::fmt -- canonical XYZZ or
+// 28-bit slots); afterwards rank g's range (g+1) mod G holds the sum over all ranks and every other range is zeroed
+// (= infinity in both formats), so the ordinary bucket reduction over the whole array yields this rank's share of
+// sum_b (b+1) B_b.
 // self_exchange (policy RCCL_SELF, world size 1 only): one ring step of the rank with itself -- the lower half of the
 // array travels through ncclSend / ncclRecv (peer = own rank, grouped) into the staging buffer, is cleared in place and
 // comes back through the same EC-add kernel: 0 + x = x, the array is unchanged.
 template <class F>
-static void ring_reduce_scatter_buckets(CommDev& cm, XYZZ<F>* buckets, uint32_t total, hipStream_t stream, bool self_exchange = false) {
+static void ring_reduce_scatter_buckets(CommDev& cm, void* buckets_, uint32_t total, int fmt, hipStream_t stream, bool self_exchange = false) {
+  using P = typename Tail28Of<F>::P;
+  constexpr bool G2 = Tail28Of<F>::G2;
+  const size_t slot = msm_slot_bytes<F>(fmt);
+  uint8_t* buckets = static_cast<uint8_t*>(buckets_);
+  auto add_inplace = [&](uint8_t* dst, const uint8_t* src, uint32_t n) {
+    if (fmt) {
+      constexpr uint32_t lpi = Tail28<P, G2>::LPI;
+      ARK_LAUNCH((slot28_add_inplace_kernel<P, G2>), dim3((uint32_t)(((uint64_t)n * lpi + 255) / 256)), dim3(256), 0, stream, (void*)dst,
+                 (const void*)src, n);
+    } else {
+      ARK_LAUNCH((xyzz_add_inplace_kernel<F>), dim3((n + 255) / 256), dim3(256), 0, stream, reinterpret_cast<XYZZ<F>*>(dst),
+                 reinterpret_cast<const XYZZ<F>*>(src), n);
+    }
+    ARK_CHECK_LAUNCH();
+  };
   const int G = cm.world, g = cm.rank;
   if (G == 1) {
     const uint32_t half = total / 2;
     if (!self_exchange || half == 0) return;
-    cm.ring_tmp.ensure((size_t)half * sizeof(XYZZ<F>));
-    XYZZ<F>* tmp = cm.ring_tmp.as<XYZZ<F>>();
+    cm.ring_tmp.ensure((size_t)half * slot);
+    uint8_t* tmp = cm.ring_tmp.as<uint8_t>();
     ARK_CHECK_NCCL(ncclGroupStart());
-    ARK_CHECK_NCCL(ncclSend(buckets, (size_t)half * sizeof(XYZZ<F>), ncclUint8, g, cm.comm, stream));
-    ARK_CHECK_NCCL(ncclRecv(tmp, (size_t)half * sizeof(XYZZ<F>), ncclUint8, g, cm.comm, stream));
+    ARK_CHECK_NCCL(ncclSend(buckets, (size_t)half * slot, ncclUint8, g, cm.comm, stream));
+    ARK_CHECK_NCCL(ncclRecv(tmp, (size_t)half * slot, ncclUint8, g, cm.comm, stream));
     ARK_CHECK_NCCL(ncclGroupEnd());
-    ARK_CHECK_HIP(hipMemsetAsync(buckets, 0, (size_t)half * sizeof(XYZZ<F>), stream));
-    ARK_LAUNCH((xyzz_add_inplace_kernel<F>), dim3((half + 255) / 256), dim3(256), 0, stream, buckets, (const XYZZ<F>*)tmp, half);
-    ARK_CHECK_LAUNCH();
+    ARK_CHECK_HIP(hipMemsetAsync(buckets, 0, (size_t)half * slot, stream));
+    add_inplace(buckets, tmp, half);
     return;
   }
   uint32_t max_n = 0;
@@ -87,8 +120,8 @@ static void ring_reduce_scatter_buckets(CommDev& cm, XYZZ<F>* buckets, uint32_t 
     ring_chunk(total, G, c, &lo, &n);
     if (n > max_n) max_n = n;
   }
-  cm.ring_tmp.ensure((size_t)max_n * sizeof(XYZZ<F>));
-  XYZZ<F>* tmp = cm.ring_tmp.as<XYZZ<F>>();
+  cm.ring_tmp.ensure((size_t)max_n * slot);
+  uint8_t* tmp = cm.ring_tmp.as<uint8_t>();
   const int right = (g + 1) % G, left = (g + G - 1) % G;
   for (int t = 0; t < G - 1; t++) {
     const int cs = ((g - t) % G + G) % G, cr = ((g - t - 1) % G + G) % G;
@@ -96,21 +129,17 @@ static void ring_reduce_scatter_buckets(CommDev& cm, XYZZ<F>* buckets, uint32_t 
     ring_chunk(total, G, cs, &slo, &sn);
     ring_chunk(total, G, cr, &rlo, &rn);
     ARK_CHECK_NCCL(ncclGroupStart());
-    ARK_CHECK_NCCL(ncclSend(buckets + slo, (size_t)sn * sizeof(XYZZ<F>), ncclUint8, right, cm.comm, stream));
-    ARK_CHECK_NCCL(ncclRecv(tmp, (size_t)rn * sizeof(XYZZ<F>), ncclUint8, left, cm.comm, stream));
+    ARK_CHECK_NCCL(ncclSend(buckets + (size_t)slo * slot, (size_t)sn * slot, ncclUint8, right, cm.comm, stream));
+    ARK_CHECK_NCCL(ncclRecv(tmp, (size_t)rn * slot, ncclUint8, left, cm.comm, stream));
     ARK_CHECK_NCCL(ncclGroupEnd());
-    if (rn) {
-      ARK_LAUNCH((xyzz_add_inplace_kernel<F>), dim3((rn + 255) / 256), dim3(256), 0, stream, buckets + rlo,
-                 (const XYZZ<F>*)tmp, rn);
-      ARK_CHECK_LAUNCH();
-    }
+    if (rn) add_inplace(buckets + (size_t)rlo * slot, tmp, rn);
   }
   const int own = (g + 1) % G;
   uint32_t olo, on;
   ring_chunk(total, G, own, &olo, &on);
-  if (olo) ARK_CHECK_HIP(hipMemsetAsync(buckets, 0, (size_t)olo * sizeof(XYZZ<F>), stream));
+  if (olo) ARK_CHECK_HIP(hipMemsetAsync(buckets, 0, (size_t)olo * slot, stream));
   if (olo + on < total)
-    ARK_CHECK_HIP(hipMemsetAsync(buckets + olo + on, 0, (size_t)(total - olo - on) * sizeof(XYZZ<F>), stream));
+    ARK_CHECK_HIP(hipMemsetAsync(buckets + (size_t)(olo + on) * slot, 0, (size_t)(total - olo - on) * slot, stream));
 }
 
 }  // namespace ark355

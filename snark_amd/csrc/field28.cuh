@@ -26,6 +26,9 @@ namespace ark355 {
 // emulator builds check every 64-bit column accumulator against a 128-bit shadow and every lazy limb operation
 // against wrap-around: the bounds analysis written next to the formulas is enforced, not assumed
 #define ARK_F28_CHECK 1
+#include <stdio.h>
+#include <stdlib.h>
+#define ARK_F28_TRAP() (fprintf(stderr, "field28.cuh:%d: limb / column bound violated\n", __LINE__), abort())
 #endif
 
 template <class P>
@@ -126,7 +129,7 @@ struct Fp28 {
 #pragma unroll
     for (int i = 0; i < N; i++) {
 #if ARK_F28_CHECK
-      if ((uint64_t)a.l[i] + b.l[i] > 0xFFFFFFFFull) __builtin_trap();
+      if ((uint64_t)a.l[i] + b.l[i] > 0xFFFFFFFFull) ARK_F28_TRAP();
 #endif
       r.l[i] = a.l[i] + b.l[i];
     }
@@ -139,7 +142,7 @@ struct Fp28 {
 #pragma unroll
     for (int i = 0; i < N; i++) {
 #if ARK_F28_CHECK
-      if (bias<K, BETA>(i) < b.l[i] || (uint64_t)a.l[i] + bias<K, BETA>(i) - b.l[i] > 0xFFFFFFFFull) __builtin_trap();
+      if (bias<K, BETA>(i) < b.l[i] || (uint64_t)a.l[i] + bias<K, BETA>(i) - b.l[i] > 0xFFFFFFFFull) ARK_F28_TRAP();
 #endif
       r.l[i] = a.l[i] + (bias<K, BETA>(i) - b.l[i]);
     }
@@ -152,7 +155,7 @@ struct Fp28 {
 #pragma unroll
     for (int i = 0; i < N; i++) {
 #if ARK_F28_CHECK
-      if (bias<K, BETA>(i) < b.l[i]) __builtin_trap();      // a limb would wrap: the bias class is too small
+      if (bias<K, BETA>(i) < b.l[i]) ARK_F28_TRAP();      // a limb would wrap: the bias class is too small
 #endif
       r.l[i] = bias<K, BETA>(i) - b.l[i];
     }
@@ -188,7 +191,7 @@ struct Fp28 {
       acc += (uint64_t)x * y;
 #if ARK_F28_CHECK
       shadow += (unsigned __int128)x * y;
-      if ((shadow >> 64) != 0) __builtin_trap();       // a column overflowed: the limb-bound analysis is wrong
+      if ((shadow >> 64) != 0) ARK_F28_TRAP();       // a column overflowed: the limb-bound analysis is wrong
 #endif
     }
     ARK_HD void shift() {
@@ -291,7 +294,7 @@ struct Fp28 {
     // the column is complete: its true value must be a non-negative 64-bit number
     ARK_HD void close() const {
 #if ARK_F28_CHECK
-      if (shadow < 0 || (shadow >> 64) != 0 || (uint64_t)shadow != acc) __builtin_trap();
+      if (shadow < 0 || (shadow >> 64) != 0 || (uint64_t)shadow != acc) ARK_F28_TRAP();
 #endif
     }
     ARK_HD void shift() {
@@ -381,7 +384,7 @@ struct Fp28 {
         dx[j][i] = (int32_t)(x[j]->l[H + i] - x[j]->l[i]);       // limbs < 2^31: the difference fits
         dy[j][i] = (int32_t)(y[j]->l[i] - y[j]->l[H + i]);
 #if ARK_F28_CHECK
-        if ((x[j]->l[H + i] | x[j]->l[i] | y[j]->l[i] | y[j]->l[H + i]) >> 31) __builtin_trap();
+        if ((x[j]->l[H + i] | x[j]->l[i] | y[j]->l[i] | y[j]->l[H + i]) >> 31) ARK_F28_TRAP();
 #endif
       }
     }

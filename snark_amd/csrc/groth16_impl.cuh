@@ -16,9 +16,10 @@
 //     C = s*A + r*B1 + L' + H.
 // The only remaining sequential work is s*A and r*B1 (two 255-bit double-and-add chains) and three affine
 // normalisations: O(1) work, independent of the circuit size.  A single GPU lane needs ~25 ms for it
-// (measured, round 1), the host ~1 ms, so by default the five XYZZ results (1 KiB) are copied back and the
-// library's own host-compiled field code finishes the proof; ARK355_DEVICE_FINALIZE=1 keeps it on the device
-// (groth16_finalize_kernel) and must give the same bytes.
+// (measured, round 1), the host ~1 ms, so the MSM results are copied back and the library's own host-compiled field code
+// finishes the proof (the device flavour of rounds 1-5, groth16_finalize_kernel, is gone).  Since round 6 the same host
+// code also does the last 2c group operations of every bucket reduction: the tails leave c partial sums per MSM
+// (tails28_impl.cuh), ~15 KB per proof, and msm_parts_finish is a Horner pass over them (~50 us per MSM).
 #pragma once
 #include <atomic>
 #include <chrono>
@@ -239,56 +240,6 @@ struct ProverScratch {
   }
 };
 
-// out layout (device): Affine<Fq> A | Affine<Fq2> B | Affine<Fq> C
-template <class Curve>
-__global__ void __launch_bounds__(192)
-groth16_finalize_kernel(const XYZZ<typename Curve::Fq>* __restrict__ g1res,   // A, B1, L', H
-                        const XYZZ<typename Curve::Fq2>* __restrict__ g2res,  // B2
-                        const typename Curve::Fr* __restrict__ rs_canon,      // r, s canonical
-                        unsigned char* __restrict__ out) {
-  using Fq = typename Curve::Fq;
-  using Fq2 = typename Curve::Fq2;
-  using Fr = typename Curve::Fr;
-  __shared__ uint32_t xch[2 * (sizeof(XYZZ<Fq>) / 4)];
-  constexpr int WORDS = sizeof(XYZZ<Fq>) / 4;
-  const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  Affine<Fq>* outA = reinterpret_cast<Affine<Fq>*>(out);
-  Affine<Fq2>* outB = reinterpret_cast<Affine<Fq2>*>(out + sizeof(Affine<Fq>));
-  Affine<Fq>* outC = reinterpret_cast<Affine<Fq>*>(out + sizeof(Affine<Fq>) + sizeof(Affine<Fq2>));
-  if (lane == 0) {
-    if (wave == 0) {
-      // s * A
-      Fr s = rs_canon[1];
-      XYZZ<Fq> sa = xyzz_mul_scalar(g1res[0], s.l, Fr::N);
-      const uint32_t* src = reinterpret_cast<const uint32_t*>(&sa);
-      for (int i = 0; i < WORDS; i++) xch[i] = src[i];
-    } else if (wave == 1) {
-      // r * B1
-      Fr r = rs_canon[0];
-      XYZZ<Fq> rb = xyzz_mul_scalar(g1res[1], r.l, Fr::N);
-      const uint32_t* src = reinterpret_cast<const uint32_t*>(&rb);
-      for (int i = 0; i < WORDS; i++) xch[WORDS + i] = src[i];
-    } else {
-      *outA = xyzz_to_affine(g1res[0]);
-      *outB = xyzz_to_affine(g2res[0]);
-    }
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    XYZZ<Fq> sa, rb;
-    uint32_t* d0 = reinterpret_cast<uint32_t*>(&sa);
-    uint32_t* d1 = reinterpret_cast<uint32_t*>(&rb);
-    for (int i = 0; i < WORDS; i++) {
-      d0[i] = xch[i];
-      d1[i] = xch[WORDS + i];
-    }
-    XYZZ<Fq> c = xyzz_add(sa, rb);
-    c = xyzz_add(c, g1res[2]);
-    c = xyzz_add(c, g1res[3]);
-    *outC = xyzz_to_affine(c);
-  }
-}
-
 // host tail: C = s*A + r*B1 + L' + H ; three affine normalisations (O(1) work, library's own host field code)
 template <class Curve>
 static void finalize_host(const XYZZ<typename Curve::Fq> g1[4], const XYZZ<typename Curve::Fq2>& g2,
@@ -311,6 +262,34 @@ static void finalize_host(const XYZZ<typename Curve::Fq> g1[4], const XYZZ<typen
   memcpy(out->b, &pb, sizeof(pb));
   memcpy(out->c, &pc, sizeof(pc));
 }
+
+// What the five MSMs of a proof leave on the device: per MSM msm_parts_count() partial sums, A, B1, L', H (G1) then B2 (G2).
+template <class Curve>
+struct ProofParts {
+  using Fq = typename Curve::Fq;
+  using Fq2 = typename Curve::Fq2;
+  MsmPlan plan[5];          // A, B1, L', H, B2
+  int fmt[5] = {0, 0, 0, 0, 0};
+  uint32_t count[5] = {0, 0, 0, 0, 0};
+  size_t off[5] = {0, 0, 0, 0, 0};          // byte offsets in the results buffer
+  size_t bytes = 0;
+  void layout() {
+    bytes = 0;
+    for (int i = 0; i < 5; i++) {
+      count[i] = msm_parts_count(plan[i], fmt[i]);
+      off[i] = bytes;
+      bytes += (size_t)count[i] * (i < 4 ? sizeof(XYZZ<Fq>) : sizeof(XYZZ<Fq2>));
+    }
+  }
+  // host: the five sums from a copy of the results buffer (the four G1 Horner passes beside the G2 one)
+  void finish(const uint8_t* land, XYZZ<Fq> g1[4], XYZZ<Fq2>& g2) const {
+    auto f_g2 = std::async(std::launch::async, [&] {
+      return msm_parts_finish<Fq2>(reinterpret_cast<const XYZZ<Fq2>*>(land + off[4]), plan[4], fmt[4]);
+    });
+    for (int i = 0; i < 4; i++) g1[i] = msm_parts_finish<Fq>(reinterpret_cast<const XYZZ<Fq>*>(land + off[i]), plan[i], fmt[i]);
+    g2 = f_g2.get();
+  }
+};
 
 // sum `count` shard partials (each: 4 G1 XYZZ + 1 G2 XYZZ, as prove_run hands back) and finish the proof
 template <class Curve>
@@ -584,10 +563,7 @@ static void prove_run(ark355_ctx* ctx, ProverScratch& sc, const PkDev& pk, const
     Fr rs_c[2] = {rc, scn};
     sc.zx.ensure((m + 4) * sizeof(Fr));
     sc.rs.ensure(2 * sizeof(Fr));
-    sc.results.ensure(4 * sizeof(XYZZ<Fq>) + sizeof(XYZZ<Fq2>));
     sc.proof.ensure(2 * sizeof(Affine<Fq>) + sizeof(Affine<Fq2>));
-    XYZZ<Fq>* g1res = sc.results.as<XYZZ<Fq>>();
-    XYZZ<Fq2>* g2res = reinterpret_cast<XYZZ<Fq2>*>(g1res + 4);
 
     ARK_CHECK_HIP(hipEventRecord(ev[E_START], sM));
     const auto zkind = z_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
@@ -666,6 +642,22 @@ static void prove_run(ark355_ctx* ctx, ProverScratch& sc, const PkDev& pk, const
       msm_prepare_phase<Fq>(pol, sc.sortH, sc.bkH, sS, pk.h_query.fmt(), &fb);
       fb.flush();
     }
+    // what the five MSMs leave for the host (c partial sums per bucket set and MSM: tails28_impl.cuh), A, B1, L', H, then B2
+    ProofParts<Curve> parts;
+    {
+      const MsmSort* so[5] = {&sc.sortZ, &sc.sortZ, &sc.sortZ, &sc.sortH, &sc.sortZ};
+      const PrecompTable* tb[5] = {&pk.a_ext, &pk.b1_ext, &pk.l_ext, &pk.h_query, &pk.b2_ext};
+      for (int i = 0; i < 5; i++) {
+        parts.plan[i] = so[i]->plan;
+        parts.fmt[i] = tb[i]->fmt();
+      }
+      parts.layout();
+    }
+    sc.results.ensure(parts.bytes);
+    uint8_t* const res_base = sc.results.as<uint8_t>();
+    XYZZ<Fq>* const g1res[4] = {reinterpret_cast<XYZZ<Fq>*>(res_base + parts.off[0]), reinterpret_cast<XYZZ<Fq>*>(res_base + parts.off[1]),
+                                reinterpret_cast<XYZZ<Fq>*>(res_base + parts.off[2]), reinterpret_cast<XYZZ<Fq>*>(res_base + parts.off[3])};
+    XYZZ<Fq2>* const g2res = reinterpret_cast<XYZZ<Fq2>*>(res_base + parts.off[4]);
     if (sSH != sS) ARK_CHECK_HIP(hipEventRecord(ev[E_FILL], sS));      // (the sort of h on another stream must see its counters cleared)
     ARK_CHECK_HIP(hipStreamWaitEvent(sS, ev[E_ZS], 0));
     msm_sort_run<Fr>(ctx, sc.sortZ, (const uint8_t*)sc.zx.p + pk.z_lo * sizeof(Fr), pk.z_cnt, 1, sS, &pk.a_ext);
@@ -729,18 +721,19 @@ static void prove_run(ark355_ctx* ctx, ProverScratch& sc, const PkDev& pk, const
       ARK_CHECK_HIP(hipStreamWaitEvent(sT, ev[E_ACC_DONE0 + j], 0));
       if (ring) {
         // bucket-level exchange: the ranks run their MSMs in the same order, so the ring steps pair up
+        const int bfmt = jb.bk->fmt;
         if (jb.g2)
-          msm_reduce_phase<Fq2>(ctx, *red_sort, *jb.bk, g2res, 0, sT, [&](XYZZ<Fq2>* bk, uint32_t nb, hipStream_t st) {
-            ring_reduce_scatter_buckets<Fq2>(*cm, bk, nb, st, pol.rccl_self != 0);
+          msm_reduce_phase<Fq2>(ctx, *red_sort, *jb.bk, g2res, 0, sT, [&](void* bk, uint32_t nb, hipStream_t st) {
+            ring_reduce_scatter_buckets<Fq2>(*cm, bk, nb, bfmt, st, pol.rccl_self != 0);
           });
         else
-          msm_reduce_phase<Fq>(ctx, *red_sort, *jb.bk, g1res + jb.res, 0, sT, [&](XYZZ<Fq>* bk, uint32_t nb, hipStream_t st) {
-            ring_reduce_scatter_buckets<Fq>(*cm, bk, nb, st, pol.rccl_self != 0);
+          msm_reduce_phase<Fq>(ctx, *red_sort, *jb.bk, g1res[jb.res], 0, sT, [&](void* bk, uint32_t nb, hipStream_t st) {
+            ring_reduce_scatter_buckets<Fq>(*cm, bk, nb, bfmt, st, pol.rccl_self != 0);
           });
       } else if (jb.g2) {
         msm_reduce_phase<Fq2>(ctx, *red_sort, *jb.bk, g2res, 0, sT);
       } else {
-        msm_reduce_phase<Fq>(ctx, *red_sort, *jb.bk, g1res + jb.res, 0, sT);
+        msm_reduce_phase<Fq>(ctx, *red_sort, *jb.bk, g1res[jb.res], 0, sT);
       }
       if (side_tail) {
         h_tails_aside = true;
@@ -765,7 +758,7 @@ static void prove_run(ark355_ctx* ctx, ProverScratch& sc, const PkDev& pk, const
       }
       const MsmSort* sorts[4] = {&sc.sortZ, &sc.sortZ, &sc.sortZ, &sc.sortH};
       MsmBuckets* bks[4] = {&sc.bkA, &sc.bkB1, &sc.bkL, &sc.bkH};
-      XYZZ<Fq>* outs[4] = {g1res + 0, g1res + 1, g1res + 2, g1res + 3};
+      XYZZ<Fq>* outs[4] = {g1res[0], g1res[1], g1res[2], g1res[3]};
       const bool batched = msm_reduce_phase_batch<Fq>(ctx, 4, sorts, bks, outs, sR);
       if (!batched)
         for (int i = 0; i < 4; i++) msm_reduce_phase<Fq>(ctx, *sorts[i], *bks[i], outs[i], 0, sR);
@@ -774,54 +767,45 @@ static void prove_run(ark355_ctx* ctx, ProverScratch& sc, const PkDev& pk, const
     }
 
     if (out) memset(out, 0, sizeof(*out));
+    // The proof's last copy: the partial sums of the five MSMs (~15 KB at c = 17) into page-locked memory; the host then runs the
+    // Horner pass of every bucket reduction and the O(1) tail (ProofParts::finish, finalize_host).
+    const size_t psz = 4 * sizeof(XYZZ<Fq>) + sizeof(XYZZ<Fq2>);
+    uint8_t* land = static_cast<uint8_t*>(sc.pinned(parts.bytes + (cm ? psz * (size_t)(cm->world + 1) : 0)));
+    ARK_CHECK_HIP(hipMemcpyAsync(land, res_base, parts.bytes, hipMemcpyDeviceToHost, sR));
+    ARK_CHECK_HIP(hipEventRecord(ev[E_END], sR));
+    t_launched = since(t_enter);
+    bool overslept = false;
+    const bool plain = !cm && !partials_out;
+    wait_event_polite(ev[E_END], spin, (plain && epi_sleep_ok(pk.N)) ? sc.drain_hint(pol.wait_adapt != 0, shape) : 0.0, &overslept);
+    t_synced = since(t_enter);
+    if (plain) sc.drain_record(shape, t_synced - t_launched, overslept);
+    XYZZ<Fq> h1[4];
+    XYZZ<Fq2> h2;
+    parts.finish(land, h1, h2);
     if (cm) {
-      // sharded prove: all-gather of the five XYZZ partial sums (A, B1, L', H in G1, then B2 in G2) straight from HBM
-      // on the reduction stream, then the O(world) additions and the O(1) tail on the host -- on every rank
-      const size_t psz = 4 * sizeof(XYZZ<Fq>) + sizeof(XYZZ<Fq2>);
-      cm->gather.ensure(psz * (size_t)cm->world);
-      ARK_CHECK_NCCL(ncclAllGather(g1res, cm->gather.p, psz, ncclUint8, cm->comm, sR));
+      // sharded prove: this rank's five XYZZ sums (A, B1, L', H in G1, then B2 in G2; 960 B for BLS12-381) go back to HBM, ONE
+      // ncclAllGather on the reduction stream, then the O(world) additions and the O(1) tail on the host -- on every rank
+      uint8_t* mine = land + parts.bytes;
+      memcpy(mine, h1, sizeof(h1));
+      memcpy(mine + sizeof(h1), &h2, sizeof(h2));
+      cm->gather.ensure(psz * (size_t)(cm->world + 1));
+      uint8_t* d_mine = cm->gather.as<uint8_t>() + psz * (size_t)cm->world;
+      ARK_CHECK_HIP(hipMemcpyAsync(d_mine, mine, psz, hipMemcpyHostToDevice, sR));
+      ARK_CHECK_NCCL(ncclAllGather(d_mine, cm->gather.p, psz, ncclUint8, cm->comm, sR));
       const size_t all_bytes = psz * (size_t)cm->world;
-      uint8_t* all = static_cast<uint8_t*>(sc.pinned(all_bytes));
+      uint8_t* all = mine + psz;
       ARK_CHECK_HIP(hipMemcpyAsync(all, cm->gather.p, all_bytes, hipMemcpyDeviceToHost, sR));
       ARK_CHECK_HIP(hipEventRecord(ev[E_END], sR));
       wait_event_polite(ev[E_END], spin);
       combine_partials_host<Curve>(all, (uint64_t)cm->world, r_canon, s_canon, out);
     } else if (partials_out) {
       // sharded prove: hand back the five XYZZ partial sums (A, B1, L', H in G1, then B2 in G2)
-      const size_t psz = 4 * sizeof(XYZZ<Fq>) + sizeof(XYZZ<Fq2>);
-      void* land = sc.pinned(psz);
-      ARK_CHECK_HIP(hipMemcpyAsync(land, g1res, psz, hipMemcpyDeviceToHost, sR));
-      ARK_CHECK_HIP(hipEventRecord(ev[E_END], sR));
-      wait_event_polite(ev[E_END], spin);
-      memcpy(partials_out, land, psz);
-    } else if (pol.device_finalize) {
-      ARK_LAUNCH((groth16_finalize_kernel<Curve>), dim3(1), dim3(192), 0, sR, (const XYZZ<Fq>*)g1res,
-                 (const XYZZ<Fq2>*)g2res, sc.rs.as<Fr>(), sc.proof.as<unsigned char>());
-      ARK_CHECK_LAUNCH();
-      const size_t fsz = 2 * sizeof(Affine<Fq>) + sizeof(Affine<Fq2>);
-      uint8_t* land = static_cast<uint8_t*>(sc.pinned(fsz));
-      ARK_CHECK_HIP(hipMemcpyAsync(land, sc.proof.p, fsz, hipMemcpyDeviceToHost, sR));
-      ARK_CHECK_HIP(hipEventRecord(ev[E_END], sR));
-      wait_event_polite(ev[E_END], spin);
-      memcpy(out->a, land, sizeof(Affine<Fq>));
-      memcpy(out->b, land + sizeof(Affine<Fq>), sizeof(Affine<Fq2>));
-      memcpy(out->c, land + sizeof(Affine<Fq>) + sizeof(Affine<Fq2>), sizeof(Affine<Fq>));
+      memcpy(partials_out, h1, sizeof(h1));
+      memcpy(partials_out + sizeof(h1), &h2, sizeof(h2));
     } else {
-      XYZZ<Fq> h1[4];
-      XYZZ<Fq2> h2;
-      uint8_t* land = static_cast<uint8_t*>(sc.pinned(sizeof(h1) + sizeof(h2)));       // g1res and g2res are adjacent
-      ARK_CHECK_HIP(hipMemcpyAsync(land, g1res, sizeof(h1) + sizeof(h2), hipMemcpyDeviceToHost, sR));
-      ARK_CHECK_HIP(hipEventRecord(ev[E_END], sR));
-      t_launched = since(t_enter);
-      bool overslept = false;
-      wait_event_polite(ev[E_END], spin, epi_sleep_ok(pk.N) ? sc.drain_hint(pol.wait_adapt != 0, shape) : 0.0, &overslept);
-      t_synced = since(t_enter);
-      sc.drain_record(shape, t_synced - t_launched, overslept);
-      memcpy(h1, land, sizeof(h1));
-      memcpy(&h2, land + sizeof(h1), sizeof(h2));
       finalize_host<Curve>(h1, h2, rc, scn, out);
-      t_tail = since(t_enter);
     }
+    t_tail = since(t_enter);
     // Every stream has drained into sR through the event chain: E_END completes only after the last event of sW (E_H),
     // sS (E_SORT2) and the accumulation stream (E_ACC_DONE0 + 4); nothing else is queued on them.  The prover used to call
     // hipStreamSynchronize on the feeder streams here.  That is NOT free: HIP streams share a handful of hardware queues, and

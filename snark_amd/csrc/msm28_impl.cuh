@@ -67,16 +67,96 @@ struct alignas(16) Affine28U {
   uint32_t w[WORDS];
 };
 
+#define ARK_KEY_NONE 0xFFFFFFFFu
+
 template <class P>
 struct Acc28 {
   Fp28<P> x, y, zz, zzz;
 };
 
-#define ARK_KEY_NONE 0xFFFFFFFFu
-
-// What the accumulation kernels write a finished run into: the canonical 32-bit XYZZ point every other kernel uses.
+// ---- bucket slots in the accumulation kernels' own form (round 6) ------------------------------------------------------
+// What the accumulation kernels write a finished run into, and what the tail kernels (tails28_impl.cuh) read and write:
+// x | y | zz | zzz, N limbs each, normalised (every limb < 2^28, the top one whatever is left); x < 6.1 p, y < 2 p,
+// zz, zzz < 1.05 p -- exactly what the accumulator holds, so a flush is 4 N stores and no arithmetic (rounds 2-5 converted
+// to the canonical 32-bit form here: ~2 000 instructions per run, and the tails converted nothing back because they ran on
+// the 32-bit out-of-line code).  The all-zero slot is the point at infinity (zz of a finite point is a unit of the field).
+template <class P>
+struct alignas(16) Slot28 {
+  static constexpr int N = Fp28<P>::N;
+  static constexpr int WORDS = 4 * N;
+  static_assert(WORDS % 4 == 0, "slot must be a whole number of 16-byte words");
+  uint32_t w[WORDS];
+};
+// G2: one Slot28 per Fq2 component (even lane of a pair: c0, odd lane: c1)
+template <class P>
+struct alignas(16) Slot28G2 {
+  Slot28<P> half[2];
+};
 template <class P, int COORDS>
-using Msm28Slot = typename std::conditional<COORDS == 4, XYZZ<Fp<P>>, XYZZ<Fp2<P>>>::type;
+using Msm28Slot = typename std::conditional<COORDS == 4, Slot28<P>, Slot28G2<P>>::type;
+
+template <class P>
+ARK_HD void slot28_put(Slot28<P>* dst, const Acc28<P>& a, bool empty) {
+  constexpr int N = Fp28<P>::N;
+  uint4* d = reinterpret_cast<uint4*>(dst);
+  uint32_t v[4 * N];
+#pragma unroll
+  for (int i = 0; i < N; i++) {
+    v[0 * N + i] = empty ? 0u : a.x.l[i];
+    v[1 * N + i] = empty ? 0u : a.y.l[i];
+    v[2 * N + i] = empty ? 0u : a.zz.l[i];
+    v[3 * N + i] = empty ? 0u : a.zzz.l[i];
+  }
+#pragma unroll
+  for (int k = 0; k < N; k++) d[k] = make_uint4(v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]);
+}
+// returns "this (half) slot is the all-zero one"
+template <class P>
+ARK_HD bool slot28_get(const Slot28<P>* src, Acc28<P>& a) {
+  constexpr int N = Fp28<P>::N;
+  const uint4* s = reinterpret_cast<const uint4*>(src);
+  uint32_t v[4 * N];
+#pragma unroll
+  for (int k = 0; k < N; k++) {
+    const uint4 t = s[k];
+    v[4 * k] = t.x;
+    v[4 * k + 1] = t.y;
+    v[4 * k + 2] = t.z;
+    v[4 * k + 3] = t.w;
+  }
+  uint32_t any = 0;
+#pragma unroll
+  for (int i = 0; i < N; i++) {
+    a.x.l[i] = v[0 * N + i];
+    a.y.l[i] = v[1 * N + i];
+    a.zz.l[i] = v[2 * N + i];
+    a.zzz.l[i] = v[3 * N + i];
+    any |= v[2 * N + i];
+  }
+  return any == 0;
+}
+
+// Where a finished run goes (same protocol as msm_flush_run, msm_impl.cuh): buckets[key] when it is the bucket's only run,
+// head[seg] when it opened the segment, tail[seg] otherwise.  Three explicit branches, NOT a select among the pointers:
+// hipcc turns such a select into an indexed load from the caller's closure object, which then cannot be scalarised -- and
+// every captured variable, the accumulator included, lives in scratch memory for the whole loop.
+template <class P>
+ARK_D void msm_flush_slot28(Slot28<P>* buckets_half, Slot28<P>* head_half, Slot28<P>* tail_half, uint32_t* head_key,
+                            uint32_t* tail_key, bool write_key, uint32_t key, const Acc28<P>& acc, bool empty, bool first_run,
+                            uint32_t run_start, uint32_t run_end, uint32_t seg, const uint32_t* offsets, const uint32_t* counts,
+                            size_t slot_stride) {
+  const uint32_t o = offsets[key], cnt = counts[key];
+  const bool complete = (run_start == o) && (run_end == o + cnt);
+  if (complete) {
+    slot28_put<P>(reinterpret_cast<Slot28<P>*>(reinterpret_cast<uint8_t*>(buckets_half) + (size_t)key * slot_stride), acc, empty);
+  } else if (first_run) {
+    slot28_put<P>(reinterpret_cast<Slot28<P>*>(reinterpret_cast<uint8_t*>(head_half) + (size_t)seg * slot_stride), acc, empty);
+    if (write_key) head_key[seg] = key;
+  } else {
+    slot28_put<P>(reinterpret_cast<Slot28<P>*>(reinterpret_cast<uint8_t*>(tail_half) + (size_t)seg * slot_stride), acc, empty);
+    if (write_key) tail_key[seg] = key;
+  }
+}
 
 template <class P, bool PACKED>
 using Row28 = typename std::conditional<PACKED, Affine28<P>, Affine28U<P>>::type;
@@ -210,7 +290,6 @@ msm_accumulate28_kernel(const Affine28U<P>* __restrict__ bases, const uint32_t* 
                         uint32_t* __restrict__ head_key, Msm28Slot<P, 4>* __restrict__ tail,
                         uint32_t* __restrict__ tail_key, uint32_t seg_len) {
   using F = Fp28<P>;
-  using Fq = Fp<P>;
   using Row = Affine28U<P>;
   constexpr int Q = Row::Q;
   const uint32_t seg = blockIdx.x * blockDim.x + threadIdx.x;
@@ -230,15 +309,8 @@ msm_accumulate28_kernel(const Affine28U<P>* __restrict__ bases, const uint32_t* 
   acc.zzz = F::zero();
   // always_inline: a closure that is inlined late keeps every captured variable (the accumulator!) in scratch memory
   auto flush = [&](uint32_t key, uint32_t run_end) __attribute__((always_inline)) {
-    XYZZ<Fq> out = XYZZ<Fq>::inf();
-    if (!empty) {
-      out.x = F::to_fp_lt8(acc.x);
-      out.y = F::to_fp_lt8(acc.y);
-      out.zz = F::to_fp_lt8(acc.zz);
-      out.zzz = F::to_fp_lt8(acc.zzz);
-    }
-    msm_flush_run<Fq>(key, out, first_run, run_start, run_end, seg, offsets, counts, buckets, head, head_key, tail,
-                      tail_key);
+    msm_flush_slot28<P>(buckets, head, tail, head_key, tail_key, true, key, acc, empty, first_run, run_start, run_end, seg, offsets,
+                        counts, sizeof(Slot28<P>));
   };
   // software prefetch of the next row into explicit 16-byte registers (see msm_accumulate_kernel)
   uint4 nx[Q];
@@ -355,7 +427,6 @@ msm_accumulate28p_kernel(const Affine28<P>* __restrict__ bases, const uint32_t* 
                         uint32_t* __restrict__ head_key, Msm28Slot<P, 4>* __restrict__ tail,
                         uint32_t* __restrict__ tail_key, uint32_t seg_len) {
   using F = Fp28<P>;
-  using Fq = Fp<P>;
   using Row = Affine28<P>;
   constexpr int Q = Row::Q;
   __shared__ uint32_t park_lds[Park28<P>::WORDS * MSM_THREADS];
@@ -378,15 +449,8 @@ msm_accumulate28p_kernel(const Affine28<P>* __restrict__ bases, const uint32_t* 
   bool parked = false;
   // always_inline: a closure that is inlined late keeps every captured variable (the accumulator!) in scratch memory
   auto flush = [&]() __attribute__((always_inline)) {
-    XYZZ<Fq> out = XYZZ<Fq>::inf();
-    if (!empty) {
-      out.x = F::to_fp_lt8(acc.x);
-      out.y = F::to_fp_lt8(acc.y);
-      out.zz = F::to_fp_lt8(acc.zz);
-      out.zzz = F::to_fp_lt8(acc.zzz);
-    }
-    msm_flush_run<Fq>(cur_key, out, first_run, run_start, run_end, seg, offsets, counts, buckets, head, head_key, tail,
-                      tail_key);
+    msm_flush_slot28<P>(buckets, head, tail, head_key, tail_key, true, cur_key, acc, empty, first_run, run_start, run_end, seg,
+                        offsets, counts, sizeof(Slot28<P>));
   };
   // entry e: key k0, row index v0, row nx (explicit 16-byte registers); entry e + 1: row index v1
   uint32_t k0 = cur_key;
@@ -512,7 +576,13 @@ struct Pair28 {
     for (int i = 0; i < N; i++) r.l[i] = ark_pair_xchg(v.l[i]);
     return r;
   }
-  ARK_D static bool both(bool b) { return b && (ark_pair_xchg(b ? 1u : 0u) != 0); }
+  // (both lanes always exchange: a lane that skipped the exchange because its own flag is false would leave its partner
+  // reading a lane that is masked off -- correct on the hardware only through DPP's bound_ctrl, and a desynchronised
+  // pair in the emulator)
+  ARK_D static bool both(bool b) {
+    const uint32_t other = ark_pair_xchg(b ? 1u : 0u);
+    return b && other != 0;
+  }
   ARK_D static F sel(bool c, const F& a, const F& b) {
     F r;
 #pragma unroll
@@ -653,7 +723,6 @@ msm_accumulate_g2l28_kernel(const Affine28G2<P, false>* __restrict__ bases, cons
                             uint32_t* __restrict__ head_key, Msm28Slot<P, 8>* __restrict__ tail,
                             uint32_t* __restrict__ tail_key, uint32_t seg_len) {
   using F = Fp28<P>;
-  using Fq = Fp<P>;
   constexpr int Q = Affine28U<P>::Q;
   const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t seg = gid >> 1, par = gid & 1u;       // blockDim is even: par == lane parity
@@ -673,35 +742,9 @@ msm_accumulate_g2l28_kernel(const Affine28G2<P, false>* __restrict__ bases, cons
   acc.zzz = F::zero();
   // always_inline: a closure that is inlined late keeps every captured variable (the accumulator!) in scratch memory
   auto flush = [&](uint32_t key, uint32_t run_end) __attribute__((always_inline)) {
-    // this lane's halves of the four Fq2 coordinates, canonical 32-bit form
-    XYZZ<Fq> mine = XYZZ<Fq>::inf();
-    if (!empty) {
-      mine.x = F::to_fp_lt8(acc.x);
-      mine.y = F::to_fp_lt8(acc.y);
-      mine.zz = F::to_fp_lt8(acc.zz);
-      mine.zzz = F::to_fp_lt8(acc.zzz);
-    }
-    const uint32_t o = offsets[key], cnt = counts[key];
-    const bool complete = (run_start == o) && (run_end == o + cnt);
-    // three explicit branches, NOT a select among the captured pointers: hipcc turns such a select into an indexed
-    // load from the closure object, which then cannot be scalarised -- and every captured variable, the accumulator
-    // included, lives in scratch memory for the whole loop (28 x 16-byte scratch accesses per mixed addition)
-    auto store = [&](XYZZ<Fp2<P>>* dst) __attribute__((always_inline)) {
-      Fq* d = reinterpret_cast<Fq*>(dst);
-      d[0 + par] = mine.x;
-      d[2 + par] = mine.y;
-      d[4 + par] = mine.zz;
-      d[6 + par] = mine.zzz;
-    };
-    if (complete) {
-      store(&buckets[key]);
-    } else if (first_run) {
-      store(&head[seg]);
-      if (par == 0) head_key[seg] = key;
-    } else {
-      store(&tail[seg]);
-      if (par == 0) tail_key[seg] = key;
-    }
+    // this lane's component of the four Fq2 coordinates: half `par` of the pair's slot
+    msm_flush_slot28<P>(&buckets->half[par], &head->half[par], &tail->half[par], head_key, tail_key, par == 0, key, acc, empty,
+                        first_run, run_start, run_end, seg, offsets, counts, sizeof(Slot28G2<P>));
   };
   for (uint32_t e = start; e < end; e++) {
     const uint32_t key = sorted_keys[e];
@@ -751,7 +794,6 @@ msm_accumulate_g2l28p_kernel(const Affine28G2<P, true>* __restrict__ bases, cons
                             uint32_t* __restrict__ head_key, Msm28Slot<P, 8>* __restrict__ tail,
                             uint32_t* __restrict__ tail_key, uint32_t seg_len) {
   using F = Fp28<P>;
-  using Fq = Fp<P>;
   using Row = Affine28<P>;
   constexpr int Q = Row::Q;
   __shared__ uint32_t park_lds[Park28<P>::WORDS * MSM_THREADS];      // this lane's halves of the parked run
@@ -775,35 +817,9 @@ msm_accumulate_g2l28p_kernel(const Affine28G2<P, true>* __restrict__ bases, cons
   bool parked = false;
   // always_inline: a closure that is inlined late keeps every captured variable (the accumulator!) in scratch memory
   auto flush = [&]() __attribute__((always_inline)) {
-    // this lane's halves of the four Fq2 coordinates, canonical 32-bit form
-    XYZZ<Fq> mine = XYZZ<Fq>::inf();
-    if (!empty) {
-      mine.x = F::to_fp_lt8(acc.x);
-      mine.y = F::to_fp_lt8(acc.y);
-      mine.zz = F::to_fp_lt8(acc.zz);
-      mine.zzz = F::to_fp_lt8(acc.zzz);
-    }
-    const uint32_t o = offsets[cur_key], cnt = counts[cur_key];
-    const bool complete = (run_start == o) && (run_end == o + cnt);
-    // three explicit branches, NOT a select among the captured pointers: hipcc turns such a select into an indexed
-    // load from the closure object, which then cannot be scalarised -- and every captured variable, the accumulator
-    // included, lives in scratch memory for the whole loop (28 x 16-byte scratch accesses per mixed addition)
-    auto store = [&](XYZZ<Fp2<P>>* dst) __attribute__((always_inline)) {
-      Fq* d = reinterpret_cast<Fq*>(dst);
-      d[0 + par] = mine.x;
-      d[2 + par] = mine.y;
-      d[4 + par] = mine.zz;
-      d[6 + par] = mine.zzz;
-    };
-    if (complete) {
-      store(&buckets[cur_key]);
-    } else if (first_run) {
-      store(&head[seg]);
-      if (par == 0) head_key[seg] = cur_key;
-    } else {
-      store(&tail[seg]);
-      if (par == 0) tail_key[seg] = cur_key;
-    }
+    // this lane's component of the four Fq2 coordinates: half `par` of the pair's slot
+    msm_flush_slot28<P>(&buckets->half[par], &head->half[par], &tail->half[par], head_key, tail_key, par == 0, cur_key, acc, empty,
+                        first_run, run_start, run_end, seg, offsets, counts, sizeof(Slot28G2<P>));
   };
   // Key and row index of entry e + 1 are loaded during entry e.  The half row itself is gathered at the top of its own
   // iteration: held in registers across the lane-pair addition (24 VGPRs) it pushes the hot loop into scratch memory

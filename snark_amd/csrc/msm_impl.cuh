@@ -547,7 +547,7 @@ ARK_D void msm_flush_run(uint32_t key, const XYZZ<F>& acc, bool first_run, uint3
 }
 
 }  // namespace ark355
-#include "msm28_impl.cuh"
+#include "tails28_impl.cuh"     // (includes msm28_impl.cuh: the 28-bit accumulation kernels and their bucket slots)
 namespace ark355 {
 
 template <class F, bool NI>
@@ -1150,162 +1150,6 @@ msm_combine_kernel(const XYZZ<F>* __restrict__ partials, uint32_t per_window, ui
   }
 }
 
-// ---- the G1 tails of SEVERAL MSMs, one launch per step (merge, heavy merge, reduction, combination) ------------------------
-// The tails are latency-bound (a few dozen dependent group operations on 32-128 workgroups): four of them side by side take
-// the time of one.  A one-stream proof runs its five accumulations first and then the tails of A, B1, L' and H together
-// (blockIdx.z = MSM): 16 dispatches and ~4 ms of stream time per 2^20 proof become 4 dispatches and ~1.4 ms.  Same lane-level
-// arithmetic as the single kernels above (the bodies are the same statements), so the bucket sums are bit-identical.
-constexpr int TAIL_BATCH_MAX = 4;
-template <class F>
-struct TailJob {
-  const uint32_t* offsets;
-  const uint32_t* counts;
-  XYZZ<F>* buckets;
-  const XYZZ<F>* head;
-  const uint32_t* head_key;
-  const XYZZ<F>* tail;
-  const uint32_t* tail_key;
-  uint32_t* heavy_count;
-  uint32_t* heavy_list;
-  XYZZ<F>* partials;
-  XYZZ<F>* out;
-  uint32_t seg_len, heavy_span;
-  int32_t accumulate;
-  uint32_t pad;
-};
-template <class F>
-struct TailBatch {
-  TailJob<F> j[TAIL_BATCH_MAX];
-};
-
-template <class F>
-__global__ void __launch_bounds__(MSM_THREADS, MSM_TAIL_WAVES)
-msm_merge_batch_kernel(TailBatch<F> tb, uint32_t total_buckets) {
-  const TailJob<F>& J = tb.j[blockIdx.z];
-  const uint32_t key = blockIdx.x * blockDim.x + threadIdx.x;
-  if (key >= total_buckets) return;
-  const uint32_t cnt = J.counts[key];
-  if (cnt == 0) return;
-  const uint32_t o = J.offsets[key];
-  const uint32_t t0 = o / J.seg_len, t1 = (o + cnt - 1) / J.seg_len;
-  if (t0 == t1) return;
-  if (t1 - t0 > J.heavy_span) {
-    J.heavy_list[atomicAdd(J.heavy_count, 1u)] = key;
-    return;
-  }
-  XYZZ<F> sum = XYZZ<F>::inf();
-  for (uint32_t t = t0; t <= t1; t++) {
-    if (J.head_key[t] == key) sum = xyzz_add(sum, J.head[t]);
-    if (J.tail_key[t] == key) sum = xyzz_add(sum, J.tail[t]);
-  }
-  J.buckets[key] = sum;
-}
-
-template <class F>
-__global__ void __launch_bounds__(MSM_THREADS, MSM_TAIL_WAVES)
-msm_merge_heavy_batch_kernel(TailBatch<F> tb) {
-  __shared__ uint32_t wave_out[(MSM_THREADS / 64) * (sizeof(XYZZ<F>) / 4)];
-  constexpr int WORDS = sizeof(XYZZ<F>) / 4;
-  const TailJob<F>& J = tb.j[blockIdx.z];
-  const uint32_t nheavy = *J.heavy_count;
-  for (uint32_t h = blockIdx.x; h < nheavy; h += gridDim.x) {
-    const uint32_t key = J.heavy_list[h];
-    const uint32_t o = J.offsets[key], cnt = J.counts[key];
-    const uint32_t t0 = o / J.seg_len, t1 = (o + cnt - 1) / J.seg_len;
-    XYZZ<F> sum = XYZZ<F>::inf();
-    for (uint32_t t = t0 + threadIdx.x; t <= t1; t += blockDim.x) {
-      if (J.head_key[t] == key) sum = xyzz_add(sum, J.head[t]);
-      if (J.tail_key[t] == key) sum = xyzz_add(sum, J.tail[t]);
-    }
-    sum = wave_reduce_sum(sum);
-    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (lane == 0) {
-      const uint32_t* src = reinterpret_cast<const uint32_t*>(&sum);
-      for (int i = 0; i < WORDS; i++) wave_out[wave * WORDS + i] = src[i];
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      XYZZ<F> tot = XYZZ<F>::inf();
-      for (uint32_t v = 0; v < blockDim.x / 64; v++) {
-        XYZZ<F> t;
-        uint32_t* dst = reinterpret_cast<uint32_t*>(&t);
-        for (int i = 0; i < WORDS; i++) dst[i] = wave_out[v * WORDS + i];
-        tot = xyzz_add(tot, t);
-      }
-      J.buckets[key] = tot;
-    }
-    __syncthreads();
-  }
-}
-
-// grid (blocks per window, windows, MSMs)
-template <class F>
-__global__ void __launch_bounds__(MSM_THREADS, MSM_TAIL_WAVES)
-msm_reduce_batch_kernel(TailBatch<F> tb, uint32_t buckets_per_window) {
-  __shared__ uint32_t wave_out[(MSM_THREADS / 64) * (sizeof(XYZZ<F>) / 4)];
-  const TailJob<F>& J = tb.j[blockIdx.z];
-  const uint32_t w = blockIdx.y;
-  const uint32_t chunk = blockIdx.x * blockDim.x + threadIdx.x;
-  const uint32_t first = chunk * MSM_RED_K;
-  XYZZ<F> contrib = XYZZ<F>::inf();
-  if (first < buckets_per_window) {
-    const uint32_t last = (first + MSM_RED_K < buckets_per_window) ? first + MSM_RED_K : buckets_per_window;
-    const XYZZ<F>* wb = J.buckets + (uint64_t)w * buckets_per_window;
-    XYZZ<F> running = XYZZ<F>::inf();
-    XYZZ<F> acc = XYZZ<F>::inf();
-    for (uint32_t b = last; b-- > first;) {
-      running = xyzz_add(running, wb[b]);
-      acc = xyzz_add(acc, running);
-    }
-    if (first != 0 && !running.is_inf()) {
-      uint32_t k = first;
-      acc = xyzz_add(acc, xyzz_mul_scalar(running, &k, 1));
-    }
-    contrib = acc;
-  }
-  contrib = wave_reduce_sum(contrib);
-  constexpr int WORDS = sizeof(XYZZ<F>) / 4;
-  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (lane == 0) {
-    const uint32_t* src = reinterpret_cast<const uint32_t*>(&contrib);
-    for (int i = 0; i < WORDS; i++) wave_out[wave * WORDS + i] = src[i];
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    XYZZ<F> sum = XYZZ<F>::inf();
-    for (uint32_t v = 0; v < blockDim.x / 64; v++) {
-      XYZZ<F> t;
-      uint32_t* dst = reinterpret_cast<uint32_t*>(&t);
-      for (int i = 0; i < WORDS; i++) dst[i] = wave_out[v * WORDS + i];
-      sum = xyzz_add(sum, t);
-    }
-    J.partials[w * gridDim.x + blockIdx.x] = sum;
-  }
-}
-
-// one wave per MSM (blockIdx.x = MSM)
-template <class F>
-__global__ void __launch_bounds__(64)
-msm_combine_batch_kernel(TailBatch<F> tb, uint32_t per_window, uint32_t windows, uint32_t c) {
-  const TailJob<F>& J = tb.j[blockIdx.x];
-  const uint32_t w = threadIdx.x;
-  XYZZ<F> v = XYZZ<F>::inf();
-  if (windows == 1) {
-    for (uint32_t i = w; i < per_window; i += 64) v = xyzz_add(v, J.partials[i]);
-  } else if (w < windows) {
-    for (uint32_t i = 0; i < per_window; i++) v = xyzz_add(v, J.partials[w * per_window + i]);
-    if (!v.is_inf()) {
-      const uint32_t dbl = c * w;
-      for (uint32_t i = 0; i < dbl; i++) v = xyzz_dbl(v);
-    }
-  }
-  v = wave_reduce_sum(v);
-  if (threadIdx.x == 0) {
-    if (J.accumulate) v = xyzz_add(v, *J.out);
-    *J.out = v;
-  }
-}
-
 // XYZZ -> affine for `count` points (one lane each)
 template <class F>
 __global__ void __launch_bounds__(64)
@@ -1717,10 +1561,35 @@ static void msm_sort(ark355_ctx* ctx, MsmSort& s, const void* d_scalars, uint64_
 // Scratch for the bucket phase of one group type.
 struct MsmBuckets {
   DevBuf buckets, head, tail, head_key, tail_key, partials, heavy_count, heavy_list, lvl_t, lvl_w;
+  DevBuf rc;                            // row / column sums of the bucket matrix (tails28_impl.cuh, stage A)
   uint32_t seg_len = 32, segs = 0;      // of the last accumulation over this bucket set (G1 and G2 differ)
+  int fmt = 0;                          // slot format of buckets / head / tail: 0 canonical XYZZ<F>, else Slot28 / Slot28G2
   bool prepared = false;                // msm_prepare_phase ran for the coming accumulation
   bool heavy_cleared = false;           // msm_prepare_phase already cleared heavy_count for the coming merge
 };
+
+// The field a group's coordinates live in, seen from the 28-bit kernels: base-field parameters + "on lane pairs"
+template <class F>
+struct Tail28Of {
+  using P = typename F::Params;
+  static constexpr bool G2 = false;
+};
+template <class P_>
+struct Tail28Of<Fp2<P_>> {
+  using P = P_;
+  static constexpr bool G2 = true;
+};
+template <class F>
+static inline size_t msm_slot_bytes(int fmt) {
+  return fmt ? sizeof(typename Tail28<typename Tail28Of<F>::P, Tail28Of<F>::G2>::Slot) : sizeof(XYZZ<F>);
+}
+// What an MSM leaves on the device for the host: ONE XYZZ sum from the 32-bit tails (one-shot MSMs over caller's bases), c
+// partial sums per bucket set from the 28-bit tails (resident tables); msm_parts_finish turns either into the sum.
+static inline uint32_t msm_parts_count(const MsmPlan& p, int fmt) { return fmt ? p.key_windows * p.c : 1u; }
+template <class F>
+static XYZZ<F> msm_parts_finish(const XYZZ<F>* parts, const MsmPlan& p, int fmt) {
+  return fmt ? msm_finish_host<F>(parts, p.key_windows, p.c) : parts[0];
+}
 
 // Phase 1 of the bucket method over an existing sort: bucket accumulation (the chip-filling kernel).
 // Size and clear the bucket set of one MSM over an existing sort.  The prover issues this on its (high-priority) sort
@@ -1728,22 +1597,24 @@ struct MsmBuckets {
 // fill kernels in front of every accumulation launch sat behind the other proofs' workgroups and opened a gap between
 // consecutive accumulations (31 fills per proof, 2.5 ms of stream time with four proofs in flight).
 template <class F>
-static void msm_prepare_phase(const TunePolicy& pol, const MsmSort& s, MsmBuckets& b, hipStream_t stream, int /*fmt*/ = 0,
+static void msm_prepare_phase(const TunePolicy& pol, const MsmSort& s, MsmBuckets& b, hipStream_t stream, int fmt = 0,
                               FillBatch* fb = nullptr) {
   const MsmPlan& p = s.plan;
   b.prepared = true;
   b.heavy_cleared = false;
+  b.fmt = fmt;
   if (p.n == 0) return;
+  const size_t slot = msm_slot_bytes<F>(fmt);
   const uint64_t entries = (uint64_t)p.windows * p.n;
   b.seg_len = msm_seg_len(entries, is_fp2<F>::value, pol.msm_seg);
   b.segs = (uint32_t)((entries + b.seg_len - 1) / b.seg_len);
   const uint32_t segs = b.segs;
-  b.buckets.ensure((size_t)p.total_buckets * sizeof(XYZZ<F>));
-  b.head.ensure((size_t)segs * sizeof(XYZZ<F>));
-  b.tail.ensure((size_t)segs * sizeof(XYZZ<F>));
+  b.buckets.ensure((size_t)p.total_buckets * slot);
+  b.head.ensure((size_t)segs * slot);
+  b.tail.ensure((size_t)segs * slot);
   b.head_key.ensure((size_t)segs * 4);
   b.tail_key.ensure((size_t)segs * 4);
-  fill_bytes(fb, b.buckets.p, 0, (size_t)p.total_buckets * sizeof(XYZZ<F>), stream);
+  fill_bytes(fb, b.buckets.p, 0, (size_t)p.total_buckets * slot, stream);
   fill_bytes(fb, b.head_key.p, 0xFF, (size_t)segs * 4, stream);
   fill_bytes(fb, b.tail_key.p, 0xFF, (size_t)segs * 4, stream);
   // the heavy-bucket counter of the merge that follows the accumulation (msm_reduce_phase clears it itself otherwise)
@@ -1766,6 +1637,7 @@ static void msm_accumulate_phase(ark355_ctx* ctx, const MsmSort& s, MsmBuckets& 
   // fmt: PrecompTable::fmt() of the table d_bases points to -- 0 canonical Affine<F> rows, 1 unpacked, 2 packed 28-bit rows
   const MsmPlan& p = s.plan;
   if (!b.prepared) msm_prepare_phase<F>(ctx->policy, s, b, stream, fmt);      // stand-alone MSMs: same stream
+  ARK_REQUIRE(b.fmt == fmt, ARK355_EINVAL, "bucket set was prepared for another slot format");
   b.prepared = false;
   if (p.n == 0) return;
   const uint32_t segs = b.segs;
@@ -1826,6 +1698,93 @@ static void msm_accumulate_phase(ark355_ctx* ctx, const MsmSort& s, MsmBuckets& 
   if (ev1) ARK_CHECK_HIP(hipEventRecord(ev1, stream));
 }
 
+// Phase 2 of `count` (<= TAIL28_MAX) MSMs over 28-bit slots whose accumulations have been queued on `stream`, as ONE launch
+// per step (tails28_impl.cuh: merge, heavy merge, row / column sums, bit sums; blockIdx.z = MSM) -- a one-stream proof runs
+// the tails of its four G1 MSMs side by side.  outs[i] receives msm_parts_count() partial sums (msm_parts_finish on the host).
+// Returns false -- nothing queued -- when the MSMs cannot share launches (different bucket layouts, an empty one, 32-bit
+// slots): the caller then runs msm_reduce_phase per MSM.
+// after_merge (optional, count == 1): called with the complete local bucket array (slots) between the merge and the
+// reduction -- the bucket-level cross-GPU exchange of comm_impl.cuh.
+template <class F, class Hook = std::nullptr_t>
+static bool msm_tails28_launch(ark355_ctx* ctx, int count, const MsmSort* const* sorts, MsmBuckets* const* bks,
+                               XYZZ<F>* const* outs, hipStream_t stream, Hook after_merge = nullptr) {
+  (void)ctx;
+  using P = typename Tail28Of<F>::P;
+  constexpr bool G2 = Tail28Of<F>::G2;
+  constexpr bool HOOK = !std::is_same<Hook, std::nullptr_t>::value;
+  using T = Tail28<P, G2>;
+  using Slot = typename T::Slot;
+  if (count < 1 || count > TAIL28_MAX) return false;
+  const MsmPlan& p0 = sorts[0]->plan;
+  // (an EMPTY shard still takes part in the bucket exchange: all-infinity bucket array, no merge)
+  const bool empty_with_hook = HOOK && count == 1 && p0.n == 0;
+  for (int i = 0; i < count; i++) {
+    const MsmPlan& p = sorts[i]->plan;
+    if ((p.n == 0 && !empty_with_hook) || !bks[i]->fmt) return false;
+    if (p.total_buckets != p0.total_buckets || p.buckets_per_window != p0.buckets_per_window || p.key_windows != p0.key_windows ||
+        p.c != p0.c)
+      return false;
+  }
+  ARK_REQUIRE(p0.c >= 3 && p0.buckets_per_window == (1u << (p0.c - 1)), ARK355_EINVAL, "bucket layout the 28-bit tails do not know");
+  uint32_t lb, hb;
+  tails28_split(p0.c, &lb, &hb);
+  const uint32_t L = 1u << lb, H = 1u << hb;
+  TailBatch28 tb;
+  memset(&tb, 0, sizeof(tb));
+  uint32_t max_heavy_all = 1;
+  for (int i = 0; i < count; i++) {
+    const MsmSort& s = *sorts[i];
+    MsmBuckets& b = *bks[i];
+    const uint32_t segs = b.segs;
+    // at most entries / (MSM_HEAVY_SPAN * segment length) buckets can be heavy; "heavy" is relative: twice the average span
+    // of a bucket once that exceeds the fixed threshold
+    const uint32_t max_heavy = segs / MSM_HEAVY_SPAN + 1;
+    const uint32_t avg_span = (uint32_t)(((uint64_t)segs + p0.total_buckets - 1) / p0.total_buckets);
+    const uint32_t heavy_span = (2 * avg_span > MSM_HEAVY_SPAN) ? 2 * avg_span : MSM_HEAVY_SPAN;
+    if (max_heavy > max_heavy_all) max_heavy_all = max_heavy;
+    b.heavy_count.ensure(16);
+    b.heavy_list.ensure((size_t)max_heavy * 4);
+    b.rc.ensure((size_t)p0.key_windows * (H + L) * sizeof(Slot));
+    if (!b.heavy_cleared) ARK_CHECK_HIP(hipMemsetAsync(b.heavy_count.p, 0, 4, stream));
+    b.heavy_cleared = false;
+    TailJob28& J = tb.j[i];
+    J.offsets = s.offsets.as<uint32_t>();
+    J.counts = s.counts.as<uint32_t>();
+    J.buckets = b.buckets.p;
+    J.head = b.head.p;
+    J.head_key = b.head_key.as<uint32_t>();
+    J.tail = b.tail.p;
+    J.tail_key = b.tail_key.as<uint32_t>();
+    J.heavy_count = b.heavy_count.as<uint32_t>();
+    J.heavy_list = b.heavy_list.as<uint32_t>();
+    J.rc = b.rc.p;
+    J.out = outs[i];
+    J.seg_len = b.seg_len;
+    J.heavy_span = heavy_span;
+  }
+  if (empty_with_hook) {
+    bks[0]->buckets.ensure((size_t)p0.total_buckets * sizeof(Slot));
+    tb.j[0].buckets = bks[0]->buckets.p;
+    ARK_CHECK_HIP(hipMemsetAsync(bks[0]->buckets.p, 0, (size_t)p0.total_buckets * sizeof(Slot), stream));
+  } else {
+    const uint32_t grid_b = (uint32_t)(((uint64_t)p0.total_buckets * T::LPI + MSM_THREADS - 1) / MSM_THREADS);
+    ARK_LAUNCH((msm_merge28_kernel<P, G2>), dim3(grid_b, 1, (uint32_t)count), dim3(MSM_THREADS), 0, stream, tb, p0.total_buckets);
+    ARK_CHECK_LAUNCH();
+    const uint32_t grid_h = max_heavy_all < ARK_MSM_HEAVY_GRID ? max_heavy_all : ARK_MSM_HEAVY_GRID;
+    ARK_LAUNCH((msm_merge_heavy28_kernel<P, G2>), dim3(grid_h, 1, (uint32_t)count), dim3(MSM_THREADS), 0, stream, tb);
+    ARK_CHECK_LAUNCH();
+  }
+  if constexpr (HOOK) {
+    ARK_REQUIRE(count == 1, ARK355_EINVAL, "the bucket exchange runs per MSM");
+    after_merge(bks[0]->buckets.p, p0.total_buckets, stream);
+  }
+  ARK_LAUNCH((msm_selsum28_kernel<P, G2, 0>), dim3(H + L, p0.key_windows, (uint32_t)count), dim3(64), 0, stream, tb, lb, hb);
+  ARK_CHECK_LAUNCH();
+  ARK_LAUNCH((msm_selsum28_kernel<P, G2, 1>), dim3(p0.c, p0.key_windows, (uint32_t)count), dim3(64), 0, stream, tb, lb, hb);
+  ARK_CHECK_LAUNCH();
+  return true;
+}
+
 // G2 tails run on lane pairs (round 2; the one-lane-per-bucket kernels with out-of-line Fq2 arithmetic they replaced took
 // 2.5x as long and are gone -- profiles/r02_g2_pair_tails_ab.txt)
 static inline bool msm_g2_pair_tails(const ark355_ctx*) { return true; }
@@ -1840,6 +1799,21 @@ static void msm_reduce_phase(ark355_ctx* ctx, const MsmSort& s, MsmBuckets& b, X
                              hipStream_t stream, Hook after_merge = nullptr) {
   const MsmPlan& p = s.plan;
   constexpr bool HOOK = !std::is_same<Hook, std::nullptr_t>::value;
+  if (b.fmt) {
+    // buckets in 28-bit slots (every MSM over resident window tables): the round-6 tails; d_out receives msm_parts_count()
+    // partial sums
+    ARK_REQUIRE(!accumulate, ARK355_EINVAL, "the 28-bit tails do not accumulate into a previous result");
+    if (p.n == 0 && !HOOK) {
+      ARK_CHECK_HIP(hipMemsetAsync(d_out, 0, (size_t)msm_parts_count(p, b.fmt) * sizeof(XYZZ<F>), stream));
+      return;
+    }
+    const MsmSort* sorts[1] = {&s};
+    MsmBuckets* bks[1] = {&b};
+    XYZZ<F>* outs[1] = {d_out};
+    const bool ok = msm_tails28_launch<F, Hook>(ctx, 1, sorts, bks, outs, stream, after_merge);
+    ARK_REQUIRE(ok, ARK355_EINVAL, "28-bit tails refused a bucket set");
+    return;
+  }
   if (p.n == 0) {
     if constexpr (HOOK) {
       // an empty shard still takes part in the exchange: all-infinity bucket array
@@ -1898,7 +1872,7 @@ static void msm_reduce_phase(ark355_ctx* ctx, const MsmSort& s, MsmBuckets& b, X
                  b.head.as<XYZZ<F>>(), b.head_key.as<uint32_t>(), b.tail.as<XYZZ<F>>(), b.tail_key.as<uint32_t>(), b.seg_len);
     ARK_CHECK_LAUNCH();
   }
-  if constexpr (HOOK) after_merge(b.buckets.as<XYZZ<F>>(), p.total_buckets, stream);
+  if constexpr (HOOK) after_merge(b.buckets.p, p.total_buckets, stream);
 
 #ifndef ARK_MSM_TWO_LEVEL_MIN
 #define ARK_MSM_TWO_LEVEL_MIN (1u << 17)        // bucket count from which the two-level reduction is used (tests: small)
@@ -1955,72 +1929,11 @@ static void msm_reduce_phase(ark355_ctx* ctx, const MsmSort& s, MsmBuckets& b, X
   ARK_CHECK_LAUNCH();
 }
 
-// Phase 2 of `count` (<= TAIL_BATCH_MAX) G1 MSMs whose accumulations have been queued on `stream`, as one launch per
-// step.  Returns false -- nothing queued -- when the MSMs cannot share launches (different bucket layouts, an empty one,
-// the two-level reduction of very large bucket sets): the caller then runs msm_reduce_phase per MSM.
 template <class F>
 static bool msm_reduce_phase_batch(ark355_ctx* ctx, int count, const MsmSort* const* sorts, MsmBuckets* const* bks,
                                    XYZZ<F>* const* outs, hipStream_t stream) {
-  static_assert(!is_fp2<F>::value, "the G2 tails run on lane pairs (msm_*_pair_kernel)");
-  if (count < 2 || count > TAIL_BATCH_MAX) return false;
-  const MsmPlan& p0 = sorts[0]->plan;
-  const uint32_t two_level_min = ctx->policy.msm_two_level_min >= 0 ? (uint32_t)ctx->policy.msm_two_level_min
-                                                                     : (uint32_t)ARK_MSM_TWO_LEVEL_MIN;
-  if (p0.key_windows == 1 && p0.total_buckets >= two_level_min) return false;
-  if (p0.key_windows > 64) return false;
-  for (int i = 0; i < count; i++) {
-    const MsmPlan& p = sorts[i]->plan;
-    if (p.n == 0) return false;
-    if (p.total_buckets != p0.total_buckets || p.buckets_per_window != p0.buckets_per_window || p.key_windows != p0.key_windows ||
-        p.c != p0.c)
-      return false;
-  }
-  const uint32_t grid_b = (p0.total_buckets + MSM_THREADS - 1) / MSM_THREADS;
-  const uint32_t chunks = (p0.buckets_per_window + MSM_RED_K - 1) / MSM_RED_K;
-  const uint32_t blocks_per_window = (chunks + MSM_THREADS - 1) / MSM_THREADS;
-  TailBatch<F> tb;
-  memset(&tb, 0, sizeof(tb));
-  uint32_t max_heavy_all = 1;
-  for (int i = 0; i < count; i++) {
-    const MsmSort& s = *sorts[i];
-    MsmBuckets& b = *bks[i];
-    const uint32_t segs = b.segs;
-    const uint32_t max_heavy = segs / MSM_HEAVY_SPAN + 1;
-    const uint32_t avg_span = (uint32_t)(((uint64_t)segs + p0.total_buckets - 1) / p0.total_buckets);
-    const uint32_t heavy_span = (2 * avg_span > MSM_HEAVY_SPAN) ? 2 * avg_span : MSM_HEAVY_SPAN;
-    if (max_heavy > max_heavy_all) max_heavy_all = max_heavy;
-    b.heavy_count.ensure(16);
-    b.heavy_list.ensure((size_t)max_heavy * 4);
-    b.partials.ensure((size_t)blocks_per_window * p0.key_windows * sizeof(XYZZ<F>));
-    if (!b.heavy_cleared) ARK_CHECK_HIP(hipMemsetAsync(b.heavy_count.p, 0, 4, stream));
-    b.heavy_cleared = false;
-    TailJob<F>& J = tb.j[i];
-    J.offsets = s.offsets.as<uint32_t>();
-    J.counts = s.counts.as<uint32_t>();
-    J.buckets = b.buckets.as<XYZZ<F>>();
-    J.head = b.head.as<XYZZ<F>>();
-    J.head_key = b.head_key.as<uint32_t>();
-    J.tail = b.tail.as<XYZZ<F>>();
-    J.tail_key = b.tail_key.as<uint32_t>();
-    J.heavy_count = b.heavy_count.as<uint32_t>();
-    J.heavy_list = b.heavy_list.as<uint32_t>();
-    J.partials = b.partials.as<XYZZ<F>>();
-    J.out = outs[i];
-    J.seg_len = b.seg_len;
-    J.heavy_span = heavy_span;
-    J.accumulate = 0;
-  }
-  ARK_LAUNCH((msm_merge_batch_kernel<F>), dim3(grid_b, 1, (uint32_t)count), dim3(MSM_THREADS), 0, stream, tb, p0.total_buckets);
-  ARK_CHECK_LAUNCH();
-  const uint32_t grid_h = max_heavy_all < ARK_MSM_HEAVY_GRID ? max_heavy_all : ARK_MSM_HEAVY_GRID;
-  ARK_LAUNCH((msm_merge_heavy_batch_kernel<F>), dim3(grid_h, 1, (uint32_t)count), dim3(MSM_THREADS), 0, stream, tb);
-  ARK_CHECK_LAUNCH();
-  ARK_LAUNCH((msm_reduce_batch_kernel<F>), dim3(blocks_per_window, p0.key_windows, (uint32_t)count), dim3(MSM_THREADS), 0, stream,
-             tb, p0.buckets_per_window);
-  ARK_CHECK_LAUNCH();
-  ARK_LAUNCH((msm_combine_batch_kernel<F>), dim3((uint32_t)count), dim3(64), 0, stream, tb, blocks_per_window, p0.key_windows, p0.c);
-  ARK_CHECK_LAUNCH();
-  return true;
+  if (count < 2) return false;
+  return msm_tails28_launch<F>(ctx, count, sorts, bks, outs, stream);
 }
 
 // Both phases on one stream.

@@ -6,7 +6,7 @@
 // ark355_prove_batch inherit the parent's policy at every call.
 //
 // Three groups:
-//   per proof      SCHED, SCHED_EXPLORE, WAIT_SPIN, WAIT_ADAPT, STREAM_PRIO, DEVICE_FINALIZE, BATCH_TAILS, SIDE_G2_TAILS,
+//   per proof      SCHED, SCHED_EXPLORE, WAIT_SPIN, WAIT_ADAPT, STREAM_PRIO, BATCH_TAILS, SIDE_G2_TAILS,
 //                  SIDE_WM, SIDE_H_TAILS, TRACE_HOST (+ the legacy spellings SERIAL and EPILOGUE_SYNC, which map onto SCHED);
 //                  sharded proofs: DWM_LOOPBACK, RCCL_SELF (window / bucket-ring combining is the `mode` argument of
 //                  ark355_prove_sharded, not a policy)
@@ -40,7 +40,6 @@ struct TunePolicy {
   int32_t wait_spin = 0;          // 1: every wait of a proof inside the HIP runtime (hipEventSynchronize)
   int32_t wait_adapt = 0;         // 1: sleep through half of the shortest recent drain before polling
   int32_t stream_prio = 1;        // feeder streams (witness map, sort, reduction) at the higher stream priority
-  int32_t device_finalize = 0;    // O(1) proof tail on the device instead of the host
   int32_t trace_host = 0;         // host wall-clock phases on stderr
   int32_t sched_explore = 3;      // samples per candidate before SCHED_AUTO latches (0: static default, no exploration)
   int32_t batch_tails = 1;        // one-stream proofs: merge / reduce / combine of the four G1 MSMs as ONE launch each
@@ -90,7 +89,6 @@ inline const TunePolicy::Field* TunePolicy::fields(int* count) {
       ARK_POLICY_FIELD32("WAIT_SPIN", wait_spin),
       ARK_POLICY_FIELD32("WAIT_ADAPT", wait_adapt),
       ARK_POLICY_FIELD32("STREAM_PRIO", stream_prio),
-      ARK_POLICY_FIELD32("DEVICE_FINALIZE", device_finalize),
       ARK_POLICY_FIELD32("TRACE_HOST", trace_host),
       ARK_POLICY_FIELD32("SCHED_EXPLORE", sched_explore),
       ARK_POLICY_FIELD32("BATCH_TAILS", batch_tails),

@@ -209,6 +209,176 @@ static void run_kara(const char* name) {
   printf("%s Karatsuba == schoolbook: ok\n", name);
 }
 
+
+// General additions on 28-bit slots (add28, add28_g2: the arithmetic of the tail kernels, tails28_impl.cuh) against the
+// canonical 32-bit formulas: a pool of points that is summed pairwise at random (so that operands carry every value class
+// a slot can hold: fresh mixed-addition results, sums of sums, negated openings), with P + P, P + (-P), P + O, O + P forced in.
+template <class Curve>
+static void run_add_g1(const char* name) {
+  using Fq = typename Curve::Fq;
+  using P = typename Fq::Params;
+  using F28 = Fp28<P>;
+  using Consts = typename Curve::Consts;
+  Rng rng{0xadd1};
+  Affine<Fq> g;
+  for (int i = 0; i < Fq::N; i++) {
+    g.x.l[i] = Consts::g1_gen_x(i);
+    g.y.l[i] = Consts::g1_gen_y(i);
+  }
+  const size_t NP = 16;
+  std::vector<XYZZ<Fq>> ref(NP);
+  std::vector<Acc28<P>> acc(NP);
+  std::vector<char> emp(NP);
+  auto fresh = [&](size_t i) {
+    uint32_t k[2] = {(uint32_t)rng.next() | 1u, (uint32_t)rng.next()};
+    const Affine<Fq> a = xyzz_to_affine(xyzz_mul_scalar(XYZZ<Fq>::from_affine(g), k, 2));
+    const bool ng = rng.next() & 1;
+    Affine<Fq> q = a;
+    if (ng) q.y = Fq::neg(q.y);
+    ref[i] = XYZZ<Fq>::from_affine(q);
+    acc[i].x = acc[i].y = acc[i].zz = acc[i].zzz = F28::zero();
+    bool e = true;
+    madd28<P>(acc[i], e, F28::from_fp(a.x), F28::from_fp(a.y), ng);       // opens the slot as the accumulation does
+    emp[i] = e;
+  };
+  for (size_t i = 0; i < NP; i++) fresh(i);
+  for (int step = 0; step < 30000; step++) {
+    const size_t i = rng.next() % NP;
+    size_t j = rng.next() % NP;
+    const uint32_t kind = rng.next() % 40;
+    Acc28<P> b = acc[j];
+    bool be = emp[j] != 0;
+    XYZZ<Fq> rb = ref[j];
+    if (kind == 0) {                          // P + P through a slot round trip
+      Slot28<P> s;
+      slot28_put<P>(&s, acc[i], emp[i] != 0);
+      be = slot28_get<P>(&s, b);
+      rb = ref[i];
+    } else if (kind == 1 && !emp[i]) {        // P + (-P)
+      b = acc[i];
+      b.y = F28::from_fp(Fq::neg(F28::to_fp(b.y)));       // canonical: stays inside the slot class y < 2p
+      be = false;
+      rb = XYZZ<Fq>::neg(ref[i]);
+    } else if (kind == 2) {                   // + infinity
+      be = true;
+      rb = XYZZ<Fq>::inf();
+    }
+    bool ae = emp[i] != 0;
+    add28<P>(acc[i], ae, b, be);
+    emp[i] = ae;
+    ref[i] = xyzz_add(ref[i], rb);
+    CHECK(ae == ref[i].is_inf());
+    if (!ae && (step % 7) == 0) {
+      XYZZ<Fq> got{F28::to_fp(acc[i].x), F28::to_fp(acc[i].y), F28::to_fp(acc[i].zz), F28::to_fp(acc[i].zzz)};
+      CHECK(same(xyzz_to_affine(got), xyzz_to_affine(ref[i])));
+    }
+    if (ae || (rng.next() % 64) == 0) fresh(i);
+  }
+  printf("%s G1 add28: ok\n", name);
+}
+
+template <class Curve>
+static void run_add_g2(const char* name) {
+  using Fq = typename Curve::Fq;
+  using Fq2 = typename Curve::Fq2;
+  using P = typename Fq::Params;
+  using F28 = Fp28<P>;
+  using Consts = typename Curve::Consts;
+  Rng rng{0xadd2};
+  Affine<Fq2> g;
+  for (int i = 0; i < Fq::N; i++) {
+    g.x.c0.l[i] = Consts::g2_gen_x0(i);
+    g.x.c1.l[i] = Consts::g2_gen_x1(i);
+    g.y.c0.l[i] = Consts::g2_gen_y0(i);
+    g.y.c1.l[i] = Consts::g2_gen_y1(i);
+  }
+  // the script is generated up front: both lanes of the pair must see the same steps
+  const size_t NP = 8, STEPS = 6000;
+  struct Step {
+    int op;            // 0: fresh(i) from point `a`, negated `ng`; 1: slot i += slot j (kind: 0 plain, 1 itself, 2 its negative, 3 infinity)
+    size_t i, j;
+    int kind;
+    Affine<Fq2> a;
+    bool ng;
+  };
+  std::vector<Step> script;
+  std::vector<XYZZ<Fq2>> ref(NP, XYZZ<Fq2>::inf());
+  std::vector<XYZZ<Fq2>> ref_after;
+  auto gen_fresh = [&](size_t i) {
+    uint32_t k[2] = {(uint32_t)rng.next() | 1u, (uint32_t)rng.next()};
+    Step s{0, i, 0, 0, xyzz_to_affine(xyzz_mul_scalar(XYZZ<Fq2>::from_affine(g), k, 2)), (bool)(rng.next() & 1)};
+    Affine<Fq2> q = s.a;
+    if (s.ng) q.y = Fq2::neg(q.y);
+    ref[i] = XYZZ<Fq2>::from_affine(q);
+    script.push_back(s);
+    ref_after.push_back(ref[i]);
+  };
+  for (size_t i = 0; i < NP; i++) gen_fresh(i);
+  for (size_t t = 0; t < STEPS; t++) {
+    Step s{1, (size_t)(rng.next() % NP), (size_t)(rng.next() % NP), 0, Affine<Fq2>::inf(), false};
+    const uint32_t kind = rng.next() % 30;
+    s.kind = kind == 0 ? 1 : (kind == 1 && !ref[s.i].is_inf()) ? 2 : kind == 2 ? 3 : 0;
+    const XYZZ<Fq2> rb = s.kind == 0 ? ref[s.j] : s.kind == 1 ? ref[s.i] : s.kind == 2 ? XYZZ<Fq2>::neg(ref[s.i]) : XYZZ<Fq2>::inf();
+    ref[s.i] = xyzz_add(ref[s.i], rb);
+    script.push_back(s);
+    ref_after.push_back(ref[s.i]);
+    if (ref[s.i].is_inf() || (rng.next() % 48) == 0) gen_fresh(s.i);
+  }
+  std::vector<XYZZ<Fq2>> got_after(script.size());
+  std::vector<char> got_empty(script.size());
+  emu::launch(dim3(1), dim3(2), 0, [&]() {
+    const uint32_t par = threadIdx.x & 1u;
+    std::vector<Acc28<P>> acc(NP);
+    std::vector<char> emp(NP, 1);
+    for (size_t t = 0; t < script.size(); t++) {
+      const Step& s = script[t];
+      if (s.op == 0) {
+        acc[s.i].x = acc[s.i].y = acc[s.i].zz = acc[s.i].zzz = F28::zero();
+        bool e = true;
+        madd28_g2<P>(acc[s.i], e, F28::from_fp(par ? s.a.x.c1 : s.a.x.c0), F28::from_fp(par ? s.a.y.c1 : s.a.y.c0), s.ng);
+        emp[s.i] = e;
+      } else {
+        Acc28<P> b = acc[s.j];
+        bool be = emp[s.j] != 0;
+        if (s.kind == 1) {
+          Slot28G2<P> slot;                    // (each lane writes and reads its own half)
+          slot28_put<P>(&slot.half[par], acc[s.i], emp[s.i] != 0);
+          const bool z = slot28_get<P>(&slot.half[par], b);
+          be = Pair28<P>::both(z);
+        } else if (s.kind == 2) {
+          b = acc[s.i];
+          b.y = F28::from_fp(Fq::neg(F28::to_fp(b.y)));       // canonical: stays inside the slot class y < 2p
+          be = false;
+        } else if (s.kind == 3) {
+          be = true;
+        }
+        bool ae = emp[s.i] != 0;
+        add28_g2<P>(acc[s.i], ae, b, be);
+        emp[s.i] = ae;
+      }
+      if (par == 0) got_empty[t] = emp[s.i];
+      if (!emp[s.i] && (acc[s.i].x.l[F28::N - 1] > 8u * F28::template kp<1>(F28::N - 1) || acc[s.i].y.l[F28::N - 1] > 3u * F28::template kp<1>(F28::N - 1))) {
+        fprintf(stderr, "slot class violated after step %zu: op %d kind %d (x top %08x, y top %08x)\n", t, s.op, s.kind,
+                acc[s.i].x.l[F28::N - 1], acc[s.i].y.l[F28::N - 1]);
+        exit(1);
+      }
+      if (!emp[s.i]) {
+        Fq* d = reinterpret_cast<Fq*>(&got_after[t]);
+        d[0 + par] = F28::to_fp(acc[s.i].x);
+        d[2 + par] = F28::to_fp(acc[s.i].y);
+        d[4 + par] = F28::to_fp(acc[s.i].zz);
+        d[6 + par] = F28::to_fp(acc[s.i].zzz);
+      }
+    }
+  });
+  for (size_t t = 0; t < script.size(); t++) {
+    CHECK((got_empty[t] != 0) == ref_after[t].is_inf());
+    if (!ref_after[t].is_inf() && ((t % 5) == 0 || t + 1 == script.size()))
+      CHECK(same(xyzz_to_affine(got_after[t]), xyzz_to_affine(ref_after[t])));
+  }
+  printf("%s G2 add28 (lane pair): ok\n", name);
+}
+
 int main() {
   run_kara<BlsFq28>("bls12_381");
   run_kara<BnFq28>("bn254");
@@ -216,6 +386,10 @@ int main() {
   run_g1<BnCurve>("bn254");
   run_g2<BlsCurve>("bls12_381");
   run_g2<BnCurve>("bn254");
+  run_add_g1<BlsCurve>("bls12_381");
+  run_add_g1<BnCurve>("bn254");
+  run_add_g2<BlsCurve>("bls12_381");
+  run_add_g2<BnCurve>("bn254");
   printf("madd28 stress: all chains agree with the 32-bit formulas\n");
   return 0;
 }

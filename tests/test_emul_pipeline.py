@@ -160,14 +160,6 @@ def test_measured_schedule_choice_explores_then_latches(emul_lib):
         emul_lib.ctx_destroy(ctx)
 
 
-def test_prove_device_finalize_kernel_gives_same_bytes(emul_lib, emul_ctx, emul_policy):
-    """ARK355_DEVICE_FINALIZE=1 keeps s*A + r*B1 and the normalisations in groth16_finalize_kernel."""
-    emul_policy.setenv("ARK355_DEVICE_FINALIZE", "1")
-    C = BN254
-    A, B, Cm, z, ell = S.mulchain_direct(C.r, 5)
-    pc.prove_case(emul_lib, emul_ctx, C, A, B, Cm, z, ell)
-
-
 def test_resident_bases_partial_and_sum(emul_lib, emul_ctx):
     """ark355_bases_load (window tables) + msm over a PREFIX of the rows + XYZZ partial / ark355_xyzz_sum:
     the pieces the multi-GPU sharded MSM is made of."""
