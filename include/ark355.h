@@ -76,6 +76,10 @@ int32_t ark355_sizes(int32_t curve, uint32_t what[4]);
  *                 itself) -- read when a key or base set is loaded THROUGH this context;
  *   per call      MSM_SEG, ACC_THREADS (workgroup size of the LDS-free accumulation kernels: 64 / 128 / 256; 0 [default]: 64 for a
  *                 proof alone on one stream, else 256), MSM_TWO_LEVEL_MIN, NTT_RMAX, NTT_DIRECT_MAX, NTT_NOFUSE (A/B and test knobs).
+ *                 CHECK_SATISFIED (default 0: a proof is computed for whatever z is handed in, as ark-groth16's release build does;
+ *                 1: ark355_prove / _dev / _batch also compare a_i b_i with c_i on the rows the witness map computes anyway -- the
+ *                 check ark-groth16 runs under debug_assert!(cs.is_satisfied()) -- and return ARK355_E_UNSATISFIABLE, with the index
+ *                 of the first unsatisfied constraint in ark355_last_error, instead of a proof that cannot verify).
  * ARK355_EINVAL for an unknown name.  ark355_prove_batch runs its worker contexts under the caller's policy.
  * (No counterpart in the reference: ark-groth16 has no runtime knobs; rayon's thread count is its only one.) */
 int32_t ark355_ctx_set_policy(ark355_ctx* ctx, const char* name, int64_t value);

@@ -82,10 +82,27 @@ pub fn with_ctx<T>(f: impl FnOnce(*mut ffi::ark355_ctx) -> Result<T, Mi355xError
             if rc != ffi::ARK355_OK {
                 return Err(Mi355xError::from_code(rc, "ark355_ctx_create".into()));
             }
-            *c = Some((dev, Ctx(raw)));
+            let ctx = Ctx(raw);
+            if !trust_cache() {
+                // every proof of this thread also checks a_i b_i = c_i on the device (include/ark355.h, policy CHECK_SATISFIED):
+                // what makes the witness-only fast path safe and the outcome independent of the cache's state (lib.rs `prepare`)
+                let rc = unsafe { ffi::ark355_ctx_set_policy(ctx.0, b"CHECK_SATISFIED\0".as_ptr() as *const core::ffi::c_char, 1) };
+                if rc != ffi::ARK355_OK {
+                    return Err(Mi355xError::from_code(rc, "ark355_ctx_set_policy(CHECK_SATISFIED)".into()));
+                }
+            }
+            *c = Some((dev, ctx));
         }
         f(c.as_ref().unwrap().1 .0)
     })
+}
+
+/// `ARK_MI355X_TRUST_CACHE=1`: no satisfaction check on the device -- a proof is computed for whatever assignment the
+/// circuit yields, as `ark-groth16`'s release build does.  For hosts that prove ONE circuit per key: with it, a circuit type
+/// that builds different systems from call to call silently gets proofs over the wrong matrices.
+pub fn trust_cache() -> bool {
+    static TRUST: OnceLock<bool> = OnceLock::new();
+    *TRUST.get_or_init(|| std::env::var("ARK_MI355X_TRUST_CACHE").map(|v| v == "1").unwrap_or(false))
 }
 
 /// Resident key + matrices of one circuit.
@@ -152,6 +169,10 @@ pub type MatHash = [u8; 32];
 /// as the last proof holding its `Arc` finishes.
 struct Registry {
     entries: Vec<(Key, Arc<Resident>)>,
+    /// (fingerprint, circuit type) pairs that lost the witness-only fast path: the library refused an assignment the type
+    /// produced in witness-only mode, so either that circuit was unsatisfied or the type builds more than one system.
+    /// Bounded like the entries (oldest dropped first).
+    unstable: Vec<(Key, &'static str)>,
 }
 impl Registry {
     /// Every entry under this fingerprint (several circuits may share one, see `fingerprint`), most recently used last.
@@ -173,6 +194,7 @@ impl Registry {
     }
     fn remove(&mut self, k: &Key) {
         self.entries.retain(|(key, _)| key != k);
+        self.unstable.retain(|(key, _)| key != k);
     }
 }
 /// `ARK_MI355X_MAX_RESIDENT_KEYS` (default 4; at least 1).
@@ -182,7 +204,7 @@ pub fn max_resident_keys() -> usize {
 }
 fn registry() -> &'static Mutex<Registry> {
     static R: OnceLock<Mutex<Registry>> = OnceLock::new();
-    R.get_or_init(|| Mutex::new(Registry { entries: Vec::new() }))
+    R.get_or_init(|| Mutex::new(Registry { entries: Vec::new(), unstable: Vec::new() }))
 }
 
 /// Fingerprint of a proving key, by CONTENT only: the verifying key, the two prover-only points, the query lengths and
@@ -196,9 +218,9 @@ fn registry() -> &'static Mutex<Registry> {
 /// domain only) and every length; their `a / b / l_query` differ only at the variables of the constraints that differ -- a
 /// handful of elements out of millions, which 1024 samples miss with probability ~99.9 %.  What identifies a cache entry
 /// is therefore the fingerprint AND the hash of the matrices it was loaded with (`matrices_hash`); several entries may
-/// share a fingerprint.  The witness-only fast path (`Groth16Mi355x::prepare`) is open only to circuit TYPES whose matrices
-/// were compared with the entry once, and every use of it re-checks the assignment against the cached matrices on the
-/// device (`confirm_hit`).
+/// share a fingerprint.  The witness-only fast path (`Mi355xGroth16::prepare`) is open only to circuit TYPES whose matrices
+/// were compared with the entry once, and every proof -- fast path or not -- has its assignment checked against the
+/// matrices on the device as part of the witness map (policy `CHECK_SATISFIED`, set in `with_ctx`).
 pub fn fingerprint<E: Mi355xCurve>(pk: &ProvingKey<E>) -> Key {
     let mut bytes = Vec::new();
     pk.vk.serialize_compressed(&mut bytes).expect("vk serialization");
@@ -238,9 +260,33 @@ pub fn fingerprint<E: Mi355xCurve>(pk: &ProvingKey<E>) -> Key {
 }
 
 /// The most recently used entry under this key's fingerprint (callers that hold ONE circuit per key: `prove_assignments`,
-/// the pool).  `SNARK::prove` goes through `candidates` and confirms the entry against its circuit.
+/// the pool); the entry is marked as used.  `SNARK::prove` goes through `candidates` and confirms the entry against its circuit.
 pub fn lookup<E: Mi355xCurve>(pk: &ProvingKey<E>) -> Option<Arc<Resident>> {
-    registry().lock().unwrap().get_all(&fingerprint(pk)).pop()
+    let k = fingerprint(pk);
+    let mut reg = registry().lock().unwrap();
+    let hit = reg.get_all(&k).pop();
+    if let Some(r) = &hit {
+        reg.touch(&k, r);
+    }
+    hit
+}
+
+/// Has `circuit_type` lost the witness-only fast path for keys with this fingerprint (`mark_unstable`)?
+pub fn is_unstable<E: Mi355xCurve>(pk: &ProvingKey<E>, circuit_type: &'static str) -> bool {
+    let k = fingerprint(pk);
+    registry().lock().unwrap().unstable.iter().any(|(key, t)| key == &k && *t == circuit_type)
+}
+
+/// `circuit_type` takes the full path (matrices rebuilt and compared) for keys with this fingerprint from now on.
+pub fn mark_unstable<E: Mi355xCurve>(pk: &ProvingKey<E>, circuit_type: &'static str) {
+    let k = fingerprint(pk);
+    let mut reg = registry().lock().unwrap();
+    if !reg.unstable.iter().any(|(key, t)| key == &k && *t == circuit_type) {
+        if reg.unstable.len() >= 64 {
+            reg.unstable.remove(0);
+        }
+        reg.unstable.push((k, circuit_type));
+    }
 }
 
 /// Every entry whose key has this key's fingerprint.
@@ -253,15 +299,21 @@ pub fn touch<E: Mi355xCurve>(pk: &ProvingKey<E>, res: &Arc<Resident>) {
     registry().lock().unwrap().touch(&fingerprint(pk), res);
 }
 
-/// Hash of the R1CS matrices (rows, columns, canonical coefficients) and the constraint count.
+/// Hash of the R1CS matrices (rows, columns, canonical coefficients) and the constraint count: what tells two cache entries
+/// under one fingerprint apart.  Not a cryptographic hash (the inputs are the caller's own circuits, not an adversary's), but
+/// every word reaches all four 64-bit lanes -- each lane absorbs the word under its own odd multiplier and is stirred by a
+/// splitmix64 finaliser -- so the 256-bit value does not degenerate into four independent hashes of a quarter of the data.
 pub fn matrices_hash<F: PrimeField>(matrices: &[Matrix<F>], num_constraints: usize) -> MatHash {
+    const MUL: [u64; 4] = [0x9e3779b97f4a7c15, 0xbf58476d1ce4e5b9, 0x94d049bb133111eb, 0xd6e8feb86659fd93];
     let mut lanes = [0xcbf29ce484222325u64, 0x84222325cbf29ce4, 0x9e3779b97f4a7c15, 0xd6e8feb86659fd93];
-    let mut n = 0usize;
     let mut feed = |w: u64| {
-        let l = &mut lanes[n & 3];
-        *l = (*l ^ w).wrapping_mul(0x100000001b3);
-        *l ^= *l >> 29;
-        n += 1;
+        for (l, m) in lanes.iter_mut().zip(MUL.iter()) {
+            let mut x = (*l ^ w).wrapping_mul(*m);
+            x ^= x >> 30;
+            x = x.wrapping_mul(0xbf58476d1ce4e5b9);
+            x ^= x >> 27;
+            *l = x.rotate_left(23).wrapping_add(w);
+        }
     };
     feed(num_constraints as u64);
     feed(matrices.len() as u64);
@@ -282,26 +334,6 @@ pub fn matrices_hash<F: PrimeField>(matrices: &[Matrix<F>], num_constraints: usi
         out[8 * i..8 * i + 8].copy_from_slice(&l.to_le_bytes());
     }
     out
-}
-
-/// Does the full assignment `z` of the caller's circuit satisfy the matrices of the cached entry (one SpMV + compare on the
-/// device, `ark355_is_satisfied`)?  `false`: the entry belongs to another circuit, or the circuit is not satisfied by its
-/// own assignment.  `ARK_MI355X_TRUST_CACHE=1` skips the check (one H2D copy of z and ~0.2 ms of kernels per proof at
-/// n = 2^20) for hosts that prove one circuit per key.
-pub fn confirm_hit<F: PrimeField>(res: &Resident, z: &[F]) -> Result<bool, Mi355xError> {
-    static TRUST: OnceLock<bool> = OnceLock::new();
-    if *TRUST.get_or_init(|| std::env::var("ARK_MI355X_TRUST_CACHE").map(|v| v == "1").unwrap_or(false)) {
-        return Ok(true);
-    }
-    if z.len() != res.num_instance + res.num_witness {
-        return Ok(false);
-    }
-    with_ctx(|ctx| {
-        let zi = scalars_image(z);
-        let mut first_bad: i64 = -1;
-        check(ctx, unsafe { ffi::ark355_is_satisfied(ctx, res.r1cs, zi.as_ptr(), z.len() as u64, &mut first_bad) })?;
-        Ok(first_bad < 0)
-    })
 }
 
 /// Release the HBM of a key (window tables: ~15 GB at n = 2^20) once no proof uses it any more.

@@ -21,9 +21,6 @@ pub enum Mi355xError {
     Rccl(String),
     /// ARK355_ENODEV: no MI355X visible to the process.
     NoDevice,
-    /// The shim's resident-key cache held an entry that this circuit's assignment does not satisfy (see
-    /// `cache::fingerprint`); nothing was proven, the entry is no longer trusted for this circuit type.
-    CacheMismatch(String),
     /// A code this version of the shim does not know.
     Unknown(i32, String),
 }
@@ -60,7 +57,6 @@ impl fmt::Display for Mi355xError {
             Self::Hip(m) => write!(f, "libark355: HIP error: {m}"),
             Self::Rccl(m) => write!(f, "libark355: RCCL error: {m}"),
             Self::NoDevice => write!(f, "libark355: no MI355X device"),
-            Self::CacheMismatch(m) => write!(f, "ark-mi355x: resident-key cache: {m}"),
             Self::Unknown(rc, m) => write!(f, "libark355: error {rc}: {m}"),
         }
     }

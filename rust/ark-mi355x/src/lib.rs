@@ -22,7 +22,7 @@ use ark_relations::gr1cs::{
 use ark_snark::{CircuitSpecificSetupSNARK, SNARK};
 use ark_std::rand::{CryptoRng, RngCore};
 
-pub use cache::{evict, lookup, set_device, Resident};
+pub use cache::{evict, lookup, matrices_hash, set_device, trust_cache, Resident};
 pub use error::Mi355xError;
 pub use marshal::{layout_self_test, Mi355xCurve};
 pub use pool::{PinnedAssignment, ProverPool, Ticket};
@@ -34,6 +34,15 @@ pub struct Mi355xGroth16<E>(PhantomData<E>);
 struct Synthesized<F: PrimeField> {
     cs: ConstraintSystemRef<F>,
     z: Vec<F>,
+}
+
+/// What `prepare` hands to the proving call: the resident handles, the full assignment, whether the witness-only fast path
+/// produced it, and the circuit type (for `refused`).
+struct Prepared<F: PrimeField> {
+    res: std::sync::Arc<cache::Resident>,
+    z: Vec<F>,
+    fast_path: bool,
+    tname: &'static str,
 }
 
 /// Run the circuit.  With the matrices already resident the constraint system is put in witness-only mode
@@ -60,30 +69,36 @@ where
     <P1::BaseField as Field>::BasePrimeField: PrimeField,
     <P2::BaseField as Field>::BasePrimeField: PrimeField,
 {
-    /// Synthesis + residency for one proof: returns the handles and the full assignment.
-    fn prepare<C: ConstraintSynthesizer<E::ScalarField>>(
-        pk: &ProvingKey<E>,
-        circuit: C,
-    ) -> Result<(std::sync::Arc<cache::Resident>, Vec<E::ScalarField>), Mi355xError> {
+    /// Synthesis + residency for one proof: the handles, the full assignment, and whether the witness-only fast path
+    /// produced it (`Prepared`).
+    ///
+    /// What a caller observes does not depend on the state of the cache.  Every proof runs with the library's
+    /// policy `CHECK_SATISFIED` (set when the thread's context is created, `cache::with_ctx`): the rows `a_i b_i = c_i` are
+    /// compared on the device as part of the witness map, at no extra copy of the assignment, and an assignment the matrices
+    /// do not accept comes back as `SynthesisError::Unsatisfiable` -- on the first call of a key (full path: the matrices are
+    /// the caller's own) exactly as on every later one (fast path: the matrices are the cached entry's).  That is the check
+    /// `ark-groth16` makes under `debug_assert!(cs.is_satisfied())`; its release build returns a proof that cannot verify
+    /// instead, and `ARK_MI355X_TRUST_CACHE=1` restores that behaviour (no check at all) for hosts that prove one circuit
+    /// per key.
+    fn prepare<C: ConstraintSynthesizer<E::ScalarField>>(pk: &ProvingKey<E>, circuit: C) -> Result<Prepared<E::ScalarField>, Mi355xError> {
         // Entries are found by the key's SAMPLED fingerprint, which two circuits can share (cache::fingerprint): an entry is
-        // used for the witness-only fast path only by circuit types whose matrices were compared with it once, and every such
-        // use re-checks the assignment against the cached matrices on the device.
+        // used for the witness-only fast path only by circuit types whose matrices were compared with it once and that have
+        // never been caught building a different system afterwards (`cache::is_unstable`).
         let tname = core::any::type_name::<C>();
         let cands = cache::candidates(pk);
-        if let Some(res) = cands.iter().find(|r| r.is_confirmed(tname)) {
-            let syn = synthesize(circuit, true)?;
-            if cache::confirm_hit(res, &syn.z)? {
-                cache::touch(pk, res);
-                return Ok((res.clone(), syn.z));
+        if !cache::is_unstable(pk, tname) {
+            if let Some(res) = cands.iter().find(|r| r.is_confirmed(tname)) {
+                let syn = synthesize(circuit, true)?;
+                if syn.z.len() == res.num_instance + res.num_witness {
+                    cache::touch(pk, res);
+                    return Ok(Prepared { res: res.clone(), z: syn.z, fast_path: true, tname });
+                }
+                // A different number of variables: this type builds more than one system.  The circuit is consumed, so this
+                // proof cannot be redone here; from now on the type takes the full path.
+                cache::mark_unstable(pk, tname);
+                res.unconfirm(tname);
+                return Err(Mi355xError::Synthesis(SynthesisError::Unsatisfiable));
             }
-            // The same circuit TYPE produced a system (or an assignment) the cached matrices do not accept; the circuit is
-            // consumed, so this proof cannot be redone here.  The next call takes the full path.
-            res.unconfirm(tname);
-            return Err(Mi355xError::CacheMismatch(format!(
-                "the assignment of `{tname}` does not satisfy the matrices cached for this proving key: either the circuit is \
-                 unsatisfied, or this type builds different constraint systems from call to call; retry (the next call \
-                 rebuilds the matrices)"
-            )));
         }
         let syn = synthesize(circuit, false)?;
         let mats = syn.cs.to_matrices()?; // constraint_system.rs:768
@@ -92,7 +107,7 @@ where
         if let Some(res) = cands.iter().find(|r| r.matrices_hash == mh) {
             res.confirm(tname);
             cache::touch(pk, res);
-            return Ok((res.clone(), syn.z));
+            return Ok(Prepared { res: res.clone(), z: syn.z, fast_path: false, tname });
         }
         let res = cache::load::<E, P1, P2>(
             pk,
@@ -102,7 +117,20 @@ where
             syn.cs.num_witness_variables(),
         )?;
         res.confirm(tname);
-        Ok((res, syn.z))
+        Ok(Prepared { res, z: syn.z, fast_path: false, tname })
+    }
+
+    /// The library refused an assignment (`CHECK_SATISFIED`).  On the fast path the shim cannot tell an unsatisfied circuit
+    /// from a circuit TYPE that builds different systems from call to call (the circuit has been consumed in witness-only
+    /// mode): the type loses the fast path for this key for good -- its later proofs rebuild and compare the matrices -- so a
+    /// type that alternates between two systems fails at most once, and a genuinely unsatisfied circuit fails every time,
+    /// cached or not.
+    fn refused(pk: &ProvingKey<E>, prep: &Prepared<E::ScalarField>, e: Mi355xError) -> Mi355xError {
+        if prep.fast_path && matches!(e, Mi355xError::Synthesis(SynthesisError::Unsatisfiable)) {
+            cache::mark_unstable(pk, prep.tname);
+            prep.res.unconfirm(prep.tname);
+        }
+        e
     }
 
     /// `create_proof_with_reduction`'s counterpart: explicit zero-knowledge randomisers (parity tests).
@@ -112,15 +140,16 @@ where
         r: E::ScalarField,
         s: E::ScalarField,
     ) -> Result<Proof<E>, Mi355xError> {
-        let (res, z) = Self::prepare(pk, circuit)?;
+        let prep = Self::prepare(pk, circuit)?;
         let (rb, sb) = (marshal::canonical_32(&r), marshal::canonical_32(&s));
         let mut raw = ffi::ark355_proof_raw { a: [0; 96], b: [0; 192], c: [0; 96] };
         cache::with_ctx(|ctx| {
-            let zi = marshal::scalars_image(&z);
+            let zi = marshal::scalars_image(&prep.z);
             cache::check(ctx, unsafe {
-                ffi::ark355_prove(ctx, res.pk, res.r1cs, zi.as_ptr(), z.len() as u64, rb.as_ptr(), sb.as_ptr(), &mut raw)
+                ffi::ark355_prove(ctx, prep.res.pk, prep.res.r1cs, zi.as_ptr(), prep.z.len() as u64, rb.as_ptr(), sb.as_ptr(), &mut raw)
             })
-        })?;
+        })
+        .map_err(|e| Self::refused(pk, &prep, e))?;
         Ok(marshal::proof_from_raw::<E, P1, P2>(&raw))
     }
 
@@ -134,15 +163,25 @@ where
         inflight: u32,
     ) -> Result<Vec<Proof<E>>, Mi355xError> {
         let mut zs = Vec::with_capacity(circuits.len());
-        let mut resident = None;
+        let mut last: Option<Prepared<E::ScalarField>> = None;
+        let mut any_fast = false;
         for c in circuits {
-            let (res, z) = Self::prepare(pk, c)?;
-            resident = Some(res);
-            zs.push(z);
+            let mut prep = Self::prepare(pk, c)?;
+            if let Some(prev) = &last {
+                if !std::sync::Arc::ptr_eq(&prev.res, &prep.res) {
+                    return Err(Mi355xError::InvalidArgument("prove_batch: the circuits do not share one constraint system".into()));
+                }
+            }
+            any_fast |= prep.fast_path;
+            zs.push(core::mem::take(&mut prep.z));
+            last = Some(prep);
         }
-        match resident {
+        match last {
             None => Ok(Vec::new()),
-            Some(res) => Self::prove_assignments(&res, &zs, rng, inflight),
+            Some(mut prep) => {
+                prep.fast_path = any_fast;
+                Self::prove_assignments(&prep.res, &zs, rng, inflight).map_err(|e| Self::refused(pk, &prep, e))
+            }
         }
     }
 

@@ -520,6 +520,9 @@ static void prove_run(ark355_ctx* ctx, ProverScratch& sc, const PkDev& pk, const
   hipStream_t sW = one_stream ? (side_wm ? sc.sW : sM) : sc.sW, sS = one_stream ? sM : sc.sS, sA = sM, sR = one_stream ? sM : sc.sR;
   hipStream_t sSH = side_wm ? sc.sW : sS;            // the stream the sort of h runs on
   const uint64_t m = pk.m, ell = pk.ell;
+  // policy CHECK_SATISFIED: whole proofs of a whole key only (a rank of a sharded proof sees 1/G of the rows, and the ranks of a
+  // collective must not disagree on its outcome)
+  const bool check_sat = pol.check_satisfied != 0 && !cm && !partials_out && pk.shard_count <= 1;
   if (cm && cm->world > 1) {
     // Every rank must have planned the same window size and table stride for its shard: the bucket-level exchange adds
     // bucket arrays of different ranks element by element.  The planners are deterministic functions of the key's
@@ -613,7 +616,7 @@ static void prove_run(ark355_ctx* ctx, ProverScratch& sc, const PkDev& pk, const
         fprintf(stderr, "[ark355] witness map distributed over %u ranks (rank %u: N / G = %llu elements per vector)%s\n", pk.shard_count,
                 pk.shard_index, (unsigned long long)(pk.N / pk.shard_count), cm ? "" : " -- LOOPBACK exchange, timing only");
     } else {
-      d_h = witness_map_run<Curve>(ctx, r1, sc.zx.p, sc.ws, sW);
+      d_h = witness_map_run<Curve>(ctx, r1, sc.zx.p, sc.ws, sW, check_sat);
       if (pk.h_dist) {
         // a key shard in the distributed layout under the replicated map: pick this rank's coefficients out of h
         const uint64_t M = pk.h_cnt;
@@ -770,8 +773,11 @@ static void prove_run(ark355_ctx* ctx, ProverScratch& sc, const PkDev& pk, const
     // The proof's last copy: the partial sums of the five MSMs (~15 KB at c = 17) into page-locked memory; the host then runs the
     // Horner pass of every bucket reduction and the O(1) tail (ProofParts::finish, finalize_host).
     const size_t psz = 4 * sizeof(XYZZ<Fq>) + sizeof(XYZZ<Fq2>);
-    uint8_t* land = static_cast<uint8_t*>(sc.pinned(parts.bytes + (cm ? psz * (size_t)(cm->world + 1) : 0)));
+    uint8_t* land = static_cast<uint8_t*>(sc.pinned(parts.bytes + 8 + (cm ? psz * (size_t)(cm->world + 1) : 0)));
     ARK_CHECK_HIP(hipMemcpyAsync(land, res_base, parts.bytes, hipMemcpyDeviceToHost, sR));
+    uint8_t* const land_sat = land + parts.bytes + (cm ? psz * (size_t)(cm->world + 1) : 0);
+    // (sR has everything of the witness-map stream behind it: the H accumulation waited for the sort of h, which waited for h)
+    if (check_sat) ARK_CHECK_HIP(hipMemcpyAsync(land_sat, sc.ws.first_bad.p, 8, hipMemcpyDeviceToHost, sR));
     ARK_CHECK_HIP(hipEventRecord(ev[E_END], sR));
     t_launched = since(t_enter);
     bool overslept = false;
@@ -863,6 +869,16 @@ static void prove_run(ark355_ctx* ctx, ProverScratch& sc, const PkDev& pk, const
     ctx->acc_ms = acc_ms;
     ctx->acc_launches = 5;
     ctx->acc_points = pts;
+    if (check_sat) {
+      unsigned long long fb;
+      memcpy(&fb, land_sat, 8);
+      if (fb != ~0ull) {
+        if (out) memset(out, 0, sizeof(*out));
+        char msg[160];
+        snprintf(msg, sizeof(msg), "constraint %llu is not satisfied by the assignment (policy CHECK_SATISFIED; the first of them)", fb);
+        throw HipError{ARK355_E_UNSATISFIABLE, msg};
+      }
+    }
   }
 }
 

@@ -49,6 +49,8 @@ struct NttTables {
   DevBuf g_lo, g_hi, gi_lo, gi_hi;     // g^j ; g^-j / N
   DevBuf seam;                         // g^j / N, j < N (the seam of the fused inverse -> coset kernel)
   DevBuf n_inv;                        // 1/N
+  DevBuf gz_hi, zconst;                // the quotient step of the witness map (ntt_quotient_tables): gi_hi scaled by 1 / (g^N - 1);
+                                       // zconst[0] = 1 / (g^N - 1), zconst[1] = that / N
   DevBuf tw_r[2][10];                  // [inverse][r]: w_R^e, e < R/2   (in-tile butterflies)
   std::map<uint32_t, DevBuf> direct;   // (inverse << 16 | s_log << 8 | r) -> w^(s p k), index (p << r) | k
   std::mutex mu;                       // the lazily built members (tw_r, direct, seam): contexts of one device share a set
@@ -493,6 +495,28 @@ static const Fr* ntt_seam_table(NttTables* t) {
   return t->seam.as<Fr>();
 }
 
+// The constants of the witness map's last step, h_k = (rho_k - c_k) / (g^N - 1) with rho = the inverse coset transform of
+// a' b' (witness_impl.cuh): the high table of g^-k / N with 1 / (g^N - 1) folded in (the low table stays gi_lo), and the
+// two constants a coefficient vector of c is scaled with (c as coefficients: zconst[0]; c as N c_k, an inverse transform
+// without its 1/N: zconst[1]).
+template <class Fr>
+static void ntt_quotient_tables(NttTables* t, const Fr** gz_hi, const Fr** zconst) {
+  std::lock_guard<std::mutex> lk(t->mu);
+  if (!t->gz_hi.p) {
+    using P = typename Fr::Params;
+    Fr n_inv;
+    ARK_CHECK_HIP(hipMemcpy(&n_inv, t->n_inv.p, sizeof(Fr), hipMemcpyDeviceToHost));
+    const Fr zinv = Fr::inv(Fr::sub(fr_pow2k(fr_from_params<Fr>(&P::gen), t->log_n), Fr::one()));
+    const Fr zc[2] = {zinv, Fr::mul(zinv, n_inv)};
+    t->zconst.alloc(sizeof(zc));
+    ARK_CHECK_HIP(hipMemcpy(t->zconst.p, zc, sizeof(zc), hipMemcpyHostToDevice));
+    const uint32_t hi_bits = t->log_n - t->lo_bits;
+    upload_powers(t->gz_hi, fr_pow2k(fr_from_params<Fr>(&P::gen_inv), t->lo_bits), 1ull << hi_bits, zc[1]);
+  }
+  *gz_hi = t->gz_hi.as<Fr>();
+  *zconst = t->zconst.as<Fr>();
+}
+
 // w^(s p k) for p < N/(s R), k < R at index (p << r) | k; nullptr when the table would exceed 2^NTT_DIRECT_MAX_LOG entries
 template <class Fr>
 static const Fr* ntt_direct_table(const TunePolicy& pol, NttTables* t, uint32_t s_log, uint32_t r, bool inverse) {
@@ -769,10 +793,17 @@ static void* ntt_passes(ark355_ctx* ctx, void* data, void* scratch, uint32_t log
 // batch > 1: `batch` vectors of the same length, vector y at data + y * batch_stride with its ping-pong partner at
 // scratch + y * batch_stride (elements), every pass ONE launch over all of them (the witness map's a, b, c: 15 dispatches
 // become 5, and a pass fills the chip three times as long); the result of vector y sits at (return value) + y * batch_stride.
+// tail > 0: the LAST `tail` vectors of the batch stop after the inverse transform (the witness map's c, whose coset
+// evaluations nobody needs: witness_impl.cuh).  *tail_res = where the first of them ended up (data or scratch side, same
+// stride), *tail_scaled = whether its 1/N has been applied (the fused path leaves N x the coefficients: the factor is folded
+// into the caller's next step instead of costing a pass of its own).
 template <class Curve>
 static void* ntt_inverse_then_coset(ark355_ctx* ctx, void* data, void* scratch, uint32_t log_n, hipStream_t stream,
-                                    uint32_t batch = 1, uint64_t batch_stride = 0) {
+                                    uint32_t batch = 1, uint64_t batch_stride = 0, uint32_t tail = 0, void** tail_res = nullptr,
+                                    bool* tail_scaled = nullptr) {
   using Fr = typename Curve::Fr;
+  ARK_REQUIRE(tail < batch && (tail == 0 || (tail_res && tail_scaled)), ARK355_EINVAL, "ntt_inverse_then_coset: bad tail");
+  const uint32_t full = batch - tail;
   const std::vector<uint32_t> radices = log_n >= 3 ? ntt_radices(ctx->policy, log_n) : std::vector<uint32_t>();
   // the seam kernel exists for first/last radices 2^5 .. 2^9 (every domain of 2^10 points or more with matching ends);
   // tests lower the bound through policy NTT_RMAX and then use radices < 6: those take the unfused path
@@ -783,6 +814,13 @@ static void* ntt_inverse_then_coset(ark355_ctx* ctx, void* data, void* scratch, 
       void* cur = (Fr*)data + (uint64_t)y * batch_stride;
       void* oth = (Fr*)scratch + (uint64_t)y * batch_stride;
       void* res = ntt_run<Curve>(ctx, cur, oth, log_n, /*inverse=*/true, /*coset=*/false, stream);
+      if (y >= full) {
+        if (y == full) {
+          *tail_res = res;
+          *tail_scaled = true;
+        }
+        continue;
+      }
       if (res != cur) { oth = cur; cur = res; }
       res = ntt_run<Curve>(ctx, cur, oth, log_n, /*inverse=*/false, /*coset=*/true, stream);
       if (y == 0) first = res;
@@ -826,14 +864,23 @@ static void* ntt_inverse_then_coset(ark355_ctx* ctx, void* data, void* scratch, 
     b.out = dst;
     const Fr* seam = ntt_seam_table<Fr>(t);
     switch (radices[0]) {      // instantiated for the radices a fused transform can start with (log_n >= NTT_SEAM_MIN_LOG)
-      case 5: ntt_launch_seam<Fr, 5>(a, b, seam, stream, batch); break;
-      case 6: ntt_launch_seam<Fr, 6>(a, b, seam, stream, batch); break;
-      case 7: ntt_launch_seam<Fr, 7>(a, b, seam, stream, batch); break;
-      case 8: ntt_launch_seam<Fr, 8>(a, b, seam, stream, batch); break;
-      case 9: ntt_launch_seam<Fr, 9>(a, b, seam, stream, batch); break;
+      case 5: ntt_launch_seam<Fr, 5>(a, b, seam, stream, full); break;
+      case 6: ntt_launch_seam<Fr, 6>(a, b, seam, stream, full); break;
+      case 7: ntt_launch_seam<Fr, 7>(a, b, seam, stream, full); break;
+      case 8: ntt_launch_seam<Fr, 8>(a, b, seam, stream, full); break;
+      case 9: ntt_launch_seam<Fr, 9>(a, b, seam, stream, full); break;
       default: throw HipError{ARK355_EINVAL, "no seam kernel for this radix"};
     }
-    ntt_twiddle_fallback<Fr>(b, radices[0], stream, batch);
+    ntt_twiddle_fallback<Fr>(b, radices[0], stream, full);
+    if (tail) {
+      // the vectors that stop here: the last inverse pass as a plain pass (no inter-pass twiddle: p == 0), unscaled
+      NttPassArgs c = make(true, np - 1, s_log);
+      c.in = src + (uint64_t)full * batch_stride;
+      c.out = dst + (uint64_t)full * batch_stride;
+      ARK_NTT_DISPATCH(radices[np - 1], (ntt_launch_pass<Fr, RL>(c, stream, tail)));
+      *tail_res = c.out;
+      *tail_scaled = false;
+    }
     Fr* tmp = src; src = dst; dst = tmp;
   }
   // coset transform, remaining passes
@@ -842,8 +889,8 @@ static void* ntt_inverse_then_coset(ark355_ctx* ctx, void* data, void* scratch, 
     NttPassArgs a = make(false, pass, s_log);
     a.in = src;
     a.out = dst;
-    ARK_NTT_DISPATCH(radices[pass], (ntt_launch_pass<Fr, RL>(a, stream, batch)));
-    ntt_twiddle_fallback<Fr>(a, radices[pass], stream, batch);
+    ARK_NTT_DISPATCH(radices[pass], (ntt_launch_pass<Fr, RL>(a, stream, full)));
+    ntt_twiddle_fallback<Fr>(a, radices[pass], stream, full);
     s_log += radices[pass];
     Fr* tmp = src; src = dst; dst = tmp;
   }

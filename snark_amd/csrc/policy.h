@@ -13,7 +13,7 @@
 //   per key load   MSM_C, MSM_C_H, PACK_ROWS, TABLE_STRIDE, HBM_BUDGET_MB, SHARD_DIST_WM
 //                  (read when a key / base set is loaded through the context: the tables are built for them)
 //   per call       MSM_SEG, ACC_THREADS, MSM_TWO_LEVEL_MIN, NTT_RMAX, NTT_DIRECT_MAX, NTT_NOFUSE (A/B and test knobs of the kernels'
-//                  host drivers)
+//                  host drivers), CHECK_SATISFIED
 #pragma once
 #include <stddef.h>
 #include <stdint.h>
@@ -66,6 +66,10 @@ struct TunePolicy {
   int32_t ntt_rmax = 0;           // 0: NTT_RMAX_LOG
   int32_t ntt_direct_max = -1;    // -1: NTT_DIRECT_MAX_LOG
   int32_t ntt_nofuse = 0;
+  int32_t check_satisfied = 0;    // 1: ark355_prove / _dev / _batch also check a_i b_i == c_i on the rows the witness map has just computed
+                                  // (one elementwise kernel, the verdict travels with the proof's last copy) and return
+                                  // ARK355_E_UNSATISFIABLE instead of a proof that cannot verify; 0 (default): prove whatever z is, as the
+                                  // reference's release build does
 
   struct Field {
     const char* name;
@@ -108,6 +112,7 @@ inline const TunePolicy::Field* TunePolicy::fields(int* count) {
       ARK_POLICY_FIELD64("MSM_TWO_LEVEL_MIN", msm_two_level_min),
       ARK_POLICY_FIELD32("NTT_RMAX", ntt_rmax),
       ARK_POLICY_FIELD32("NTT_DIRECT_MAX", ntt_direct_max),
+      ARK_POLICY_FIELD32("CHECK_SATISFIED", check_satisfied),
       ARK_POLICY_FIELD32("NTT_NOFUSE", ntt_nofuse),
   };
   *count = (int)(sizeof(tab) / sizeof(tab[0]));

@@ -3,7 +3,7 @@
 // Rounds 1-3 sharded only the MSM terms; every rank repeated the whole witness map (SpMV + 7 NTTs of N points), which at
 // n = 2^22 is ~10 ms of chip-filling work of the 25 ms a rank of eight spends on a proof (profiles/r04_runA_shard_rank_22.json:
 // 3.9x on eight GPUs).  Here a rank owns 1/G of every vector through the whole map, and what crosses xGMI is three
-// all-to-all exchanges of N/G elements per vector (2 x 3 vectors + 1 vector: 7 N/G x 32 B per rank and proof, 29 MB at
+// all-to-all exchanges of N/G elements per vector (3 + 2 + 1 vectors: 6 N/G x 32 B per rank and proof, 25 MB at
 // N = 2^23, G = 8, spread over all seven links of a rank at once).
 //
 // N = G M, w = primitive N-th root.  Two layouts of a length-N vector over the ranks:
@@ -17,12 +17,15 @@
 // kernel (dwm_seam_kernel: inverse transform's columns, g^k / N, forward transform's columns) and the vectors change
 // hands only where the arithmetic needs it:
 //   SpMV of this rank's rows (layout R)                                      a, b, c: M elements each
-//   local inverse M-NTT x3 | all-to-all | seam kernel | all-to-all | local forward M-NTT x3     -> a', b', c' on the coset (R)
-//   pointwise (a' b' - c') / Z                                               (R, local)
-//   local inverse M-NTT | all-to-all | final kernel (columns, g^-k / N)      -> h in layout B
-// so rank r ends up with h[k1 + M k2] for its k1 range, stored as h_loc[k2 (M/G) + (k1 - r M/G)], and its shard of
-// h_query holds the bases of exactly those coefficients in that order (pk_upload, PkDev::h_dist).  Three exchanges, seven
-// local transforms of N/G points.  G is a power of two with G^2 | N/8; anything else keeps the replicated map.
+//   local inverse M-NTT x3 | all-to-all (a, b, c) | seam kernel | all-to-all (a, b) | local forward M-NTT x2   -> a', b' on the coset (R)
+//   pointwise a' b'                                                           (R, local)
+//   local inverse M-NTT | all-to-all | final kernel (columns, g^-k / N, minus c, 1 / Z)      -> h in layout B
+// c takes part in the inverse transform only (round 6; the six-transform form of the map, witness_impl.cuh
+// witness_map_run: h_k = (rho_k - c_k) / (g^N - 1) with rho the inverse coset transform of a' b'): the seam kernel leaves
+// c's coefficients in layout B on the rank that will hold the same coefficients of h, so c never travels back.
+// So rank r ends up with h[k1 + M k2] for its k1 range, stored as h_loc[k2 (M/G) + (k1 - r M/G)], and its shard of
+// h_query holds the bases of exactly those coefficients in that order (pk_upload, PkDev::h_dist).  Three exchanges (3 + 2 + 1
+// vectors), six local transforms of N/G points.  G is a power of two with G^2 | N/8; anything else keeps the replicated map.
 //
 // The exchange is RCCL (grouped ncclSend / ncclRecv pairs: an all-to-all over the rank's direct xGMI links) on the
 // witness-map stream; it is ordered against the prover's other collectives by data dependence (plan check before, the
@@ -85,11 +88,14 @@ ARK_D void dwm_small_dft(Fr (&x)[1 << LG], const Fr* roots) {
 // The seam of the distributed inverse -> coset pair, one lane per (vector, k1) of this rank's block:
 //   recv[v][g][j]  = Y_g[k1]          (rank g's local inverse transform, k1 = r Mc + j)
 //   send[v][g'][j] = w^(g' k1) sum_k2 (w^M)^(k2 g') (g^k / N) X[k], k = k1 + M k2, X[k] = sum_g (w^-M)^(g k2) w^-(g k1) Y_g[k1]
+// Vector 2 (c) stops after the inverse transform's columns: c_loc[k2 Mc + j] = N c[k1 + M k2] (unscaled; the final kernel
+// folds the 1/N in), the layout h_loc will have.
 template <class Fr, int LG>
 __global__ void __launch_bounds__(256)
 dwm_seam_kernel(const Fr* __restrict__ recv, Fr* __restrict__ send, uint64_t vec_stride, uint32_t mc, uint32_t rank,
                 uint64_t m_local, DwmRoots<Fr> roots, const Fr* __restrict__ w_lo, const Fr* __restrict__ w_hi,
-                const Fr* __restrict__ wi_lo, const Fr* __restrict__ wi_hi, uint32_t lo_bits, const Fr* __restrict__ seam) {
+                const Fr* __restrict__ wi_lo, const Fr* __restrict__ wi_hi, uint32_t lo_bits, const Fr* __restrict__ seam,
+                Fr* __restrict__ c_loc) {
   constexpr int G = 1 << LG;
   const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= mc) return;
@@ -103,6 +109,11 @@ dwm_seam_kernel(const Fr* __restrict__ recv, Fr* __restrict__ send, uint64_t vec
     if (g != 0) x[g] = Fr::mul(x[g], pow_lookup<Fr>(wi_lo, wi_hi, lo_bits, (uint64_t)g * k1));
   }
   dwm_small_dft<Fr, LG>(x, roots.inv);
+  if (blockIdx.y == 2) {
+#pragma unroll
+    for (int k2 = 0; k2 < G; k2++) c_loc[(uint64_t)k2 * mc + j] = x[k2];
+    return;
+  }
 #pragma unroll
   for (int k2 = 0; k2 < G; k2++) x[k2] = Fr::mul(x[k2], seam[k1 + m_local * (uint64_t)k2]);
   dwm_small_dft<Fr, LG>(x, roots.fwd);
@@ -113,13 +124,15 @@ dwm_seam_kernel(const Fr* __restrict__ recv, Fr* __restrict__ send, uint64_t vec
   }
 }
 
-// The columns of the last (inverse coset) transform: h[k1 + M k2] = (g^-k / N) sum_g (w^-M)^(g k2) w^-(g k1) Y_g[k1],
-// stored at h_loc[k2 Mc + j].
+// The columns of the last (inverse coset) transform and the quotient step:
+//   h[k1 + M k2] = (g^-k / (N (g^N - 1))) sum_g (w^-M)^(g k2) w^-(g k1) Y_g[k1]  -  c_loc[k2 Mc + j] / (N (g^N - 1)),
+// stored at h_loc[k2 Mc + j]  (gz_hi, zc_n: ntt_quotient_tables; c_loc: what dwm_seam_kernel left).
 template <class Fr, int LG>
 __global__ void __launch_bounds__(256)
 dwm_final_kernel(const Fr* __restrict__ recv, Fr* __restrict__ h_loc, uint32_t mc, uint32_t rank, uint64_t m_local,
                  DwmRoots<Fr> roots, const Fr* __restrict__ wi_lo, const Fr* __restrict__ wi_hi,
-                 const Fr* __restrict__ gi_lo, const Fr* __restrict__ gi_hi, uint32_t lo_bits) {
+                 const Fr* __restrict__ gi_lo, const Fr* __restrict__ gz_hi, uint32_t lo_bits, const Fr* __restrict__ c_loc,
+                 const Fr* __restrict__ zc_n) {
   constexpr int G = 1 << LG;
   const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= mc) return;
@@ -131,9 +144,11 @@ dwm_final_kernel(const Fr* __restrict__ recv, Fr* __restrict__ h_loc, uint32_t m
     if (g != 0) x[g] = Fr::mul(x[g], pow_lookup<Fr>(wi_lo, wi_hi, lo_bits, (uint64_t)g * k1));
   }
   dwm_small_dft<Fr, LG>(x, roots.inv);
+  const Fr cf = *zc_n;
 #pragma unroll
   for (int k2 = 0; k2 < G; k2++)
-    h_loc[(uint64_t)k2 * mc + j] = Fr::mul(x[k2], pow_lookup<Fr>(gi_lo, gi_hi, lo_bits, k1 + m_local * (uint64_t)k2));
+    h_loc[(uint64_t)k2 * mc + j] = Fr::sub(Fr::mul(x[k2], pow_lookup<Fr>(gi_lo, gz_hi, lo_bits, k1 + m_local * (uint64_t)k2)),
+                                           Fr::mul(c_loc[(uint64_t)k2 * mc + j], cf));
 }
 
 // h in the distributed layout from a whole h (replicated witness map over a key shard loaded for the distributed one):
@@ -158,10 +173,10 @@ static inline bool dwm_supported(uint32_t log_n, uint32_t world, bool self_one =
 }
 
 // Scratch of one rank of the distributed map: the three vectors with their ping-pong partners (ws, M elements each), the
-// landing zone / staging area of the exchanges (3 M each), the local h (M).
+// landing zone / staging area of the exchanges (3 M / 2 M), the local h and the local coefficients of c (M each).
 struct DwmScratch {
   WitnessScratch ws;
-  DevBuf recv, send, h;
+  DevBuf recv, send, h, c_loc;
 };
 
 template <class Fr>
@@ -195,12 +210,13 @@ static typename Curve::Fr* dwm_stage_a(ark355_ctx* ctx, const R1csDev& r, const 
   const uint64_t M = r.N >> lg;
   spmv_run<Curve>(r, d_z, sc.ws, stream, rank, world);
   sc.recv.ensure(3 * M * sizeof(Fr));
-  sc.send.ensure(3 * M * sizeof(Fr));
+  sc.send.ensure(2 * M * sizeof(Fr));
   sc.h.ensure(M * sizeof(Fr));
+  sc.c_loc.ensure(M * sizeof(Fr));
   return (Fr*)ntt_passes<Curve>(ctx, sc.ws.buf[0].p, sc.ws.buf[1].p, r.log_n - lg, /*inverse=*/true, stream, 3, 2 * M);
 }
 
-// stage B: the seam kernel, recv (3 vectors, stride M) -> send (3 vectors, stride M)
+// stage B: the seam kernel, recv (3 vectors, stride M) -> send (a, b: 2 vectors, stride M) and c_loc
 template <class Curve>
 static void dwm_stage_b(ark355_ctx* ctx, const R1csDev& r, uint32_t world, uint32_t rank, DwmScratch& sc, hipStream_t stream) {
   using Fr = typename Curve::Fr;
@@ -215,7 +231,7 @@ static void dwm_stage_b(ark355_ctx* ctx, const R1csDev& r, uint32_t world, uint3
 #define ARK_DWM_SEAM(LGV)                                                                                                     \
   ARK_LAUNCH((dwm_seam_kernel<Fr, LGV>), grid, dim3(256), 0, stream, (const Fr*)sc.recv.as<Fr>(), sc.send.as<Fr>(), M, mc, rank, M,  \
              roots, (const Fr*)t->w_lo.as<Fr>(), (const Fr*)t->w_hi.as<Fr>(), (const Fr*)t->wi_lo.as<Fr>(),                      \
-             (const Fr*)t->wi_hi.as<Fr>(), t->lo_bits, seam)
+             (const Fr*)t->wi_hi.as<Fr>(), t->lo_bits, seam, sc.c_loc.as<Fr>())
   switch (lg) {
     case 0: ARK_DWM_SEAM(0); break;
     case 1: ARK_DWM_SEAM(1); break;
@@ -228,25 +244,24 @@ static void dwm_stage_b(ark355_ctx* ctx, const R1csDev& r, uint32_t world, uint3
   ARK_CHECK_LAUNCH();
 }
 
-// stage C: local forward transforms of the three vectors that the second exchange landed in ws.buf[0 / 2 / 4], the
-// pointwise step, the local inverse transform of the quotient's coset evaluations.  Returns the result (M elements).
+// stage C: local forward transforms of the two vectors that the second exchange landed in ws.buf[0 / 2], their pointwise
+// product, its local inverse transform.  Returns the result (M elements).
 template <class Curve>
 static typename Curve::Fr* dwm_stage_c(ark355_ctx* ctx, const R1csDev& r, uint32_t world, DwmScratch& sc, hipStream_t stream) {
   using Fr = typename Curve::Fr;
   uint32_t lg = 0;
   while ((1u << lg) < world) lg++;
   const uint64_t M = r.N >> lg;
-  Fr* res0 = (Fr*)ntt_passes<Curve>(ctx, sc.ws.buf[0].p, sc.ws.buf[1].p, r.log_n - lg, /*inverse=*/false, stream, 3, 2 * M);
+  Fr* res0 = (Fr*)ntt_passes<Curve>(ctx, sc.ws.buf[0].p, sc.ws.buf[1].p, r.log_n - lg, /*inverse=*/false, stream, 2, 2 * M);
   const bool swapped = res0 != sc.ws.buf[0].as<Fr>();
-  Fr* cur[3];
-  Fr* oth[3];
-  for (int v = 0; v < 3; v++) {
+  Fr* cur[2];
+  Fr* oth[2];
+  for (int v = 0; v < 2; v++) {
     cur[v] = sc.ws.buf[2 * v + (swapped ? 1 : 0)].as<Fr>();
     oth[v] = sc.ws.buf[2 * v + (swapped ? 0 : 1)].as<Fr>();
   }
   const uint32_t grid = (uint32_t)((M + 255) / 256);
-  ARK_LAUNCH((qap_pointwise_kernel<Fr>), dim3(grid), dim3(256), 0, stream, (const Fr*)cur[0], (const Fr*)cur[1], (const Fr*)cur[2],
-             r.zinv.as<Fr>(), M, oth[0]);
+  ARK_LAUNCH((qap_mul_kernel<Fr>), dim3(grid), dim3(256), 0, stream, (const Fr*)cur[0], (const Fr*)cur[1], M, oth[0]);
   ARK_CHECK_LAUNCH();
   return (Fr*)ntt_passes<Curve>(ctx, oth[0], cur[0], r.log_n - lg, /*inverse=*/true, stream);
 }
@@ -261,11 +276,14 @@ static void dwm_stage_d(ark355_ctx* ctx, const R1csDev& r, uint32_t world, uint3
   const uint32_t mc = (uint32_t)(M >> lg);
   NttTables* t = get_ntt_tables<Curve>(ctx, r.log_n);
   const DwmRoots<Fr> roots = dwm_roots<Fr>(r.log_n, lg);
+  const Fr* gz_hi = nullptr;
+  const Fr* zconst = nullptr;
+  ntt_quotient_tables<Fr>(t, &gz_hi, &zconst);
   const dim3 grid((mc + 255) / 256);
 #define ARK_DWM_FINAL(LGV)                                                                                                  \
   ARK_LAUNCH((dwm_final_kernel<Fr, LGV>), grid, dim3(256), 0, stream, (const Fr*)sc.recv.as<Fr>(), sc.h.as<Fr>(), mc, rank, M, roots, \
-             (const Fr*)t->wi_lo.as<Fr>(), (const Fr*)t->wi_hi.as<Fr>(), (const Fr*)t->gi_lo.as<Fr>(),                         \
-             (const Fr*)t->gi_hi.as<Fr>(), t->lo_bits)
+             (const Fr*)t->wi_lo.as<Fr>(), (const Fr*)t->wi_hi.as<Fr>(), (const Fr*)t->gi_lo.as<Fr>(), gz_hi, t->lo_bits,       \
+             (const Fr*)sc.c_loc.as<Fr>(), zconst + 1)
   switch (lg) {
     case 0: ARK_DWM_FINAL(0); break;
     case 1: ARK_DWM_FINAL(1); break;
@@ -325,7 +343,7 @@ static void* witness_map_dist_run(ark355_ctx* ctx, const R1csDev& r, const void*
   Fr* y = dwm_stage_a<Curve>(ctx, r, d_z, world, rank, sc, stream);
   dwm_all_to_all<Fr>(cm, world, rank, y, 2 * M, sc.recv.as<Fr>(), M, 3, mc, stream, loopback, self_rccl);
   dwm_stage_b<Curve>(ctx, r, world, rank, sc, stream);
-  dwm_all_to_all<Fr>(cm, world, rank, sc.send.as<Fr>(), M, sc.ws.buf[0].as<Fr>(), 2 * M, 3, mc, stream, loopback, self_rccl);
+  dwm_all_to_all<Fr>(cm, world, rank, sc.send.as<Fr>(), M, sc.ws.buf[0].as<Fr>(), 2 * M, 2, mc, stream, loopback, self_rccl);
   Fr* q = dwm_stage_c<Curve>(ctx, r, world, sc, stream);
   dwm_all_to_all<Fr>(cm, world, rank, q, M, sc.recv.as<Fr>(), M, 1, mc, stream, loopback, self_rccl);
   dwm_stage_d<Curve>(ctx, r, world, rank, sc, stream);
@@ -363,7 +381,7 @@ static void witness_map_dist_sim(ark355_ctx* ctx, const R1csDev& r, const void* 
     snd[g] = ranks[g]->send.template as<Fr>();
     rcv[g] = ranks[g]->ws.buf[0].template as<Fr>();
   }
-  exchange(snd, M, rcv, 2 * M, 3);
+  exchange(snd, M, rcv, 2 * M, 2);
   for (uint32_t g = 0; g < world; g++) snd[g] = dwm_stage_c<Curve>(ctx, r, world, *ranks[g], stream);
   for (uint32_t g = 0; g < world; g++) rcv[g] = ranks[g]->recv.template as<Fr>();
   exchange(snd, M, rcv, M, 1);

@@ -6,8 +6,8 @@
 //                  Sr1csAdapter::evaluate_constraint (sr1cs/mod.rs:24-56, which skips the multiply when
 //                  the coefficient is one :42-46).  Repeated columns in a row are summed.
 //                  a_{n+j} = z_j for j < ell (input-consistency rows), everything else 0.
-//   K6  7 NTTs     ntt_impl.cuh
-//   K7  pointwise  t_i = (a'_i b'_i - c'_i) * (g^N - 1)^-1
+//   K6  6 NTTs     ntt_impl.cuh (the reference runs 7: see witness_map_run)
+//   K7  pointwise  a'_i b'_i on the coset, then h_k = (rho_k - c_k) * (g^N - 1)^-1 on coefficients
 //   a9  satisfaction check: first i with a_i b_i != c_i (which_constraint_is_unsatisfied,
 //                  gr1cs/predicate/mod.rs:185-204)
 #pragma once
@@ -75,6 +75,25 @@ qap_pointwise_kernel(const Fr* __restrict__ a, const Fr* __restrict__ b, const F
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N) return;
   out[i] = Fr::mul(Fr::sub(Fr::mul(a[i], b[i]), c[i]), *zinv);
+}
+
+// the two elementwise steps of the six-transform map (witness_map_run)
+template <class Fr>
+__global__ void __launch_bounds__(256)
+qap_mul_kernel(const Fr* __restrict__ a, const Fr* __restrict__ b, uint64_t N, Fr* __restrict__ out) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  out[i] = Fr::mul(a[i], b[i]);
+}
+// h[k] = raw[k] * (g^-k / (N (g^N - 1))) - c[k] * cf     (raw: the inverse transform of a' b' without any scaling; c: the
+// coefficients of c, or N times them, with cf = 1 / (g^N - 1) or that / N: ntt_quotient_tables).  In place on raw.
+template <class Fr>
+__global__ void __launch_bounds__(256)
+qap_quotient_kernel(Fr* __restrict__ raw, const Fr* __restrict__ c, uint64_t N, const Fr* __restrict__ gi_lo,
+                    const Fr* __restrict__ gz_hi, uint32_t lo_bits, const Fr* __restrict__ cf) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  raw[i] = Fr::sub(Fr::mul(raw[i], pow_lookup<Fr>(gi_lo, gz_hi, lo_bits, i)), Fr::mul(c[i], *cf));
 }
 
 template <class Curve>
@@ -199,30 +218,68 @@ static void spmv_run(const R1csDev& r, const void* d_z, WitnessScratch& ws, hipS
 }
 
 // returns device pointer to h[0..N) (Montgomery)
+//
+// Six transforms where the reference's LibsnarkReduction runs seven (un-vendored ark-groth16 r1cs_to_qap.rs: ifft a, b, c;
+// coset_fft a, b, c; ab - c divided by Z(g) pointwise; coset_ifft): the coset evaluations of c are never needed.  With
+// Z = x^N - 1 and a b = h Z + c (deg h <= N - 2, deg c <= N - 1), the evaluations of a b on g H determine
+//     rho = a b mod (x^N - g^N) = (g^N - 1) h + c        (the high half of a b is h, the low half c - h),
+// and rho is what the inverse coset transform of a' b' returns; c's coefficients are already there after its inverse
+// transform.  So h_k = (rho_k - c_k) / (g^N - 1) -- the same field elements as the reference's h for ANY assignment (the
+// map is linear: coset_ifft(a'b' - c') = coset_ifft(a'b') - c), hence the same bytes.  Domains of fewer than 8 points keep
+// the seven-transform form (one-lane kernels).
+// check_rows: also compare a_i b_i with c_i on the rows the SpMV has just written (policy CHECK_SATISFIED); the index of
+// the first unsatisfied constraint (or ~0) is left in ws.first_bad for the caller to fetch.
 template <class Curve>
 static void* witness_map_run(ark355_ctx* ctx, const R1csDev& r, const void* d_z, WitnessScratch& ws,
-                             hipStream_t stream) {
+                             hipStream_t stream, bool check_rows = false) {
   using Fr = typename Curve::Fr;
   spmv_run<Curve>(r, d_z, ws, stream);
+  if (check_rows) {
+    ws.first_bad.ensure(8);
+    ARK_CHECK_HIP(hipMemsetAsync(ws.first_bad.p, 0xFF, 8, stream));
+    if (r.n) {
+      ARK_LAUNCH((r1cs_check_kernel<Fr>), dim3((uint32_t)((r.n + 255) / 256)), dim3(256), 0, stream, (const Fr*)ws.buf[0].as<Fr>(),
+                 (const Fr*)ws.buf[2].as<Fr>(), (const Fr*)ws.buf[4].as<Fr>(), r.n, ws.first_bad.as<unsigned long long>());
+      ARK_CHECK_LAUNCH();
+    }
+  }
+  const uint32_t grid = (uint32_t)((r.N + 255) / 256);
+  const uint64_t stride = 2 * r.N;
   void* cur[3];
   void* oth[3];
-  {
-    // evaluations on H -> evaluations on g H: inverse NTT and coset NTT with the seam fused (ntt_impl.cuh), the three
-    // vectors in one launch per pass
-    const uint64_t stride = 2 * r.N;
+  if (r.log_n < 3) {
     Fr* res0 = (Fr*)ntt_inverse_then_coset<Curve>(ctx, ws.buf[0].p, ws.buf[1].p, r.log_n, stream, 3, stride);
     const bool swapped = res0 != ws.buf[0].as<Fr>();
     for (int v = 0; v < 3; v++) {
       cur[v] = ws.buf[2 * v + (swapped ? 1 : 0)].p;
       oth[v] = ws.buf[2 * v + (swapped ? 0 : 1)].p;
     }
+    ARK_LAUNCH((qap_pointwise_kernel<Fr>), dim3(grid), dim3(256), 0, stream, (const Fr*)cur[0], (const Fr*)cur[1],
+               (const Fr*)cur[2], r.zinv.as<Fr>(), r.N, (Fr*)oth[0]);
+    ARK_CHECK_LAUNCH();
+    return ntt_run<Curve>(ctx, oth[0], cur[0], r.log_n, /*inverse=*/true, /*coset=*/true, stream);
   }
-  const uint32_t grid = (uint32_t)((r.N + 255) / 256);
-  ARK_LAUNCH((qap_pointwise_kernel<Fr>), dim3(grid), dim3(256), 0, stream, (const Fr*)cur[0], (const Fr*)cur[1],
-             (const Fr*)cur[2], r.zinv.as<Fr>(), r.N, (Fr*)oth[0]);
+  // evaluations on H -> coefficients (a, b, c) -> evaluations on g H (a, b): inverse NTT and coset NTT with the seam fused
+  // (ntt_impl.cuh), the vectors in one launch per pass
+  void* c_coef = nullptr;
+  bool c_scaled = false;
+  Fr* res0 = (Fr*)ntt_inverse_then_coset<Curve>(ctx, ws.buf[0].p, ws.buf[1].p, r.log_n, stream, 3, stride, 1, &c_coef, &c_scaled);
+  const bool swapped = res0 != ws.buf[0].as<Fr>();
+  for (int v = 0; v < 2; v++) {
+    cur[v] = ws.buf[2 * v + (swapped ? 1 : 0)].p;
+    oth[v] = ws.buf[2 * v + (swapped ? 0 : 1)].p;
+  }
+  ARK_LAUNCH((qap_mul_kernel<Fr>), dim3(grid), dim3(256), 0, stream, (const Fr*)cur[0], (const Fr*)cur[1], r.N, (Fr*)oth[0]);
   ARK_CHECK_LAUNCH();
-  void* res = ntt_run<Curve>(ctx, oth[0], cur[0], r.log_n, /*inverse=*/true, /*coset=*/true, stream);
-  return res;
+  Fr* raw = (Fr*)ntt_passes<Curve>(ctx, oth[0], cur[0], r.log_n, /*inverse=*/true, stream);
+  NttTables* t = get_ntt_tables<Curve>(ctx, r.log_n);
+  const Fr* gz_hi = nullptr;
+  const Fr* zconst = nullptr;
+  ntt_quotient_tables<Fr>(t, &gz_hi, &zconst);
+  ARK_LAUNCH((qap_quotient_kernel<Fr>), dim3(grid), dim3(256), 0, stream, raw, (const Fr*)c_coef, r.N, (const Fr*)t->gi_lo.as<Fr>(), gz_hi,
+             t->lo_bits, zconst + (c_scaled ? 0 : 1));
+  ARK_CHECK_LAUNCH();
+  return raw;
 }
 
 }  // namespace ark355

@@ -199,6 +199,12 @@ def check_witness_map_full(lib, ctx, C, inst, dist_worlds=()):
         got = lib.witness_map(ctx, rh, zb, len(z), 32)
         exp = cbase.witness_map(C, n, ell, w, mats, zb)
         assert len(got) == len(exp) and got == exp, (C.name, n)
+        # an assignment that does NOT satisfy the constraints: the reference's map has no satisfaction check and returns
+        # coset_ifft((a'b' - c') / Z(g)) whatever z is; the six-transform form (witness_impl.cuh) must agree there too
+        zbad = list(z)
+        zbad[len(z) // 2] = (zbad[len(z) // 2] + 12345) % C.r
+        zbb = S._mont_bytes(C.r, zbad)
+        assert lib.witness_map(ctx, rh, zbb, len(z), 32) == cbase.witness_map(C, n, ell, w, mats, zbb), (C.name, n, "unsatisfied")
         for world in dist_worlds:
             got = lib.witness_map_dist_sim(ctx, rh, zb, len(z), 32, world)
             assert got == exp, (C.name, n, "distributed over", world)

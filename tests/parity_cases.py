@@ -139,6 +139,9 @@ def r1cs_case(lib, ctx, C, A, B, Cm, z, ell):
             assert lib.is_satisfied(ctx, r1, z_bytes(C, zbad), m) == R.first_unsatisfied_r1cs(A, B, Cm, zbad, C.r)
         h = lib.witness_map(ctx, r1, zb, m, sz["fr"])
         assert fr_vec_from_mont(C, h) == G.witness_map(C, A, B, Cm, z, ell)
+        # (an unsatisfied assignment maps to the same h as the reference's seven-transform form)
+        h = lib.witness_map(ctx, r1, z_bytes(C, zbad), m, sz["fr"])
+        assert fr_vec_from_mont(C, h) == G.witness_map(C, A, B, Cm, zbad, ell)
     finally:
         lib.dll.ark355_r1cs_free(r1)
 
@@ -212,6 +215,48 @@ def prove_case(lib, ctx, C, A, B, Cm, z, ell, td=None, rs=((0x1234567890abcdef, 
         lib.dll.ark355_pk_free(pkh)
         lib.dll.ark355_r1cs_free(r1)
     return pk
+
+
+def check_satisfied_case(lib, ctx, C, policy, n=13):
+    """Policy CHECK_SATISFIED.  Off (default): an assignment that does not satisfy the constraints is proven like any other, and
+    the proof is the one the reference's algorithm yields for it (oracle O1: seven transforms, five MSMs) -- the six-transform
+    witness map of the library agrees with it for ANY assignment.  On: ARK355_E_UNSATISFIABLE (SynthesisError::Unsatisfiable)
+    with the index of the first unsatisfied constraint; satisfied assignments prove as before."""
+    sz = lib.sizes(C.curve_id)
+    A, B, Cm, z, ell = S.mulchain_direct(C.r, n)
+    m = len(z)
+    td = G.Trapdoor(tau=987654321, alpha=5, beta=7, gamma=11, delta=13)
+    pk = G.setup(C, A, B, Cm, ell, m, td)
+    r1 = r1cs_load_from_rows(lib, ctx, C, A, B, Cm, ell, m - ell)
+    pkh = pk_load_from_oracle(lib, ctx, C, pk, ell, m - ell, 1 << pk.domain_log)
+    try:
+        zbad = list(z)
+        zbad[ell + n // 2] = (zbad[ell + n // 2] + 1) % C.r
+        bad = R.first_unsatisfied_r1cs(A, B, Cm, zbad, C.r)
+        assert bad is not None and bad >= 0
+        r_, s_ = 77, 99
+        a, b, c = lib.prove(ctx, pkh, r1, z_bytes(C, zbad), m, Z.fr_canon(C, r_), Z.fr_canon(C, s_), sz)
+        got = G.Proof(Z.g1_from_raw(C, a), Z.g2_from_raw(C, b), Z.g1_from_raw(C, c))
+        assert got == G.prove(C, pk, A, B, Cm, zbad, ell, r_, s_), "unsatisfied assignment, policy off: the reference's (unverifiable) proof"
+        assert not G.verify(C, pk.vk, zbad[1:ell], got)
+        policy.setenv("ARK355_CHECK_SATISFIED", "1")
+        a, b, c = lib.prove(ctx, pkh, r1, z_bytes(C, z), m, Z.fr_canon(C, r_), Z.fr_canon(C, s_), sz)
+        assert G.Proof(Z.g1_from_raw(C, a), Z.g2_from_raw(C, b), Z.g1_from_raw(C, c)) == G.prove_closed_form(C, pk, z, ell, r_, s_)
+        try:
+            lib.prove(ctx, pkh, r1, z_bytes(C, zbad), m, Z.fr_canon(C, r_), Z.fr_canon(C, s_), sz)
+            assert False, "unsatisfied assignment must be refused under CHECK_SATISFIED"
+        except Exception as e:
+            assert getattr(e, "code", None) == -17, e
+            assert ("constraint %d " % bad) in str(e), (str(e), bad)
+        # the batch entry reports the same error
+        try:
+            lib.prove_batch(ctx, pkh, r1, [z_bytes(C, z), z_bytes(C, zbad)], m, [Z.fr_canon(C, 1)] * 2, [Z.fr_canon(C, 2)] * 2, sz, inflight=2)
+            assert False, "batch with an unsatisfied assignment must fail under CHECK_SATISFIED"
+        except Exception as e:
+            assert getattr(e, "code", None) == -17, e
+    finally:
+        lib.dll.ark355_pk_free(pkh)
+        lib.dll.ark355_r1cs_free(r1)
 
 
 def prove_batch_case(lib, ctx, C, count=5, n=9, inflight=3):

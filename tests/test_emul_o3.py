@@ -71,6 +71,8 @@ def test_large_size_checks_on_the_emulator(emul_lib, emul_ctx):
     O.check_ntt_full(emul_lib, emul_ctx, BLS12_381, 9)
     O.check_ntt_full(emul_lib, emul_ctx, BN254, 4)
     O.check_witness_map_full(emul_lib, emul_ctx, BLS12_381, S.mulchain_csr(BLS12_381.r, 61))
+    # N = 2^10 = 2^5 x 2^5: the smallest domain on the fused inverse -> coset path (seam kernel; c leaves after its inverse)
+    O.check_witness_map_full(emul_lib, emul_ctx, BLS12_381, S.mulchain_csr(BLS12_381.r, 1000))
     # (the oracle's Python pairing on an O3-keyed proof runs in the GPU tier at 2^20; here the library's own pairing only)
     O.check_instance(emul_lib, emul_ctx, BLS12_381, S.mulchain_csr(BLS12_381.r, 33), [(9, 11)], sharded=True)
 

@@ -88,6 +88,11 @@ def test_prove_bytes_equal_oracle(emul_lib, emul_ctx, C):
     pc.prove_case(emul_lib, emul_ctx, C, A, B, Cm, z, ell, rs=((0x1234567890abcdef, 0xfedcba0987654321aabbccdd), (0, 5)))
 
 
+@pytest.mark.parametrize("C", [BLS12_381, BN254], ids=lambda c: c.name)
+def test_check_satisfied_policy(emul_lib, emul_ctx, emul_policy, C):
+    pc.check_satisfied_case(emul_lib, emul_ctx, C, emul_policy)
+
+
 @pytest.mark.parametrize("sched", ["SERIAL=1", "SERIAL=0", "SCHED=2", "SCHED=3"])
 def test_prove_schedules_give_the_same_bytes(emul_lib, emul_ctx, emul_policy, sched):
     """prove_run's schedules (policy SCHED; SERIAL=1 / 0 are the legacy spellings of 0 / 1): one stream, the five-stream
