@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- Groth16 prove throughput (R1CS constraints/s, BLS12-381) on MI355X.
 
-A "step" is ONE Groth16 proof (witness map: SpMV + 7 NTTs; 4 G1 MSMs + 1 G2 MSM; finalize) of the
+A "step" is ONE Groth16 proof (witness map: SpMV + 6 NTTs; 4 G1 MSMs + 1 G2 MSM; finalize) of the
 workload BASELINE.json's metric is quoted on: configs[1], the 2^20-constraint synthetic R1CS ("S2
 mulchain") over BLS12-381, literal n = 2^20 => domain N = 2^21.  Proving key, CSR matrices
 and the assignment z are resident in HBM when the timed region starts.
@@ -35,14 +35,32 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-# Secondary, integer roofline of the bucket-accumulation kernels.  The scarce instruction is v_mad_u64_u32: the
-# whole chip issues 28.8 T of them per second (tools/ubench.hip, profiles/r01_ubench_*.txt: 46.8 per clock per CU).
-# Multiply-adds per mixed addition are read off the ISA of the shipped kernels (tools/isa_blocks.py, hot blocks):
-#   G1 and lane-split G2 (two lanes per addition) on radix-2^28 limbs (msm_accumulate28_kernel, msm_accumulate_g2l28_kernel).
-MAD_PEAK_T = 29.3            # tools/ubench5, two waves per SIMD (profiles/r05_runA_ubench5.txt); round 1 read 28.7 with eight
-# Round 5 (one Karatsuba level over the operand products, v_mad_u64_u32 + v_mad_i64_i32): 3155 / 2 x 4410 (BLS12-381),
-# 1526 / 2 x 2162 (BN254); rounds 2-4: 3542 / 2 x 5292, 1720 / 2 x 2610.
-MADS_PER_ADD = {"bls12_381": {"g1": 3155, "g2": 2 * 4410}, "bn254": {"g1": 1526, "g2": 2 * 2162}}
+# Secondary, integer roofline of the bucket-accumulation kernels (msm_accumulate28_kernel, msm_accumulate_g2l28_kernel: G1 and
+# lane-split G2, two lanes per addition, on radix-2^28 limbs).  The scarce instruction is v_mad_u64_u32.
+# Round 6: both numbers are MEASURED, not entered.  The peak is what the chip issues in a 20 ms loop of nothing but that instruction
+# at the accumulation kernels' occupancy (ark355_diag_mad_rate, right before and right after the timed region).  A loop that light
+# runs at the full 2.4 GHz on every box (31.5-32.5 T/s), so this is the hardware's peak, not the box's sustained rate: what differs
+# from box to box is the clock under the REAL load (2.1-2.3 GHz under the 1400 W cap: 4-5 % in every time of this path), and that
+# is normalised separately, with the GPU's own cycle counter (`box`, box_block below).  MAD_PEAK_REF_T is the fallback when the
+# diagnostic is unavailable (tools/ubench5 on a throttled box, profiles/r05_runA_ubench5.txt).  The multiply-adds per mixed addition are counted in the
+# code object of the library that runs (tools/code_object_stats.py at build time -> snark_amd/libark355.stats.json); the table
+# below is the fallback for a library built without the stats file and says so in the line.
+MAD_PEAK_REF_T = 29.3
+MADS_PER_ADD_FALLBACK = {"bls12_381": {"g1": 3155, "g2": 2 * 4410}, "bn254": {"g1": 1526, "g2": 2 * 2162}}
+
+
+def mads_per_add(curve):
+    """(table, source): v_mad_u64_u32 + v_mad_i64_i32 per mixed addition of the shipped accumulation kernels (G2: both lanes)."""
+    try:
+        import snark_amd
+        st = json.load(open(os.path.splitext(snark_amd.LIB_PATH)[0] + ".stats.json"))
+        g1 = st[curve + ".g1"]["hot_block"]["multiply_adds"]
+        g2 = st[curve + ".g2"]["hot_block"]["multiply_adds"]
+        if g1 > 0 and g2 > 0:
+            return {"g1": g1, "g2": 2 * g2}, "code object of the loaded library (tools/code_object_stats.py, hot path of the kernels)"
+    except Exception:                                         # noqa: BLE001
+        pass
+    return MADS_PER_ADD_FALLBACK[curve], "fallback constants (no libark355.stats.json next to the library)"
 
 
 def parse_args():
@@ -66,6 +84,8 @@ def parse_args():
     ap.add_argument("--no-telemetry", action="store_true", help="no clock / power sampling")
     ap.add_argument("--no-e2e", action="store_true",
                     help="skip the synthesis-in-the-loop reading (host mirror feeding in-flight proofs; after the timed region)")
+    ap.add_argument("--e2e-s3", action="store_true",
+                    help="the e2e block also runs the S3 bench-LC circuit (mirror-bound: ~50 s, says nothing about a Rust host)")
     ap.add_argument("--profile-run", action="store_true",
                     help="for rocprofv3: nothing but preparation, warm-up and the timed region (no A/B, isolated, single-proof, "
                          "latency or stand-alone readings), so that every proof of the trace ran under ONE schedule (ARK355_SCHED)")
@@ -94,11 +114,13 @@ def spawn_ranks(args):
     return subprocess.call(cmd, env=env)
 
 
-def cpu_baseline(curve_name, log_n_sample=None):
-    """Oracle CPU restatement on a bounded sample of the same workload (rank 0, N=1 only)."""
+def cpu_baseline(curve_name, log_n_sample=None, workload=None):
+    """Oracle CPU restatement on a bounded sample of the same workload (rank 0, N=1 only).  workload: the bench's own statement,
+    key and one of its GPU proofs -- on a host that can time the full size the CPU proofs run on exactly that, and the first one
+    is compared byte for byte with the GPU's (`parity_vs_oracle`): the oracle in its role as checker."""
     try:
         from oracle.c import cbase
-        return cbase.bench_prove(curve_name, log_n_sample)
+        return cbase.bench_prove(curve_name, log_n_sample, workload=workload)
     except Exception as e:            # pragma: no cover - fallback keeps the bench line complete
         sys.stderr.write("[bench] C oracle unavailable (%r); timing the Python oracle on a tiny sample\n" % (e,))
     from oracle import groth16 as G, synthetic as S
@@ -114,13 +136,16 @@ def cpu_baseline(curve_name, log_n_sample=None):
             "sample": "pure-Python oracle (scalar, naive MSM), 2^7-constraint mulchain, 1 proof"}
 
 
-def e2e_reading(curve, n, inflight, device_value):
+def e2e_reading(curve, n, inflight, device_value, s3=False):
     """SURVEY 8f-4, outside the timed region: SNARK::prove WITH synthesis in the loop.  K witness-only synthesis threads (one
     constraint system each -- the reference's ConstraintSystemRef is Rc<RefCell>, so a thread per proof is its parallel unit)
     hand assignments in page-locked buffers to `inflight` proving threads (Groth16::prove_pipelined of host_mirror/snark.hpp,
-    the C++ stand-in for a Rust host; tests/cpp/test_host_mirror --e2e), in its own process with its own key.  Two circuits:
-    S3 = the reference's own benchmark shape (relations/examples/bench.rs:22-83 made satisfiable: up to ten terms per linear
-    combination, ~45 field multiplications of host work per constraint) and S2 = the bench's own mulchain (one)."""
+    the C++ stand-in for a Rust host; tests/cpp/test_host_mirror --e2e), in its own process with its own key.  The circuit is S2,
+    the bench's own mulchain (one field multiplication of host work per constraint); `value` of the block is that reading.
+    s3=True (flag --e2e-s3) adds S3, the reference's benchmark SHAPE (relations/examples/bench.rs:22-83: up to ten terms per
+    linear combination) made satisfiable by evaluating those combinations in the witness closures -- ~45 field multiplications
+    per constraint that the reference's own closures (`Ok(self.a)`, bench.rs:74-76) do not do, on a C++ mirror that is not
+    ark-relations: the S3 figure is MIRROR-BOUND and says nothing about a Rust host; it is labelled so."""
     import subprocess
     try:
         from snark_amd import build as B
@@ -137,7 +162,10 @@ def e2e_reading(curve, n, inflight, device_value):
         env.pop("ARK355_E2E_SWEEP", None)
         out = {"unit": "constraints/s", "synthesis_threads": threads, "inflight": inflight, "host_cpu_quota_cores": quota,
                "host": "C++ mirror of ark-relations (host_mirror/), witness-only synthesis; a Rust host runs the real crate"}
-        for tag, circuit, count, extra in (("s3_bench_lc", "benchlc", max(inflight, threads), ["e2e-only"]), ("s2_mulchain", "mulchain", 6 * inflight, [])):
+        cases = [("s2_mulchain", "mulchain", 6 * inflight, [])]
+        if s3:
+            cases.append(("s3_bench_lc_mirror_bound", "benchlc", max(inflight, threads), ["e2e-only"]))
+        for tag, circuit, count, extra in cases:
             t0 = time.perf_counter()
             try:
                 r = subprocess.run([exe, "--e2e", curve, str(n), str(count), str(threads), str(inflight), circuit] + extra,
@@ -160,8 +188,11 @@ def e2e_reading(curve, n, inflight, device_value):
             best = max(rec["ratio_to_value"] or 0, rec.get("ratio_to_device_only_same_process") or 0)
             rec["bound"] = "device" if best >= 0.9 else "host synthesis (%d threads of a %d-core quota)" % (threads, quota)
             out[tag] = rec
-        if "value" in out.get("s3_bench_lc", {}):
-            out["value"] = out["s3_bench_lc"]["value"]
+        if "value" in out.get("s2_mulchain", {}):
+            out["value"] = out["s2_mulchain"]["value"]
+        if "s3_bench_lc_mirror_bound" in out and "value" in out["s3_bench_lc_mirror_bound"]:
+            out["s3_bench_lc_mirror_bound"]["note"] = ("bounded by the C++ mirror's witness closures (they evaluate the linear combinations; the "
+                                                       "reference's bench.rs closures return a stored value), not by the path")
         return out
     except Exception as e:                                    # noqa: BLE001
         return {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
@@ -182,6 +213,37 @@ def thread_cpu_times():
             out[(tid, comm)] = (int(f[11]) + int(f[12])) / tick
     except OSError:
         pass
+    return out
+
+
+REF_GFXCLK_MHZ = 2200.0       # the clock the normalised figures are quoted at (boxes of the pool sustain 2.1-2.3 GHz under the 1400 W cap)
+
+
+def box_block(gpu_clocks, dt, steps, value, n, telemetry):
+    """Box-independent reading of the timed region.  The GPU counts its own shader-clock cycles (s_memtime) and a constant 100 MHz
+    reference (s_memrealtime); read right before and right after the region (ark355_diag_clocks) they give the cycles the region
+    took at whatever clock THIS box sustained under its power cap: cycles per constraint is what to compare across boxes and
+    commits, and `*_at_ref_clock` are the headline figures rescaled to REF_GFXCLK_MHZ."""
+    out = {"ref_gfxclk_mhz": REF_GFXCLK_MHZ}
+    try:
+        (c0, r0), (c1, r1) = gpu_clocks["t0"], gpu_clocks["t1"]
+        if c1 > c0 and r1 > r0:
+            cycles, ticks = c1 - c0, r1 - r0
+            clk = cycles / ticks * 100.0                       # MHz
+            out["gfxclk_mhz_mean_on_chip"] = clk
+            out["region_ms_on_chip"] = ticks / 1e5
+            out["gfx_cycles_per_step"] = cycles / steps
+            out["gfx_cycles_per_constraint"] = cycles / steps / n
+            out["ms_per_step_at_ref_clock"] = cycles / steps / (REF_GFXCLK_MHZ * 1e3)
+            out["value_at_ref_clock"] = value * (REF_GFXCLK_MHZ / clk)
+    except Exception as e:                                    # noqa: BLE001
+        out["error"] = ("no on-chip counters: %s %s" % (type(e).__name__, {k: v for k, v in gpu_clocks.items() if k.endswith("_error")}))[:200]
+    try:
+        out["gfxclk_mhz_mean_smi"] = telemetry["timed_region"]["current_gfxclk"]["mean"]
+    except Exception:                                         # noqa: BLE001
+        pass
+    out["note"] = ("cycles = the GPU's shader-clock counter over the timed region (host launch gaps included: they are part of the step); "
+                   "compare gfx_cycles_per_constraint / *_at_ref_clock across boxes and commits, raw ms_per_step / value only within one box")
     return out
 
 
@@ -519,9 +581,29 @@ def main():
     gc.collect()
     gc.freeze()
     rec = [0.0, 0, 0]
+    # the multiply-add rate of this box, warm, right before (and right after) the timed region -- outside it
+    mad_peak = {}
+    def read_mad_peak(tag):
+        if emul or rank != 0 or args.profile_run:
+            return
+        try:
+            mad_peak[tag] = g.lib.diag_mad_rate(g.ctx, 20.0)["tmad_per_s"]
+        except Exception as e:                                # noqa: BLE001
+            mad_peak[tag + "_error"] = str(e)[:120]
+    read_mad_peak("before")
+    gpu_clocks = {}
+    def read_gpu_clocks(tag):
+        # shader-clock cycles and 100 MHz ticks of the GPU's own counters (ark355_diag_clocks), bracketing the timed region
+        if emul or rank != 0 or args.profile_run:
+            return
+        try:
+            gpu_clocks[tag] = g.lib.diag_clocks(g.ctx)
+        except Exception as e:                                # noqa: BLE001
+            gpu_clocks[tag + "_error"] = str(e)[:120]
     if world > 1:
         dist.barrier()
     dev_sync()
+    read_gpu_clocks("t0")
     thr0 = thread_cpu_times()
     worker_cpu[0] = 0.0
     cpu0 = time.process_time()
@@ -533,6 +615,8 @@ def main():
         dist.barrier()
     dt = time.perf_counter() - t0
     wall1 = time.time()
+    read_gpu_clocks("t1")
+    read_mad_peak("after")
     if sampler is not None:
         time.sleep(0.06)                         # let the sampler's last reading of the region land
         telemetry["timed_region"] = sampler.window(wall0, wall1)
@@ -712,11 +796,13 @@ def main():
         alg_bytes_per_launch = alg_bytes_per_proof / 5.0
         avg_launch_ms = acc_ms_sum / max(1, acc_launches)
         achieved = alg_bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
-        prove_alg_bytes = (7 * 64 * N + alg_bytes_per_proof + 32 * m + 8 * int(sum(int(rp[-1]) for rp in r1.row_ptr))
+        prove_alg_bytes = (6 * 64 * N + alg_bytes_per_proof + 32 * m + 8 * int(sum(int(rp[-1]) for rp in r1.row_ptr))
                            + 3 * 32 * n)
         # integer roofline: multiply-adds issued by the accumulation launches / their summed duration
         windows = acc_points / max(1, args.steps) / float(g1_terms + g2_terms)       # table windows per term
-        mpa = MADS_PER_ADD[args.curve]
+        mpa, mpa_source = mads_per_add(args.curve)
+        peaks = [v for k, v in mad_peak.items() if not k.endswith("_error") and v and v > 0]
+        mad_peak_t = sum(peaks) / len(peaks) if peaks else None
         mads_per_proof = windows * (g1_terms * mpa["g1"] + g2_terms * mpa["g2"])
         acc_ms_per_proof = acc_ms_sum / max(1, args.steps)
         mad_rate_t = mads_per_proof / (acc_ms_per_proof * 1e-3) / 1e12 if acc_ms_per_proof > 0 else 0.0
@@ -750,13 +836,20 @@ def main():
                              "frac": alg_bytes_per_launch / (solo * 1e-3) / 1e9 / HBM_PEAK_GBS,
                              "note": "same kernel, one proof in flight, measured after the timed region"},
                          "note": "integer-ALU bound by construction (~10 Fq mul per 128 B term); see DESIGN.md",
-                         "alu": {"unit": "T v_mad_u64_u32/s", "achieved": mad_rate_t, "peak": MAD_PEAK_T,
-                                 "frac": mad_rate_t / MAD_PEAK_T, "windows_per_term": windows,
-                                 "mads_per_add": mpa,
+                         "alu": {"unit": "T v_mad_u64_u32/s", "achieved": mad_rate_t, "peak": mad_peak_t or MAD_PEAK_REF_T,
+                                 "frac": mad_rate_t / (mad_peak_t or MAD_PEAK_REF_T),
+                                 "peak_source": ("measured on this box around the timed region (ark355_diag_mad_rate): %s" % json.dumps(mad_peak))
+                                                if mad_peak_t else "reference constant (not measured in this run)",
+                                 "windows_per_term": windows,
+                                 "mads_per_add": mpa, "mads_per_add_source": mpa_source,
                                  "note": "all 5 accumulation launches of a proof; with several proofs in flight the "
                                          "launches share the chip, so the single-stream run (--inflight 1) is the "
                                          "clean reading"}},
             "parity": parity,
+            # box-normalised figures: the same library reads 4-5 % apart on two boxes of the pool (sustained clock under the power
+            # cap); these are the headline numbers rescaled to a box that issues MAD_PEAK_REF_T multiply-adds per second, and the
+            # time in gfx clock cycles (mean gfxclk of the timed region from the telemetry sampler)
+            "box": box_block(gpu_clocks, dt, args.steps, (1 if shard else world) * n * args.steps / dt, n, telemetry),
             # host CPU seconds burnt per second of the timed region by this rank (launch threads, waits, the O(1) proof tail)
             "host_cpu_cores": host_cpu_s / dt if dt > 0 else None,
             "host_cpu_threads": host_cpu_threads,      # cores per thread name over the timed region (top 8)
@@ -797,9 +890,25 @@ def main():
             pass
         if not args.no_e2e and world == 1 and not emul and not shard:
             stage("e2e (synthesis in the loop) ...")
-            out["e2e"] = e2e_reading(args.curve, n, len(ctxs), out["value"])
+            out["e2e"] = e2e_reading(args.curve, n, len(ctxs), out["value"], s3=args.e2e_s3)
         if not args.no_cpu_baseline and world == 1 and not emul:
-            out["cpu_baseline"] = cpu_baseline(args.curve)
+            wl = None
+            try:
+                if results and not shard:
+                    pr, r_, s_ = results[0]
+                    sz = g.sizes
+                    raw = (pr.a, pr.b, pr.c) if hasattr(pr, "a") else tuple(pr)
+                    wl = {"n": n, "ell": r1.ell, "w": r1.w, "mats": [(r1.row_ptr[i], r1.col[i], r1.coeff[i]) for i in range(3)],
+                          "z": synthetic.z_to_mont_bytes(cv, z), "r": r_, "s": s_, "proof": raw,
+                          "pk": {"a_query": pk.a_query, "b_g1_query": pk.b_g1_query, "b_g2_query": pk.b_g2_query, "h_query": pk.h_query,
+                                 "l_query": pk.l_query, "alpha_g1": pk.vk.alpha_g1, "beta_g1": pk.beta_g1, "delta_g1": pk.delta_g1,
+                                 "beta_g2": pk.vk.beta_g2, "delta_g2": pk.vk.delta_g2}}
+            except Exception as e:                            # noqa: BLE001
+                stage("cpu_baseline: the bench's workload could not be handed to the oracle (%s)" % e)
+                wl = None
+            out["cpu_baseline"] = cpu_baseline(args.curve, workload=wl)
+            if out["cpu_baseline"].get("parity_vs_oracle") == "MISMATCH":
+                out["parity"] = "MISMATCH against oracle/c"
         if sampler is not None:
             telemetry["host_at_end"] = GT.host_counters()
         if not emul and not args.profile_run:

@@ -108,6 +108,18 @@ int32_t ark355_diag_streams(ark355_ctx** ctxs, uint32_t count, int8_t* serialise
  * DESIGN.md section 10).  *lanes (may be NULL) = the number of streams on pairwise different hardware queues the library
  * found for one-stream proofs on this device (probed once, at the first ark355_ctx_create). */
 int32_t ark355_diag_dispatch(ark355_ctx* ctx, uint32_t launches, uint32_t spin_us, float* gap_us, uint32_t* lanes);
+/* Diagnostic: the rate at which THIS box issues v_mad_u64_u32 right now -- the instruction the bucket-accumulation kernels are
+ * made of, at their occupancy (two waves per SIMD), for about target_ms (0.1 .. 1000) milliseconds on the context's stream.
+ * *tmad_per_s = 10^12 multiply-adds per second over the whole chip (negative: the build cannot measure it), *elapsed_ms (may be
+ * NULL) = the duration of the measuring launch.  The sustained gfx clock under the power cap differs from box to box by a few
+ * per cent; bench.py prices its integer roofline against this reading and reports box-normalised times with it. */
+int32_t ark355_diag_mad_rate(ark355_ctx* ctx, float target_ms, float* tmad_per_s, float* elapsed_ms);
+/* Diagnostic: the GPU's two free-running counters, read by one lane at the same moment on the context's stream (the call
+ * synchronises that stream): out[0] = shader-clock cycles (s_memtime: follows the gfx clock the power management grants),
+ * out[1] = ticks of the constant 100 MHz reference (s_memrealtime).  Two calls bracket a region: cycles / work is a time that
+ * does not depend on the clock this box sustained, cycles / ticks x 100 MHz the region's mean gfx clock.  Zeros when the build
+ * cannot tell (emulator).  bench.py reports `gfx_cycles_per_constraint` with it. */
+int32_t ark355_diag_clocks(ark355_ctx* ctx, uint64_t out[2]);
 
 /* Page-locked host memory for assignments / key vectors handed to the entry points below: H2D copies from pinned
  * memory run at PCIe rate (~55 GB/s) and truly asynchronously; pageable memory is staged by the runtime at a fraction

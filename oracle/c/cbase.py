@@ -266,12 +266,44 @@ def _cpu_quota():
     return None
 
 
-def bench_prove(curve_name="bls12_381", log_n=None, budget_s=20.0):
+def _bench_prove_workload(cv, curve_name, L, hw, quota, cores, log_n, budget_s, wl):
+    """bench_prove on the caller's own statement and key; the first proof doubles as the parity check of the caller's proof."""
+    n, ell, w, mats, zb, pk = wl["n"], wl["ell"], wl["w"], wl["mats"], wl["z"], wl["pk"]
+    N = 1
+    while N < n + ell:
+        N <<= 1
+    rng = np.random.default_rng(1)
+    times, t_start = [], time.perf_counter()
+    tm = {}
+    got = prove(cv, n, ell, w, mats, zb, pk, wl["r"], wl["s"], timings=tm)
+    parity = "GPU proof bytes == oracle/c proof bytes (same statement, key, z, r, s)" if tuple(got) == tuple(wl["proof"]) else "MISMATCH"
+    times.append((tm["total_s"], tm["witness_map_s"], tm["msm_s"]))
+    while len(times) < 5 and (len(times) < 2 or (time.perf_counter() - t_start) < budget_s):
+        tm = {}
+        prove(cv, n, ell, w, mats, zb, pk, int(rng.integers(1, 1 << 62)), int(rng.integers(1, 1 << 62)), timings=tm)
+        times.append((tm["total_s"], tm["witness_map_s"], tm["msm_s"]))
+    L.cb_set_threads(hw)
+    times.sort()
+    med, med_w, med_m = times[len(times) // 2]
+    return {"value": n / med, "unit": "constraints/s", "cores": cores, "kind": "port", "parity_vs_oracle": parity,
+            "sample": "oracle/c (arkworks-algorithm C restatement; Pippenger tasks = window x term-chunk, OpenMP x%d): "
+                      "median of %d Groth16/%s proofs of THE BENCH'S OWN statement and key (S2 mulchain, n = %d, N = 2^%d), "
+                      "%.3f s each (witness map %.3f s, MSMs + tail %.3f s), assignment in host memory -> proof%s"
+                      % (cores, len(times), curve_name, n, N.bit_length() - 1, med, med_w, med_m,
+                         ("; host shows %d hardware threads, container CPU quota %.1f cores" % (hw, quota)) if quota else "")}
+
+
+def bench_prove(curve_name="bls12_381", log_n=None, budget_s=20.0, workload=None):
     """cpu_baseline for bench.py: the C restatement on all host cores, on the benchmark's own configuration (S2
-    mulchain, n = 2^20, N = 2^21) whenever the host has the cores to finish a proof in seconds (>= 32 threads);
+    mulchain, n = 2^20, N = 2^21) whenever the host has the cores to finish a proof in seconds (>= 12 threads);
     smaller hosts time a 2^16 sample and say so.  Same timing window as the GPU figure: assignment resident in host
     memory -> three affine proof points.  Bases are k_i*G made with the C fixed-base routine
-    (their distribution does not affect Pippenger's cost)."""
+    (their distribution does not affect Pippenger's cost).
+
+    workload (round 6; the oracle as CHECKER of the bench's own proofs): dict(n, ell, w, mats, z = Montgomery bytes, pk = raw
+    key arrays under the names of ark355_pk_desc, r, s, proof = (a, b, c) raw affine bytes the GPU returned for (z, r, s)).
+    When the host can time the full size, the timed CPU proofs run on THIS statement and key, the first of them with the
+    bench's (r, s), and its bytes are compared with the GPU's: the line then reports `parity_vs_oracle`."""
     from .. import synthetic as S
     from .. import serialize as Z
     cv = CURVES[curve_name]
@@ -284,6 +316,8 @@ def bench_prove(curve_name="bls12_381", log_n=None, budget_s=20.0):
     L.cb_set_threads(cores)
     if log_n is None:
         log_n = 20 if cores >= 12 else 16
+    if workload is not None and workload["n"] == (1 << log_n):
+        return _bench_prove_workload(cv, curve_name, L, hw, quota, cores, log_n, budget_s, workload)
     n, ell, w, mats, z = S.mulchain_csr(cv.r, 1 << log_n)
     m = ell + w
     N = 1

@@ -49,6 +49,7 @@ SYMBOLS = [
     "ark355_points_decode", "ark355_points_encode", "ark355_proof_to_bytes", "ark355_proof_from_bytes",
     "ark355_setup_scalars", "ark355_verify_batch",
     "ark355_ctx_set_policy", "ark355_ctx_get_policy", "ark355_sched_info", "ark355_sched_reset", "ark355_diag_streams", "ark355_diag_dispatch",
+    "ark355_diag_mad_rate", "ark355_diag_clocks",
 ]
 
 SCHED_NAMES = {-1: "auto", 0: "one_stream", 1: "pipeline", 2: "pipeline_sync", 3: "one_stream_spin"}
@@ -177,6 +178,8 @@ class Lib:
         d.ark355_sched_reset.argtypes = [vp]
         d.ark355_diag_streams.argtypes = [vp, u32, vp]
         d.ark355_diag_dispatch.argtypes = [vp, u32, u32, P(C.c_float), P(u32)]
+        d.ark355_diag_mad_rate.argtypes = [vp, C.c_float, P(C.c_float), P(C.c_float)]
+        d.ark355_diag_clocks.argtypes = [vp, P(u64)]
         d.ark355_get_timings.argtypes = [vp, P(Timings)]
         d.ark355_get_kernel_stats.argtypes = [vp, P(C.c_float), P(u64), P(u64)]
         for name in SYMBOLS:
@@ -228,6 +231,18 @@ class Lib:
         gap, lanes = C.c_float(0), C.c_uint32(0)
         self.check(ctx, self.dll.ark355_diag_dispatch(ctx, launches, spin_us, C.byref(gap), C.byref(lanes)))
         return {"gap_us": round(float(gap.value), 2), "launches": launches, "spin_us": spin_us, "lanes": int(lanes.value)}
+
+    def diag_mad_rate(self, ctx, target_ms=20.0):
+        """T (10^12) v_mad_u64_u32 per second this box issues right now at the accumulation kernels' occupancy (< 0: emulator)."""
+        rate, ms = C.c_float(0), C.c_float(0)
+        self.check(ctx, self.dll.ark355_diag_mad_rate(ctx, float(target_ms), C.byref(rate), C.byref(ms)))
+        return {"tmad_per_s": float(rate.value), "elapsed_ms": float(ms.value)}
+
+    def diag_clocks(self, ctx):
+        """(shader-clock cycles, ticks of the constant 100 MHz reference) read on the GPU at the same moment."""
+        out = (C.c_uint64 * 2)()
+        self.check(ctx, self.dll.ark355_diag_clocks(ctx, out))
+        return int(out[0]), int(out[1])
 
     def sched_reset(self, ctx):
         self.check(ctx, self.dll.ark355_sched_reset(ctx))

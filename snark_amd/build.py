@@ -71,7 +71,31 @@ def build(force=False, verbose=True, resource_log=False):
     if verbose:
         print("[snark_amd.build]", " ".join(cmd), flush=True)
     subprocess.check_call(cmd)
+    write_stats(OUT, verbose)
     return OUT
+
+
+def write_stats(lib_path, verbose=False):
+    """Instruction counts of the shipped kernels, read from the code objects inside the library just linked
+    (tools/code_object_stats.py): libark355.stats.json next to it.  bench.py prices its integer roofline with the
+    multiply-adds per mixed addition found there; the file also records the scratch accesses of the hot loops."""
+    import json
+    tools = os.path.normpath(os.path.join(HERE, "..", "tools"))
+    path = os.path.splitext(lib_path)[0] + ".stats.json"
+    try:
+        sys.path.insert(0, tools)
+        import code_object_stats
+        st = code_object_stats.library_stats(lib_path)
+        with open(path, "w") as f:
+            json.dump(st, f, indent=1, sort_keys=True)
+        if verbose:
+            print("[snark_amd.build] kernel statistics ->", path, flush=True)
+    except Exception as e:                                    # noqa: BLE001 -- statistics are not part of the product
+        if verbose:
+            print("[snark_amd.build] no kernel statistics (%s)" % e, flush=True)
+    finally:
+        if tools in sys.path:
+            sys.path.remove(tools)
 
 
 def build_host_mirror_exe(verbose=False):

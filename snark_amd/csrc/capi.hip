@@ -49,14 +49,16 @@ CtxExtra::~CtxExtra() {
   for (ark355_ctx* c : lanes) ark355_ctx_destroy(c);
 }
 
+// locked: the caller already holds ctx->mu (ark355_diag_streams takes every context's mutex in one sorted try-lock pass)
 template <class Fn>
-int32_t guarded(ark355_ctx* ctx, Fn&& fn) {
+int32_t guarded(ark355_ctx* ctx, Fn&& fn, bool locked = false) {
   try {
-    if (ctx) {
+    if (ctx && !locked) {
       std::lock_guard<std::mutex> lk(ctx->mu);
       (void)hipSetDevice(ctx->device);
       fn();
     } else {
+      if (ctx) (void)hipSetDevice(ctx->device);
       fn();
     }
     return ARK355_OK;
@@ -205,18 +207,25 @@ int32_t ark355_diag_streams(ark355_ctx** ctxs, uint32_t count, int8_t* serialise
   if (!ctxs || !serialised || count == 0 || count > 16) return ARK355_EINVAL;
   for (uint32_t i = 0; i < count; i++)
     if (!ctxs[i]) return ARK355_EINVAL;
-  // The probe synchronises and launches on EVERY passed context's stream: the other contexts are locked too (in address order:
-  // two callers with overlapping sets cannot deadlock), and a context that is proving right now makes the call fail instead of
-  // racing with it.
-  std::vector<ark355_ctx*> others;
-  for (uint32_t i = 1; i < count; i++)
-    if (ctxs[i] != ctxs[0] && std::find(others.begin(), others.end(), ctxs[i]) == others.end()) others.push_back(ctxs[i]);
-  std::sort(others.begin(), others.end());
+  // The probe synchronises and launches on EVERY passed context's stream, so every one of them is locked for its duration --
+  // ctxs[0] included, all in ONE pass of try-locks in address order: no caller ever blocks while it holds a mutex, so two callers
+  // with overlapping sets cannot deadlock (ctxs[0] used to be locked blockingly after the others), and a context
+  // that is proving right now makes the call fail instead of racing with it.  The bookkeeping allocates: it
+  // sits inside the same exception mapping as everything else.
   std::vector<std::unique_lock<std::mutex>> held;
-  for (ark355_ctx* c : others) {
-    std::unique_lock<std::mutex> lk(c->mu, std::try_to_lock);
-    if (!lk.owns_lock()) return ARK355_EINVAL;          // busy: the diagnostic wants an idle device
-    held.push_back(std::move(lk));
+  try {
+    std::vector<ark355_ctx*> all(ctxs, ctxs + count);
+    std::sort(all.begin(), all.end());
+    all.erase(std::unique(all.begin(), all.end()), all.end());
+    for (ark355_ctx* c : all) {
+      std::unique_lock<std::mutex> lk(c->mu, std::try_to_lock);
+      if (!lk.owns_lock()) return ARK355_EINVAL;          // busy: the diagnostic wants an idle device
+      held.push_back(std::move(lk));
+    }
+  } catch (const std::bad_alloc&) {
+    return ARK355_ENOMEM;
+  } catch (...) {
+    return ARK355_EINVAL;
   }
   // streams probed: every context's own stream, then the three feeder streams of ctxs[0] (created if need be)
   return guarded(ctxs[0], [&] {
@@ -231,7 +240,7 @@ int32_t ark355_diag_streams(ark355_ctx** ctxs, uint32_t count, int8_t* serialise
     for (size_t i = 0; i < n; i++)
       for (size_t j = 0; j < n; j++)
         serialised[i * n + j] = (int8_t)(i == j ? 1 : diag_streams_serialised(st[i], st[j]));
-  });
+  }, /*locked=*/true);
 }
 int32_t ark355_diag_dispatch(ark355_ctx* ctx, uint32_t launches, uint32_t spin_us, float* gap_us, uint32_t* lanes) {
   if (!ctx || !gap_us || launches == 0 || launches > 100000 || spin_us > 100000) return ARK355_EINVAL;
@@ -239,6 +248,14 @@ int32_t ark355_diag_dispatch(ark355_ctx* ctx, uint32_t launches, uint32_t spin_u
     *gap_us = diag_dispatch_gap_us(ctx->stream, launches, spin_us);
     if (lanes) *lanes = (uint32_t)LanePool::of(ctx->device).size();
   });
+}
+int32_t ark355_diag_mad_rate(ark355_ctx* ctx, float target_ms, float* tmad_per_s, float* elapsed_ms) {
+  if (!ctx || !tmad_per_s || !(target_ms >= 0.1f) || target_ms > 1000.f) return ARK355_EINVAL;
+  return guarded(ctx, [&] { *tmad_per_s = diag_mad_rate_t(ctx->stream, ctx->device, target_ms, elapsed_ms); });
+}
+int32_t ark355_diag_clocks(ark355_ctx* ctx, uint64_t out[2]) {
+  if (!ctx || !out) return ARK355_EINVAL;
+  return guarded(ctx, [&] { diag_clocks(ctx->stream, out); });
 }
 int32_t ark355_sched_reset(const ark355_ctx* ctx) {
   if (!ctx) return ARK355_EINVAL;

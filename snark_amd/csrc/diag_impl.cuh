@@ -91,6 +91,107 @@ static inline float diag_dispatch_gap_us(hipStream_t st, uint32_t launches = 200
 #endif
 }
 
+// The chip's sustained v_mad_u64_u32 issue rate on THIS box, NOW: the instruction the bucket-accumulation kernels are made of
+// (field28.cuh; 71 % of their instructions), at their occupancy (two waves per SIMD), eight independent chains per lane so that
+// the multiplier's latency is covered.  The rate follows the gfx clock the box sustains under its power cap (2.1-2.3 GHz on the
+// pool this was developed on: a 4-5 % spread in every proof time), so bench.py prices `roofline.alu` against THIS number instead
+// of a constant read off another box, and reports its times in units of it.  Two launches: a short one to size the second,
+// which runs for about target_ms.  Returns T (10^12) multiply-adds per second; < 0: not measurable on this build.
+#if !defined(ARK_EMUL)
+static __global__ void __launch_bounds__(256, 2) diag_mad_kernel(uint64_t* sink, uint32_t a0, uint32_t iters) {
+  const uint32_t a = a0 + threadIdx.x, b = (a0 * 2654435761u) ^ (blockIdx.x * 256u + threadIdx.x);
+  uint64_t acc[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) acc[i] = (uint64_t)(i * 77 + a) << 7;
+  for (uint32_t it = 0; it < iters; it++) {
+#pragma unroll
+    for (int rep = 0; rep < 4; rep++) {
+#pragma unroll
+      for (int i = 0; i < 8; i++) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc[i]) : "v"(a), "v"(b) : "vcc");
+    }
+  }
+  uint64_t s = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) s += acc[i];
+  if (s == 0x5a5a5a5a5a5a5a5aull) *sink = s;        // (never true in practice: keeps the chains alive)
+}
+#endif
+static inline float diag_mad_rate_t(hipStream_t st, int device, float target_ms, float* elapsed_ms) {
+#if defined(ARK_EMUL)
+  (void)st; (void)device; (void)target_ms;
+  if (elapsed_ms) *elapsed_ms = 0.f;
+  return -1.f;
+#else
+  int cus = 0;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus <= 0) cus = 256;
+  const uint32_t grid = (uint32_t)cus * 2u;          // two workgroups of four waves per CU: two waves per SIMD
+  DevBuf sink(8);
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  ARK_CHECK_HIP(hipEventCreate(&e0));
+  ARK_CHECK_HIP(hipEventCreate(&e1));
+  float ms = 0.f;
+  uint32_t iters = 4000;
+  try {
+    // (an untimed first launch: the one-off cost of loading the kernel must not end up in the sizing pass -- it did in the first
+    // version, the measuring launch came out ten times too short and read 7 % low)
+    ARK_LAUNCH(diag_mad_kernel, dim3(grid), dim3(256), 0, st, sink.as<uint64_t>(), 1u, 64u);
+    ARK_CHECK_LAUNCH();
+    for (int pass = 0; pass < 2; pass++) {
+      ARK_CHECK_HIP(hipEventRecord(e0, st));
+      ARK_LAUNCH(diag_mad_kernel, dim3(grid), dim3(256), 0, st, sink.as<uint64_t>(), 12345u + (uint32_t)pass, iters);
+      ARK_CHECK_LAUNCH();
+      ARK_CHECK_HIP(hipEventRecord(e1, st));
+      ARK_CHECK_HIP(hipEventSynchronize(e1));
+      ARK_CHECK_HIP(hipEventElapsedTime(&ms, e0, e1));
+      if (pass == 0) {
+        const double scale = (ms > 1e-3 ? (double)target_ms / ms : 1.0);
+        double it2 = (double)iters * scale;
+        if (it2 < 1000.0) it2 = 1000.0;
+        if (it2 > 4.0e7) it2 = 4.0e7;
+        iters = (uint32_t)it2;
+      }
+    }
+  } catch (...) {
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    throw;
+  }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  if (elapsed_ms) *elapsed_ms = ms;
+  const double mads = (double)grid * 256.0 * (double)iters * 32.0;
+  return ms > 0.f ? (float)(mads / ((double)ms * 1e-3) / 1e12) : -1.f;
+#endif
+}
+
+// The two free-running counters of the GPU, read by one lane at the same moment: s_memtime counts SHADER-CLOCK cycles (it slows
+// down and speeds up with the gfx clock the power management grants), s_memrealtime a constant 100 MHz reference.  Two readings
+// bracket a region: (shader cycles elapsed) / (work done) is a time in units that do not depend on which clock THIS box sustained
+// under its power cap, and (shader cycles) / (reference ticks) x 100 MHz is the mean gfx clock of the region, measured on the
+// chip itself rather than sampled over SMI.  out[0] = shader cycles, out[1] = 100 MHz ticks; zeros on builds that cannot tell.
+#if !defined(ARK_EMUL)
+static __global__ void diag_clocks_kernel(uint64_t* out) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    const uint64_t a = __builtin_readcyclecounter();        // s_memtime
+    const uint64_t b = wall_clock64();                      // s_memrealtime
+    out[0] = a;
+    out[1] = b;
+  }
+}
+#endif
+static inline void diag_clocks(hipStream_t st, uint64_t out[2]) {
+  out[0] = out[1] = 0;
+#if defined(ARK_EMUL)
+  (void)st;
+#else
+  DevBuf d(16);
+  ARK_LAUNCH(diag_clocks_kernel, dim3(1), dim3(64), 0, st, d.as<uint64_t>());
+  ARK_CHECK_LAUNCH();
+  ARK_CHECK_HIP(hipMemcpyAsync(out, d.p, 16, hipMemcpyDeviceToHost, st));
+  ARK_CHECK_HIP(hipStreamSynchronize(st));
+#endif
+}
+
 // Streams for one-stream proofs ("lanes"), one set per device: created back to back at the first request and then
 // PROBED so that the set handed out sits on pairwise different hardware queues (diag_streams_serialised).  Round 4 found
 // two of bench.py's four context streams on one queue on a fresh box -- two of the four proofs "in flight" took turns --

@@ -648,34 +648,112 @@ ARK_HD_NOINLINE typename Fp28<P>::Vec dbl28_g2_coord_ni(Fp28<P> x, Fp28<P> y, in
 // The addition comes in two halves so that the accumulation loop can issue the gather of the NEXT table row between
 // them: after the first half px / py are dead, and the row's latency hides under the eight products of the second.
 // madd28_g2_head returns false when the entry is already dealt with (bucket opened, doubling, cancellation).
+// Where zz / zzz of the pair's accumulator live between their uses.  ZzRegs: in the accumulator's own registers.  ZzLds
+// (round 6): in LDS.  The lane-pair addition over BLS12-381 does not fit 256 registers -- the code object of the first
+// round-6 library shows the allocator writing three 14-limb values (new zz, new zzz and one more) to scratch memory while
+// the fused Y3 pass runs and fetching them back at the end of every addition: 53 scratch loads + 41 stores per iteration
+// (tools/code_object_stats.py), and the kernel 11 % slower than round 5's (7.17 against 6.47 ms per 2^20-term launch), whose
+// spills happened to sit in the flush path.  zz and zzz are each read twice and written once per addition, so they are the
+// cheapest state to keep elsewhere, and so are x and y (the new x is dead during the fused Y3 pass, where the pressure peaks;
+// with all four there the listing shows 5 scratch loads + 4 stores per addition): 4 x 4 b128 slots per lane (256 B; 64 KiB for
+// 256 lanes, two workgroups per CU), every lane on its own consecutive 16-byte column, i.e. conflict-free: 32 ds_read_b128 +
+// 16 ds_write_b128 per addition of ~7 600 instructions.
 template <class P>
-ARK_D bool madd28_g2_head(Acc28<P>& acc, bool& empty, const Fp28<P>& px, const Fp28<P>& py, bool negate,
+struct ZzRegs {
+  Acc28<P>& a;
+  ARK_D Fp28<P> zz() const { return a.zz; }
+  ARK_D Fp28<P> zzz() const { return a.zzz; }
+  ARK_D Fp28<P> x() const { return a.x; }
+  ARK_D Fp28<P> y() const { return a.y; }
+  ARK_D void set_y(const Fp28<P>& v) const { a.y = v; }
+  ARK_D void set_zz(const Fp28<P>& v) const { a.zz = v; }
+  ARK_D void set_zzz(const Fp28<P>& v) const { a.zzz = v; }
+  ARK_D void set_x(const Fp28<P>& v) const { a.x = v; }
+};
+#ifndef ARK_G2L28_LDS_VALUES
+#define ARK_G2L28_LDS_VALUES 4      // how many of zz, zzz, x, y (in that order) live in LDS: 0 (none: rounds 2-5), 2, 3, 4
+#endif
+template <class P>
+struct ZzLds {
+  using F = Fp28<P>;
+  static constexpr int N = F::N, QN = (N + 3) / 4;
+  static constexpr int VALUES = ARK_G2L28_LDS_VALUES < 2 ? 2 : ARK_G2L28_LDS_VALUES;
+  Acc28<P>& a;        // the coordinates that stay in registers
+  uint4* mine;        // quad q of value s (0: zz, 1: zzz, 2: x, 3: y) sits at mine[(s * QN + q) * stride]
+  uint32_t stride;    // lanes of the workgroup
+  static size_t bytes(uint32_t threads) { return (size_t)VALUES * QN * threads * sizeof(uint4); }
+  // (the barrier keeps the compiler from serving a later read out of registers it loaded earlier: the point of the exercise
+  // is that the value is NOT live in between)
+  ARK_D F get(int s) const {
+    asm volatile("" ::: "memory");
+    F r;
+#pragma unroll
+    for (int q = 0; q < QN; q++) {
+      const uint4 t = mine[(size_t)(s * QN + q) * stride];
+      r.l[4 * q] = t.x;
+      if (4 * q + 1 < N) r.l[4 * q + 1] = t.y;
+      if (4 * q + 2 < N) r.l[4 * q + 2] = t.z;
+      if (4 * q + 3 < N) r.l[4 * q + 3] = t.w;
+    }
+    return r;
+  }
+  ARK_D void put(int s, const F& v) const {
+#pragma unroll
+    for (int q = 0; q < QN; q++)
+      mine[(size_t)(s * QN + q) * stride] = make_uint4(v.l[4 * q], 4 * q + 1 < N ? v.l[4 * q + 1] : 0u, 4 * q + 2 < N ? v.l[4 * q + 2] : 0u,
+                                                         4 * q + 3 < N ? v.l[4 * q + 3] : 0u);
+  }
+  ARK_D F zz() const { return get(0); }
+  ARK_D F zzz() const { return get(1); }
+  ARK_D void set_zz(const F& v) const { put(0, v); }
+  ARK_D void set_zzz(const F& v) const { put(1, v); }
+  ARK_D F x() const {
+    if constexpr (VALUES > 2) return get(2);
+    else return a.x;
+  }
+  ARK_D void set_x(const F& v) const {
+    if constexpr (VALUES > 2) put(2, v);
+    else a.x = v;
+  }
+  ARK_D F y() const {
+    if constexpr (VALUES > 3) return get(3);
+    else return a.y;
+  }
+  ARK_D void set_y(const F& v) const {
+    if constexpr (VALUES > 3) put(3, v);
+    else a.y = v;
+  }
+};
+
+template <class P, class Z>
+ARK_D bool madd28_g2_head(Acc28<P>& acc, const Z& z, bool& empty, const Fp28<P>& px, const Fp28<P>& py, bool negate,
                           Fp28<P>& Pd, Fp28<P>& R) {
   using F = Fp28<P>;
   using L = Pair28<P>;
   const F pys = L::sel(negate, F::template neg<2, 1>(py), py);
   if (empty) {
     const F one = L::odd() ? F::zero() : F::from_vec(one28_ni<P>());
-    acc.x = px;
-    acc.y = F::norm(pys);
-    acc.zz = one;
-    acc.zzz = one;
+    z.set_x(px);
+    z.set_y(F::norm(pys));
+    z.set_zz(one);
+    z.set_zzz(one);
     empty = false;
     return false;
   }
-  const F U2 = L::template mul<2, 1>(px, acc.zz);
-  const F S2 = L::template mul<3, 3>(pys, acc.zzz);          // pys limbs <= 2^29 - 1
-  Pd = F::norm(F::template sub<8, 1>(U2, acc.x));
-  R = F::norm(F::template sub<3, 1>(S2, acc.y));
+  const F U2 = L::template mul<2, 1>(px, z.zz());
+  const F S2 = L::template mul<3, 3>(pys, z.zzz());          // pys limbs <= 2^29 - 1
+  Pd = F::norm(F::template sub<8, 1>(U2, z.x()));
+  R = F::norm(F::template sub<3, 1>(S2, z.y()));
   if (L::both(Pd.multiple_hint() < 10u)) {
     if (L::both(F::is_zero_mod_p_inl(Pd))) {
       if (L::both(F::is_zero_mod_p_inl(R))) {
         const F yn = F::norm(pys);
-        acc.x = F::from_vec(dbl28_g2_coord_ni<P>(px, yn, 0));
-        acc.y = F::from_vec(dbl28_g2_coord_ni<P>(px, yn, 1));
-        acc.zz = F::from_vec(dbl28_g2_coord_ni<P>(px, yn, 2));
-        acc.zzz = F::from_vec(dbl28_g2_coord_ni<P>(px, yn, 3));
-        if (L::both(acc.zz.limbs_all_zero())) empty = true;
+        z.set_x(F::from_vec(dbl28_g2_coord_ni<P>(px, yn, 0)));
+        z.set_y(F::from_vec(dbl28_g2_coord_ni<P>(px, yn, 1)));
+        const F nzz = F::from_vec(dbl28_g2_coord_ni<P>(px, yn, 2));
+        z.set_zz(nzz);
+        z.set_zzz(F::from_vec(dbl28_g2_coord_ni<P>(px, yn, 3)));
+        if (L::both(nzz.limbs_all_zero())) empty = true;
       } else {
         empty = true;
       }
@@ -684,26 +762,32 @@ ARK_D bool madd28_g2_head(Acc28<P>& acc, bool& empty, const Fp28<P>& px, const F
   }
   return true;
 }
-template <class P>
-ARK_D void madd28_g2_tail(Acc28<P>& acc, const Fp28<P>& Pd, const Fp28<P>& R) {
+template <class P, class Z>
+ARK_D void madd28_g2_tail(Acc28<P>& acc, const Z& z, const Fp28<P>& Pd, const Fp28<P>& R) {
   using F = Fp28<P>;
   using L = Pair28<P>;
   const F PP = L::template sqr<11>(Pd);
   const F PPP = L::template mul<11, 1>(Pd, PP);
-  const F Q = L::template mul<8, 1>(acc.x, PP);
-  acc.zz = L::template mul<3, 1>(acc.zz, PP);
-  acc.zzz = L::template mul<3, 1>(acc.zzz, PPP);
+  const F Q = L::template mul<8, 1>(z.x(), PP);
+  z.set_zz(L::template mul<3, 1>(z.zz(), PP));
+  z.set_zzz(L::template mul<3, 1>(z.zzz(), PPP));
   const F W = F::add(PPP, F::add(Q, Q));
   const F X3 = F::norm(F::add(L::template sqr<6>(R), F::template neg<5, 4>(W)));
   const F T = F::norm(F::template sub<8, 1>(Q, X3));
-  const F NY = F::template neg<3, 1>(acc.y);
-  acc.y = L::template mul2<6, 1, 4, 3>(R, T, NY, PPP);
-  acc.x = X3;
+  const F NY = F::template neg<3, 1>(z.y());
+  z.set_x(X3);
+  z.set_y(L::template mul2<6, 1, 4, 3>(R, T, NY, PPP));
 }
+template <class P, class Z>
+ARK_D void madd28_g2z(Acc28<P>& acc, const Z& z, bool& empty, const Fp28<P>& px, const Fp28<P>& py, bool negate) {
+  Fp28<P> Pd, R;
+  if (madd28_g2_head<P, Z>(acc, z, empty, px, py, negate, Pd, R)) madd28_g2_tail<P, Z>(acc, z, Pd, R);
+}
+// (zz / zzz in the accumulator's registers: the packed-row kernel, BN254, tests)
 template <class P>
 ARK_D void madd28_g2(Acc28<P>& acc, bool& empty, const Fp28<P>& px, const Fp28<P>& py, bool negate) {
-  Fp28<P> Pd, R;
-  if (madd28_g2_head<P>(acc, empty, px, py, negate, Pd, R)) madd28_g2_tail<P>(acc, Pd, R);
+  const ZzRegs<P> z{acc};
+  madd28_g2z<P, ZzRegs<P>>(acc, z, empty, px, py, negate);
 }
 
 #ifndef ARK_G2L28_WAVES
@@ -714,7 +798,11 @@ ARK_D void madd28_g2(Acc28<P>& acc, bool& empty, const Fp28<P>& px, const Fp28<P
 // Key, row index and this lane's half row are loaded at the top of every iteration: held in registers across the lane-pair
 // addition the half row (28 VGPRs) pushes the hot loop into scratch memory, and loading ahead was measured neutral in
 // round 2 (an addition is 2.2x as long as in G1; waits for memory are a few percent of a wave's cycles).
+// ZLDS: zz / zzz of the accumulator in LDS (ZzLds above; dynamic LDS of ZzLds<P>::bytes(blockDim.x)); the host asks for it
+// where the registers do not suffice (g2l28_zz_in_lds: 14-limb fields).
 template <class P>
+constexpr bool g2l28_zz_in_lds() { return ARK_G2L28_LDS_VALUES > 0 && Fp28<P>::N > 12; }
+template <class P, bool ZLDS>
 __global__ void __launch_bounds__(MSM_THREADS, ARK_G2L28_WAVES)
 msm_accumulate_g2l28_kernel(const Affine28G2<P, false>* __restrict__ bases, const uint32_t* __restrict__ sorted_keys,
                             const uint32_t* __restrict__ sorted_vals, const uint32_t* __restrict__ total_ptr,
@@ -723,6 +811,7 @@ msm_accumulate_g2l28_kernel(const Affine28G2<P, false>* __restrict__ bases, cons
                             uint32_t* __restrict__ head_key, Msm28Slot<P, 8>* __restrict__ tail,
                             uint32_t* __restrict__ tail_key, uint32_t seg_len) {
   using F = Fp28<P>;
+  using Zt = typename std::conditional<ZLDS, ZzLds<P>, ZzRegs<P>>::type;
   constexpr int Q = Affine28U<P>::Q;
   const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t seg = gid >> 1, par = gid & 1u;       // blockDim is even: par == lane parity
@@ -740,9 +829,22 @@ msm_accumulate_g2l28_kernel(const Affine28G2<P, false>* __restrict__ bases, cons
   acc.y = F::zero();
   acc.zz = F::zero();
   acc.zzz = F::zero();
+  ARK_DYN_SMEM(uint4, zlds);
+  Zt z = [&]() {
+    if constexpr (ZLDS) return ZzLds<P>{acc, zlds + threadIdx.x, blockDim.x};
+    else return ZzRegs<P>{acc};
+  }();
   // always_inline: a closure that is inlined late keeps every captured variable (the accumulator!) in scratch memory
   auto flush = [&](uint32_t key, uint32_t run_end) __attribute__((always_inline)) {
     // this lane's component of the four Fq2 coordinates: half `par` of the pair's slot
+    if constexpr (ZLDS) {
+      if (!empty) {
+        acc.x = z.x();
+        acc.y = z.y();
+        acc.zz = z.zz();
+        acc.zzz = z.zzz();
+      }
+    }
     msm_flush_slot28<P>(&buckets->half[par], &head->half[par], &tail->half[par], head_key, tail_key, par == 0, key, acc, empty,
                         first_run, run_start, run_end, seg, offsets, counts, sizeof(Slot28G2<P>));
   };
@@ -778,7 +880,7 @@ msm_accumulate_g2l28_kernel(const Affine28G2<P, false>* __restrict__ bases, cons
 #pragma unroll
     for (int k = 0; k < F::N; k++) any |= px.l[k] | py.l[k];
     if ((any | ark_pair_xchg(any)) == 0) continue;       // base at infinity (pair-wide)
-    madd28_g2<P>(acc, empty, px, py, (v >> 31) != 0);
+    madd28_g2z<P, Zt>(acc, z, empty, px, py, (v >> 31) != 0);
   }
   flush(cur_key, end);
 }

@@ -1663,7 +1663,9 @@ static void msm_accumulate_phase(ark355_ctx* ctx, const MsmSort& s, MsmBuckets& 
                  s.counts.as<uint32_t>(), msm_slots28<P, 8>(b, p.total_buckets, 0), msm_slots28<P, 8>(b, p.total_buckets, 1),
                  b.head_key.as<uint32_t>(), msm_slots28<P, 8>(b, p.total_buckets, 2), b.tail_key.as<uint32_t>(), b.seg_len);
     } else if (fmt == 1) {
-      ARK_LAUNCH((msm_accumulate_g2l28_kernel<P>), dim3((2 * segs + acc_t - 1) / acc_t), dim3(acc_t), 0, stream,
+      constexpr bool ZL = g2l28_zz_in_lds<P>();
+      ARK_LAUNCH((msm_accumulate_g2l28_kernel<P, ZL>), dim3((2 * segs + acc_t - 1) / acc_t), dim3(acc_t),
+                 ZL ? ZzLds<P>::bytes(acc_t) : (size_t)0, stream,
                  reinterpret_cast<const Affine28G2<P, false>*>(d_bases), s.sorted_keys.as<uint32_t>(),
                  s.sorted_vals.as<uint32_t>(), s.total.as<uint32_t>(), s.offsets.as<uint32_t>(),
                  s.counts.as<uint32_t>(), msm_slots28<P, 8>(b, p.total_buckets, 0), msm_slots28<P, 8>(b, p.total_buckets, 1),
