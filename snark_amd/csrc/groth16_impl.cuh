@@ -611,7 +611,9 @@ static void prove_run(ark355_ctx* ctx, ProverScratch& sc, const PkDev& pk, const
       // communicator serves them all.  The bucket-ring exchange interleaves its own send / receive steps with the MSMs
       // and therefore keeps the replicated map.
       d_h = witness_map_dist_run<Curve>(ctx, r1, sc.zx.p, sc.dwm, cm, pk.shard_count, pk.shard_index, sW, /*loopback=*/!cm,
-                                        /*self_rccl=*/cm && pk.shard_count == 1 && pol.rccl_self != 0);
+                                        // a whole key in the distributed layout exists only when it was loaded under policy
+                                        // RCCL_SELF: the KEY says that the rank is its own peer, whatever the policy reads now
+                                        /*self_rccl=*/cm && pk.shard_count == 1);
       if (trace_host)
         fprintf(stderr, "[ark355] witness map distributed over %u ranks (rank %u: N / G = %llu elements per vector)%s\n", pk.shard_count,
                 pk.shard_index, (unsigned long long)(pk.N / pk.shard_count), cm ? "" : " -- LOOPBACK exchange, timing only");

@@ -110,6 +110,31 @@ def check_instance(lib, ctx, C, inst, rs_pairs, batch=0, inflight=4, sharded=Fal
                     got_s = lib.prove_sharded(ctx, comm, pkh, rh, zb, len(z), Z.fr_canon(C, r_), Z.fr_canon(C, s_), sizes,
                                               mode=mode)
                     assert got_s == exp, (C.name, n, "ark355_prove_sharded vs oracle/c", mode)
+        if sharded:
+            # Policy RCCL_SELF: the key loaded AGAIN, now in the layout of the distributed witness map, whose three all-to-all
+            # exchanges run as grouped ncclSend / ncclRecv pairs of rank 0 with itself, and the bucket ring makes one step with
+            # itself per MSM -- the point-to-point calls of an 8-GPU proof on the one GPU there is, compared with the ORACLE's
+            # proof at this size (the self exchange had only met the package's own closed form at n = 300).
+            # The policy is reset BEFORE the proofs: the key, not the policy of the moment, says that the rank is its own peer.
+            lib.ctx_set_policy(ctx, "RCCL_SELF", 1)
+            try:
+                pkh2, rh2 = load(lib, ctx, C, inst, pk)
+            finally:
+                lib.ctx_set_policy(ctx, "RCCL_SELF", 0)
+            try:
+                r_, s_ = rs_pairs[0]
+                exp = oracle_prove(C, inst, zb, pk, r_, s_)
+                got_s = lib.prove_sharded(ctx, comm, pkh2, rh2, zb, len(z), Z.fr_canon(C, r_), Z.fr_canon(C, s_), sizes, mode=SHARD_WINDOW)
+                assert got_s == exp, (C.name, n, "RCCL_SELF: distributed witness map over ncclSend / ncclRecv vs oracle/c")
+                lib.ctx_set_policy(ctx, "RCCL_SELF", 1)
+                got_s = lib.prove_sharded(ctx, comm, pkh2, rh2, zb, len(z), Z.fr_canon(C, r_), Z.fr_canon(C, s_), sizes, mode=SHARD_BUCKET_RING)
+                assert got_s == exp, (C.name, n, "RCCL_SELF: bucket ring with itself vs oracle/c")
+                lib.ctx_set_policy(ctx, "RCCL_SELF", 0)
+                # the same key through the plain entry point: replicated map + gather of the rank's coefficients
+                assert lib.prove(ctx, pkh2, rh2, zb, len(z), Z.fr_canon(C, r_), Z.fr_canon(C, s_), sizes) == exp
+            finally:
+                lib.ctx_set_policy(ctx, "RCCL_SELF", 0)
+                free(lib, pkh2, rh2)
         t3 = time.perf_counter()
         if batch:
             rnd = random.Random(batch)

@@ -271,3 +271,26 @@ def test_prove_one_stream_schedule(gpu_lib, gpu_ctx, gpu_policy, serial):
     C = BLS12_381
     A, B, Cm, z, ell = S.mulchain_direct(C.r, 300)
     pc.prove_case(gpu_lib, gpu_ctx, C, A, B, Cm, z, ell, verify=True)
+
+
+@pytest.mark.parametrize("C", CURVES, ids=lambda c: c.name)
+def test_check_satisfied_policy(gpu_lib, gpu_ctx, gpu_policy, C):
+    """Policy CHECK_SATISFIED (round 6): off, an unsatisfied assignment is proven as the reference's algorithm would prove it
+    (oracle O1, seven transforms -- the library's six-transform map agrees for any z); on, ARK355_E_UNSATISFIABLE with the
+    index of the first unsatisfied constraint, from ark355_prove and ark355_prove_batch alike."""
+    pc.check_satisfied_case(gpu_lib, gpu_ctx, C, gpu_policy, n=300)
+
+
+def test_box_diagnostics(gpu_lib, gpu_ctx):
+    """ark355_diag_mad_rate / ark355_diag_clocks (what bench.py's `roofline.alu.peak` and `box` block are made of): a plausible
+    multiply-add rate for a 256-CU part, and counters that move forward at a gfx clock between 0.5 and 3 GHz."""
+    import time
+    r = gpu_lib.diag_mad_rate(gpu_ctx, 5.0)
+    assert 10.0 < r["tmad_per_s"] < 60.0 and 1.0 < r["elapsed_ms"] < 50.0, r
+    c0 = gpu_lib.diag_clocks(gpu_ctx)
+    gpu_lib.diag_mad_rate(gpu_ctx, 5.0)
+    time.sleep(0.01)
+    c1 = gpu_lib.diag_clocks(gpu_ctx)
+    assert c1[0] > c0[0] and c1[1] > c0[1], (c0, c1)
+    ms = (c1[1] - c0[1]) / 1e5
+    assert 10.0 < ms < 2000.0, ms                     # the 100 MHz reference: about the 15+ ms that passed
