@@ -68,8 +68,8 @@ int32_t ark355_sizes(int32_t curve, uint32_t what[4]);
  *   per proof     SCHED (-1 measured choice [default], 0 one stream, 1 five-stream pipeline, 2 pipeline + epilogue stream
  *                 synchronises, 3 one stream + wait inside the HIP runtime), SCHED_EXPLORE (samples per schedule before the
  *                 measured choice latches; 0 = static defaults), WAIT_SPIN, WAIT_ADAPT, STREAM_PRIO, BATCH_TAILS,
- *                 SIDE_G2_TAILS, SIDE_WM (a proof alone on the device: G2 tails / witness map on side streams), SIDE_H_TAILS (pipeline:
- *                 the last MSM's tails on the sort stream),
+ *                 SIDE_G2_TAILS, SIDE_WM, SIDE_G1_TAILS (a proof alone on the device: G2 tails / witness map / the tails of A, B1, L' on
+ *                 side streams), SIDE_H_TAILS (pipeline: the last MSM's tails on the sort stream),
  *                 TRACE_HOST; legacy spellings SERIAL (1 -> SCHED 0, 0 -> SCHED 1) and EPILOGUE_SYNC (on a pipeline: 1 -> 2);
  *   per key load  MSM_C, MSM_C_H (window size of all tables / of the h_query table; 0 = planner), PACK_ROWS
  *                 (table rows bit-packed 1 / one word per limb 0 / per curve -1), TABLE_STRIDE, HBM_BUDGET_MB, SHARD_DIST_WM, RCCL_SELF (diagnostic: a rank at world size 1 exchanges with

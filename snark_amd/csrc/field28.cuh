@@ -12,7 +12,11 @@
 // R' = 2^(28 N) (R' = R * 2^SHIFT with R = 2^(32 NB) of field.cuh).  Values are NOT kept canonical:
 //   * "N"  (normalised): every limb < 2^28 except possibly the top one; value < 2^11 p.
 //   * "L1" (lazy):       limbs < 2^30 (sums / biased differences of N values).
-//   mul/mul2sum accept operands whose limb bounds 2^x, 2^y satisfy x + y <= 60 (see the column bound in mul) and
+//   mul/mul2sum accept operands whose limb bounds 2^x, 2^y satisfy x + y <= 60 (see the column bound in mul) AND,
+//   since the Karatsuba level of round 5 is the default (mulsum -> mulsum_kara), whose EVERY limb is below 2^31: the
+//   level multiplies signed differences of limbs (v_mad_i64_i32), so a 2^32 limb against a 2^28 limb -- legal for the
+//   schoolbook pass -- is not.  Every caller in this library stays below 2^30.6; the emulator build traps on a limb
+//   >= 2^31 (ARK_F28_TRAP in mulsum_kara), the device build does not check.  They
 //   return an N value < 1.05 p as long as the product of the operand VALUES is < 2^10 p^2 -- far above anything
 //   the mixed addition produces.  Only the kernel boundary converts: window tables are converted to this form
 //   once per key (from_fp), flushed bucket partials are converted back to the canonical 32-bit Montgomery form
@@ -374,6 +378,8 @@ struct Fp28 {
       kcol_hi<K + 1, J>(c, g, x, y, dx, dy, m, r);
     }
   }
+  // CONTRACT (beyond the column bound of mulsum_school): every limb of every operand < 2^31 -- the half differences below
+  // must fit a signed 32-bit multiplier operand.  Checked by the emulator build only.
   template <int J>
   ARK_HD static Fp28 mulsum_kara(const Fp28* const (&x)[J], const Fp28* const (&y)[J]) {
     int32_t dx[J][H], dy[J][H];

@@ -764,10 +764,24 @@ static void prove_run(ark355_ctx* ctx, ProverScratch& sc, const PkDev& pk, const
       const MsmSort* sorts[4] = {&sc.sortZ, &sc.sortZ, &sc.sortZ, &sc.sortH};
       MsmBuckets* bks[4] = {&sc.bkA, &sc.bkB1, &sc.bkL, &sc.bkH};
       XYZZ<Fq>* outs[4] = {g1res[0], g1res[1], g1res[2], g1res[3]};
-      const bool batched = msm_reduce_phase_batch<Fq>(ctx, 4, sorts, bks, outs, sR);
-      if (!batched)
-        for (int i = 0; i < 4; i++) msm_reduce_phase<Fq>(ctx, *sorts[i], *bks[i], outs[i], 0, sR);
-      if (trace_host) fprintf(stderr, "[ark355] G1 tails: %s\n", batched ? "one launch per step for the four MSMs" : "per MSM");
+      // Policy SIDE_G1_TAILS (lone proofs): the tails of A, B1, L' as a batch of three on the second stream, behind the G2 tails and
+      // under the H accumulation; the proof's stream ends with H's own tails alone.
+      const bool side_g1 = side_g2 && pol.side_g1_tails != 0;
+      bool batched;
+      if (side_g1) {
+        ARK_CHECK_HIP(hipStreamWaitEvent(sc.sR, ev[E_ACC_DONE0 + 3], 0));
+        batched = msm_reduce_phase_batch<Fq>(ctx, 3, sorts, bks, outs, sc.sR);
+        if (!batched)
+          for (int i = 0; i < 3; i++) msm_reduce_phase<Fq>(ctx, *sorts[i], *bks[i], outs[i], 0, sc.sR);
+        ARK_CHECK_HIP(hipEventRecord(ev[E_G2T], sc.sR));        // (re-recorded: now behind the G2 tails AND the batch of three)
+        msm_reduce_phase<Fq>(ctx, *sorts[3], *bks[3], outs[3], 0, sR);
+      } else {
+        batched = msm_reduce_phase_batch<Fq>(ctx, 4, sorts, bks, outs, sR);
+        if (!batched)
+          for (int i = 0; i < 4; i++) msm_reduce_phase<Fq>(ctx, *sorts[i], *bks[i], outs[i], 0, sR);
+      }
+      if (trace_host)
+        fprintf(stderr, "[ark355] G1 tails: %s%s\n", batched ? "one launch per step" : "per MSM", side_g1 ? " (A, B1, L' aside, H at the end)" : " for the four MSMs");
       if (side_g2) ARK_CHECK_HIP(hipStreamWaitEvent(sR, ev[E_G2T], 0));
     }
 

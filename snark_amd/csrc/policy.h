@@ -45,6 +45,8 @@ struct TunePolicy {
   int32_t batch_tails = 1;        // one-stream proofs: merge / reduce / combine of the four G1 MSMs as ONE launch each
   int32_t side_g2_tails = 1;      // a one-stream proof ALONE on the device: its G2 tails on a second stream, under the G1 accumulations
   int32_t side_wm = 1;            // ... and its witness map + the sort of h on a second stream, beside the sort of z and the first four accumulations
+  int32_t side_g1_tails = 0;      // a one-stream proof ALONE on the device: the tails of A, B1, L' as a batch of three on the second stream, under the
+                                  // H accumulation; only H's own tails at the end of the proof (round 6 re-run of round 5's run S on the 28-bit tails)
   int32_t side_h_tails = 1;       // multi-stream schedules: the tails of the last MSM (H) on the sort stream instead of behind the tails of L'
   int32_t dwm_loopback = 0;       // DIAGNOSTIC (timing only, wrong proofs): ark355_prove_shard runs the distributed witness map of its
                                   // rank with the exchanges as local copies -- the per-rank cost of a G-GPU proof on one GPU
@@ -99,6 +101,7 @@ inline const TunePolicy::Field* TunePolicy::fields(int* count) {
       ARK_POLICY_FIELD32("SIDE_G2_TAILS", side_g2_tails),
       ARK_POLICY_FIELD32("SIDE_WM", side_wm),
       ARK_POLICY_FIELD32("SIDE_H_TAILS", side_h_tails),
+      ARK_POLICY_FIELD32("SIDE_G1_TAILS", side_g1_tails),
       ARK_POLICY_FIELD32("MSM_C", msm_c),
       ARK_POLICY_FIELD32("MSM_C_H", msm_c_h),
       ARK_POLICY_FIELD32("PACK_ROWS", pack_rows),

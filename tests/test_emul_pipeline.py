@@ -105,14 +105,19 @@ def test_prove_schedules_give_the_same_bytes(emul_lib, emul_ctx, emul_policy, sc
     assert emul_lib.ctx_get_policy(emul_ctx, "SCHED") == {"SERIAL=1": 0, "SERIAL=0": 1, "SCHED=2": 2, "SCHED=3": 3}[sched]
 
 
-@pytest.mark.parametrize("batch", [1, 0])
+@pytest.mark.parametrize("batch", [1, 0, "aside"])
 @pytest.mark.parametrize("circuit", ["mulchain", "dummy", "bench_lc"])
 def test_one_stream_batched_g1_tails(emul_lib, emul_ctx, emul_policy, circuit, batch):
     """One-stream proofs run the merge / heavy merge / reduction / combination of the four G1 MSMs as one launch each
     (msm_reduce_phase_batch; policy BATCH_TAILS = 0 keeps one launch per MSM) and clear their scratch with one fill kernel:
     same bytes as the oracle either way, incl. the all-equal DummyCircuit (heavy buckets: every term of a window in ONE bucket)."""
     emul_policy.setenv("ARK355_SCHED", "0")
-    emul_policy.setenv("ARK355_BATCH_TAILS", str(batch))
+    if batch == "aside":
+        # (round 6) a lone proof's tails of A, B1, L' as a batch of three on the second stream, H's own at the end
+        emul_policy.setenv("ARK355_BATCH_TAILS", "1")
+        emul_policy.setenv("ARK355_SIDE_G1_TAILS", "1")
+    else:
+        emul_policy.setenv("ARK355_BATCH_TAILS", str(batch))
     C = BLS12_381
     if circuit == "mulchain":
         inst = S.mulchain_direct(C.r, 37)

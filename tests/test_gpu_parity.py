@@ -238,7 +238,7 @@ def test_prove_with_window_17_negating_high_scalars(gpu_lib, gpu_ctx, gpu_policy
     pc.prove_case(gpu_lib, gpu_ctx, C, A, B, Cm, z, ell, rs=((C.r - 3, 12345),))
 
 
-@pytest.mark.parametrize("batch,side", [(1, 1), (1, 0), (0, 0)], ids=["batched+side", "batched", "per-msm"])
+@pytest.mark.parametrize("batch,side", [(1, 1), (1, 0), (0, 0), (1, 2)], ids=["batched+side", "batched", "per-msm", "batched+side+g1-aside"])
 @pytest.mark.parametrize("circuit", ["mulchain", "dummy"])
 def test_one_stream_tail_variants(gpu_lib, gpu_ctx, gpu_policy, circuit, batch, side):
     """A one-stream proof: the four G1 tails as one launch per step (policy BATCH_TAILS) and -- the proof being alone on the
@@ -246,7 +246,8 @@ def test_one_stream_tail_variants(gpu_lib, gpu_ctx, gpu_policy, circuit, batch, 
     rounds 1-3; uniform scalars and the all-equal DummyCircuit (heavy buckets).  Proof bytes == oracle every way."""
     gpu_policy.setenv("ARK355_SCHED", "0")
     gpu_policy.setenv("ARK355_BATCH_TAILS", str(batch))
-    gpu_policy.setenv("ARK355_SIDE_G2_TAILS", str(side))
+    gpu_policy.setenv("ARK355_SIDE_G2_TAILS", "1" if side else "0")
+    gpu_policy.setenv("ARK355_SIDE_G1_TAILS", "1" if side == 2 else "0")     # (round 6) A, B1, L' tails aside as a batch of three
     C = BLS12_381
     inst = S.mulchain_direct(C.r, 700) if circuit == "mulchain" else S.cs_to_instance(S.dummy_cs(C.r, 900))
     pc.prove_case(gpu_lib, gpu_ctx, C, *inst, rs=((11, 0xABCDEF),))
