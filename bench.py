@@ -226,12 +226,13 @@ def box_block(gpu_clocks, dt, steps, value, n, telemetry):
     commits, and `*_at_ref_clock` are the headline figures rescaled to REF_GFXCLK_MHZ."""
     out = {"ref_gfxclk_mhz": REF_GFXCLK_MHZ}
     try:
-        (c0, r0), (c1, r1) = gpu_clocks["t0"], gpu_clocks["t1"]
-        if c1 > c0 and r1 > r0:
-            cycles, ticks = c1 - c0, r1 - r0
-            clk = cycles / ticks * 100.0                       # MHz
+        from snark_amd._binding import Lib
+        clk, ms, units = Lib.diag_clocks_delta(gpu_clocks["t0"], gpu_clocks["t1"])
+        if clk:
+            cycles = clk * 1e3 * ms                            # MHz x ms = 10^3 cycles
             out["gfxclk_mhz_mean_on_chip"] = clk
-            out["region_ms_on_chip"] = ticks / 1e5
+            out["compute_units_read"] = units
+            out["region_ms_on_chip"] = ms
             out["gfx_cycles_per_step"] = cycles / steps
             out["gfx_cycles_per_constraint"] = cycles / steps / n
             out["ms_per_step_at_ref_clock"] = cycles / steps / (REF_GFXCLK_MHZ * 1e3)

@@ -114,12 +114,14 @@ int32_t ark355_diag_dispatch(ark355_ctx* ctx, uint32_t launches, uint32_t spin_u
  * NULL) = the duration of the measuring launch.  The sustained gfx clock under the power cap differs from box to box by a few
  * per cent; bench.py prices its integer roofline against this reading and reports box-normalised times with it. */
 int32_t ark355_diag_mad_rate(ark355_ctx* ctx, float target_ms, float* tmad_per_s, float* elapsed_ms);
-/* Diagnostic: the GPU's two free-running counters, read by one lane at the same moment on the context's stream (the call
- * synchronises that stream): out[0] = shader-clock cycles (s_memtime: follows the gfx clock the power management grants),
- * out[1] = ticks of the constant 100 MHz reference (s_memrealtime).  Two calls bracket a region: cycles / work is a time that
- * does not depend on the clock this box sustained, cycles / ticks x 100 MHz the region's mean gfx clock.  Zeros when the build
- * cannot tell (emulator).  bench.py reports `gfx_cycles_per_constraint` with it. */
-int32_t ark355_diag_clocks(ark355_ctx* ctx, uint64_t out[2]);
+/* Diagnostic: the GPU's free-running counters, read by one wave per compute unit at (nearly) the same moment on the context's
+ * stream (the call synchronises that stream): pairs[2 i] = shader-clock cycles (s_memtime: follows the gfx clock the power
+ * management grants), pairs[2 i + 1] = ticks of the constant 100 MHz reference (s_memrealtime), for compute unit slot i < *count
+ * (1024 slots; zeros where no wave landed; capacity = pairs the buffer holds, at least 1024).  The cycle counters of different
+ * compute units differ by arbitrary offsets: two calls bracket a region, and per slot present in both
+ * (cycles delta) / (ticks delta) x 100 MHz is the region's mean gfx clock; bench.py reports the median over the slots and
+ * `gfx_cycles_per_constraint` with it. */
+int32_t ark355_diag_clocks(ark355_ctx* ctx, uint64_t* pairs, uint32_t capacity, uint32_t* count);
 
 /* Page-locked host memory for assignments / key vectors handed to the entry points below: H2D copies from pinned
  * memory run at PCIe rate (~55 GB/s) and truly asynchronously; pageable memory is staged by the runtime at a fraction

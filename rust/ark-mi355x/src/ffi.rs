@@ -118,7 +118,7 @@ extern "C" {
     pub fn ark355_diag_streams(ctxs: *mut *mut ark355_ctx, count: u32, serialised: *mut i8) -> i32;
     pub fn ark355_diag_dispatch(ctx: *mut ark355_ctx, launches: u32, spin_us: u32, gap_us: *mut f32, lanes: *mut u32) -> i32;
     pub fn ark355_diag_mad_rate(ctx: *mut ark355_ctx, target_ms: f32, tmad_per_s: *mut f32, elapsed_ms: *mut f32) -> i32;
-    pub fn ark355_diag_clocks(ctx: *mut ark355_ctx, out: *mut u64) -> i32;
+    pub fn ark355_diag_clocks(ctx: *mut ark355_ctx, pairs: *mut u64, capacity: u32, count: *mut u32) -> i32;
 
     pub fn ark355_host_alloc(bytes: u64, out: *mut *mut c_void) -> i32;
     pub fn ark355_host_free(p: *mut c_void);

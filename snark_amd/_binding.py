@@ -179,7 +179,7 @@ class Lib:
         d.ark355_diag_streams.argtypes = [vp, u32, vp]
         d.ark355_diag_dispatch.argtypes = [vp, u32, u32, P(C.c_float), P(u32)]
         d.ark355_diag_mad_rate.argtypes = [vp, C.c_float, P(C.c_float), P(C.c_float)]
-        d.ark355_diag_clocks.argtypes = [vp, P(u64)]
+        d.ark355_diag_clocks.argtypes = [vp, P(u64), u32, P(u32)]
         d.ark355_get_timings.argtypes = [vp, P(Timings)]
         d.ark355_get_kernel_stats.argtypes = [vp, P(C.c_float), P(u64), P(u64)]
         for name in SYMBOLS:
@@ -239,10 +239,28 @@ class Lib:
         return {"tmad_per_s": float(rate.value), "elapsed_ms": float(ms.value)}
 
     def diag_clocks(self, ctx):
-        """(shader-clock cycles, ticks of the constant 100 MHz reference) read on the GPU at the same moment."""
-        out = (C.c_uint64 * 2)()
-        self.check(ctx, self.dll.ark355_diag_clocks(ctx, out))
-        return int(out[0]), int(out[1])
+        """{slot: (shader-clock cycles, ticks of the constant 100 MHz reference)} read on the GPU, one pair per compute unit."""
+        cap = 1024
+        buf = (C.c_uint64 * (2 * cap))()
+        cnt = C.c_uint32(0)
+        self.check(ctx, self.dll.ark355_diag_clocks(ctx, buf, cap, C.byref(cnt)))
+        return {i: (int(buf[2 * i]), int(buf[2 * i + 1])) for i in range(int(cnt.value)) if buf[2 * i + 1]}
+
+    @staticmethod
+    def diag_clocks_delta(c0, c1):
+        """Two diag_clocks readings -> (median gfx clock in MHz over the compute units present in both, elapsed ms, units used)."""
+        ratios, ticks = [], []
+        for k, (a0, r0) in c0.items():
+            if k in c1:
+                a1, r1 = c1[k]
+                if a1 > a0 and r1 > r0:
+                    ratios.append((a1 - a0) / (r1 - r0) * 100.0)
+                    ticks.append(r1 - r0)
+        if not ratios:
+            return None, None, 0
+        ratios.sort()
+        ticks.sort()
+        return ratios[len(ratios) // 2], ticks[len(ticks) // 2] / 1e5, len(ratios)
 
     def sched_reset(self, ctx):
         self.check(ctx, self.dll.ark355_sched_reset(ctx))

@@ -253,9 +253,12 @@ int32_t ark355_diag_mad_rate(ark355_ctx* ctx, float target_ms, float* tmad_per_s
   if (!ctx || !tmad_per_s || !(target_ms >= 0.1f) || target_ms > 1000.f) return ARK355_EINVAL;
   return guarded(ctx, [&] { *tmad_per_s = diag_mad_rate_t(ctx->stream, ctx->device, target_ms, elapsed_ms); });
 }
-int32_t ark355_diag_clocks(ark355_ctx* ctx, uint64_t out[2]) {
-  if (!ctx || !out) return ARK355_EINVAL;
-  return guarded(ctx, [&] { diag_clocks(ctx->stream, out); });
+int32_t ark355_diag_clocks(ark355_ctx* ctx, uint64_t* pairs, uint32_t capacity, uint32_t* count) {
+  if (!ctx || !pairs || !count || capacity < DIAG_CLOCK_SLOTS) return ARK355_EINVAL;
+  return guarded(ctx, [&] {
+    diag_clocks(ctx->stream, pairs);
+    *count = DIAG_CLOCK_SLOTS;
+  });
 }
 int32_t ark355_sched_reset(const ark355_ctx* ctx) {
   if (!ctx) return ARK355_EINVAL;

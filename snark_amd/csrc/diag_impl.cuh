@@ -169,35 +169,37 @@ static inline float diag_mad_rate_t(hipStream_t st, int device, float target_ms,
 // bracket a region: (shader cycles elapsed) / (work done) is a time in units that do not depend on which clock THIS box sustained
 // under its power cap, and (shader cycles) / (reference ticks) x 100 MHz is the mean gfx clock of the region, measured on the
 // chip itself rather than sampled over SMI.  out[0] = shader cycles, out[1] = 100 MHz ticks; zeros on builds that cannot tell.
-// Every XCD keeps its OWN shader-cycle counter (they differ by arbitrary offsets: two readings taken on different XCDs are
-// not comparable -- the first version launched one workgroup, which lands on whichever XCD is next, and read mean clocks between
-// 1.5 and 2.2 GHz for the same library), so the probe covers all of them (64 workgroups, dealt round-robin over the XCDs) and
-// reports the pair read on XCC 0 (HW_REG_XCC_ID), every time.
+// The shader-cycle counter is NOT one counter: readings taken on different XCDs (and, as run G showed, not only XCDs) differ by
+// arbitrary offsets, so two readings are comparable only when they come from the same place.  The probe therefore covers the
+// chip (2 048 one-wave workgroups) and records one (cycles, ticks) pair PER COMPUTE UNIT, keyed by (XCC_ID, HW_ID.se / sh / cu);
+// a caller brackets a region with two probes and takes, per compute unit present in both, the ratio of the two deltas -- the
+// median over the compute units is the region's mean gfx clock (diag_clocks_delta).
+constexpr uint32_t DIAG_CLOCK_SLOTS = 8 * 128;       // 8 XCCs x (se, sh, cu) of HW_REG_HW_ID packed into 7 bits
 #if !defined(ARK_EMUL)
 static __global__ void diag_clocks_kernel(uint64_t* out) {
   if (threadIdx.x == 0) {
-    const uint32_t xcc = __builtin_amdgcn_s_getreg((3u << 11) | 20u) & 15u;       // HW_REG_XCC_ID (20), bits [3:0]
+    const uint32_t xcc = __builtin_amdgcn_s_getreg((3u << 11) | 20u) & 7u;        // HW_REG_XCC_ID (20), bits [3:0]
+    const uint32_t hw = __builtin_amdgcn_s_getreg((15u << 11) | (0u << 6) | 4u);   // HW_REG_HW_ID (4), bits [15:0]: cu_id [11:8], sh_id [12], se_id [15:13]
+    const uint32_t slot = xcc * 128u + ((hw >> 8) & 127u);
     const uint64_t a = __builtin_readcyclecounter();        // s_memtime
     const uint64_t b = wall_clock64();                      // s_memrealtime
-    out[2 * xcc] = a;
-    out[2 * xcc + 1] = b;
+    out[2 * slot] = a;
+    out[2 * slot + 1] = b;
   }
 }
 #endif
-static inline void diag_clocks(hipStream_t st, uint64_t out[2]) {
-  out[0] = out[1] = 0;
+// out: DIAG_CLOCK_SLOTS pairs (zeros where no workgroup landed)
+static inline void diag_clocks(hipStream_t st, uint64_t* out) {
+  memset(out, 0, (size_t)DIAG_CLOCK_SLOTS * 16);
 #if defined(ARK_EMUL)
   (void)st;
 #else
-  DevBuf d(32 * 8);
-  ARK_CHECK_HIP(hipMemsetAsync(d.p, 0, 32 * 8, st));
-  ARK_LAUNCH(diag_clocks_kernel, dim3(64), dim3(64), 0, st, d.as<uint64_t>());
+  DevBuf d((size_t)DIAG_CLOCK_SLOTS * 16);
+  ARK_CHECK_HIP(hipMemsetAsync(d.p, 0, (size_t)DIAG_CLOCK_SLOTS * 16, st));
+  ARK_LAUNCH(diag_clocks_kernel, dim3(2048), dim3(64), 0, st, d.as<uint64_t>());
   ARK_CHECK_LAUNCH();
-  uint64_t h[32];
-  ARK_CHECK_HIP(hipMemcpyAsync(h, d.p, sizeof(h), hipMemcpyDeviceToHost, st));
+  ARK_CHECK_HIP(hipMemcpyAsync(out, d.p, (size_t)DIAG_CLOCK_SLOTS * 16, hipMemcpyDeviceToHost, st));
   ARK_CHECK_HIP(hipStreamSynchronize(st));
-  out[0] = h[0];
-  out[1] = h[1];
 #endif
 }
 

@@ -289,9 +289,9 @@ def test_box_diagnostics(gpu_lib, gpu_ctx):
     r = gpu_lib.diag_mad_rate(gpu_ctx, 5.0)
     assert 10.0 < r["tmad_per_s"] < 60.0 and 1.0 < r["elapsed_ms"] < 50.0, r
     c0 = gpu_lib.diag_clocks(gpu_ctx)
-    gpu_lib.diag_mad_rate(gpu_ctx, 5.0)
-    time.sleep(0.01)
+    gpu_lib.diag_mad_rate(gpu_ctx, 20.0)
     c1 = gpu_lib.diag_clocks(gpu_ctx)
-    assert c1[0] > c0[0] and c1[1] > c0[1], (c0, c1)
-    ms = (c1[1] - c0[1]) / 1e5
-    assert 10.0 < ms < 2000.0, ms                     # the 100 MHz reference: about the 15+ ms that passed
+    clk, ms, units = gpu_lib.diag_clocks_delta(c0, c1)
+    assert units >= 64, units                         # most of the 256 compute units answered both probes
+    assert 15.0 < ms < 500.0, ms                      # the 100 MHz reference: the ~20 ms loop plus two probes
+    assert 1000.0 < clk < 2600.0, clk                 # a busy chip runs between 1 and 2.5 GHz
