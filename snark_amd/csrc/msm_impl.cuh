@@ -135,13 +135,16 @@ inline MsmPlan msm_plan(uint64_t n, uint32_t scalar_bits, bool precomp = false, 
     if (found) break;
   }
   if (precomp && !force_c) {
-    // Resident window tables of 2^20 terms and more over 255-bit scalars (BLS12-381): c = 17 with the scalars above (r - 1) / 2
-    // negated (negate_high below) is 15 windows instead of 16 -- 6 % fewer additions, 1/16 less table memory, 2^16 buckets.
-    // Round 3 measured +1 % (the tails of twice the buckets ate the rest); with the batched tails of round 4 the same A/B reads
-    // 23.77 -> 23.27 ms per proof in flight and 28.6 -> 27.7 ms for a single proof, accumulation 20.9 -> 19.8 ms
-    // (profiles/r04_c17_ab.txt).  Smaller vectors keep 16 (fewer than 256 terms per bucket: flush divergence), BN254 keeps 16
-    // (254 bits: measured -0.8 % in round 3).
-    if (c == 16 && scalar_bits == 255 && n >= (1ull << 20)) c = 17;
+    // Resident window tables of 2^18 terms and more: c = 17.  Over 255-bit scalars (BLS12-381) with the scalars above (r - 1) / 2
+    // negated (negate_high below) that is 15 windows instead of 16 -- 6 % fewer additions, 1/16 less table memory, 2^16 buckets;
+    // over 254-bit scalars (BN254) 15 windows of 17 bits hold the value and its carry bit as they are.
+    // History: round 3 measured +1 % at 2^20 (the tails of twice the buckets ate the rest); with the batched tails of round 4
+    // 23.77 -> 23.27 ms per proof in flight (profiles/r04_c17_ab.txt) and c = 17 became the choice from 2^20 terms on, BLS12-381
+    // only (smaller vectors: "fewer than 256 terms per bucket: flush divergence"; BN254: -0.8 % in round 3).  Round 6 made the
+    // flush 14 stores and the tails plain sums, and run I (profiles/r06_runI_c17_small_bn254.txt, same box, interleaved) reads:
+    // BN254 2^20 13.61 -> 13.04-13.13 ms per proof (-3.8 %), BLS12-381 2^19 10.77 -> 10.48 ms, 2^18 x 8 in flight 5.67-5.74 ->
+    // 5.59-5.61 ms, the 2^19-term shards of a rank of the sharded 2^22 proof 13.5-13.6 -> 12.9-13.6 ms.
+    if (c == 16 && (scalar_bits == 255 || scalar_bits == 254) && n >= (1ull << 18)) c = 17;
     // tuning knob for resident keys (window tables): policy MSM_C=<bits>, applied when the key is loaded
     if (pref_c >= 4 && pref_c <= 24 && n >= 1024) c = pref_c;
   }
