@@ -145,6 +145,12 @@ inline MsmPlan msm_plan(uint64_t n, uint32_t scalar_bits, bool precomp = false, 
     // BN254 2^20 13.61 -> 13.04-13.13 ms per proof (-3.8 %), BLS12-381 2^19 10.77 -> 10.48 ms, 2^18 x 8 in flight 5.67-5.74 ->
     // 5.59-5.61 ms, the 2^19-term shards of a rank of the sharded 2^22 proof 13.5-13.6 -> 12.9-13.6 ms.
     if (c == 16 && (scalar_bits == 255 || scalar_bits == 254) && n >= (1ull << 18)) c = 17;
+    // ... and c = 20 from 2^22 terms on: 13 windows instead of 15 (-13 % additions, tables 13/15 the size) against the fixed cost of
+    // 2^19 buckets per MSM (fills, sorts over 8x the keys, two general additions per bucket in the row / column sums: ~1 ms per MSM,
+    // whatever its length).  Run B: at 2^20 constraints it loses (23.1 against 22.4 ms per proof; the H MSM alone, 2^21 terms: 22.8);
+    // run K, 2^22 constraints on one GPU, same box, interleaved: 81.4 -> 76.7 ms per proof (-5.8 %, 54.7 M constraints/s), c = 19:
+    // 79.3 (profiles/r06_runK_large_key_windows.txt).
+    if (c == 17 && n >= (1ull << 22)) c = 20;
     // tuning knob for resident keys (window tables): policy MSM_C=<bits>, applied when the key is loaded
     if (pref_c >= 4 && pref_c <= 24 && n >= 1024) c = pref_c;
   }
