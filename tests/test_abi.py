@@ -84,3 +84,28 @@ def test_host_only_entry_points_reject_bad_arguments(built_lib):
     ib = (C.c_uint8 * 192)(*inf)
     assert lib.dll.ark355_proof_from_bytes(snark_amd.BLS12_381, ib, 192, 1, 1, out) == 0
     assert bytes(raw.a) == bytes(96) and bytes(raw.b) == bytes(192) and bytes(raw.c) == bytes(96)
+
+
+def test_kernel_statistics_are_read_from_the_built_library(built_lib):
+    """tools/code_object_stats.py on the library just built (what snark_amd/build.py writes next to it and bench.py prices its
+    integer roofline with): the accumulation kernels of both curves are found in the code objects, their hot paths hold the
+    multiply-adds of one mixed addition (thousands, G2 per lane more than G1), the G1 loops make no scratch access and the
+    BLS12-381 lane-pair loop -- whose accumulator lives in LDS since round 6 -- only a handful."""
+    import json
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    try:
+        import code_object_stats as cos
+        st = cos.library_stats(built_lib)
+    finally:
+        sys.path.remove(os.path.join(ROOT, "tools"))
+    for key in ("bls12_381.g1", "bls12_381.g2", "bn254.g1", "bn254.g2"):
+        assert key in st, (key, sorted(st))
+    g1, g2 = st["bls12_381.g1"]["hot_block"], st["bls12_381.g2"]["hot_block"]
+    assert 2500 < g1["multiply_adds"] < 4000 and g1["multiply_adds"] < g2["multiply_adds"] < 6000
+    assert st["bn254.g1"]["hot_block"]["multiply_adds"] < g1["multiply_adds"]
+    assert max(b["scratch_loads"] for b in (g1, st["bn254.g1"]["hot_block"])) == 0
+    assert g2["lds"] >= 48 and g2["scratch_loads"] + g2["scratch_stores"] < 40, g2
+    side = os.path.splitext(built_lib)[0] + ".stats.json"
+    if os.path.exists(side):
+        assert json.load(open(side))["bls12_381.g1"]["hot_block"]["multiply_adds"] == g1["multiply_adds"]
