@@ -210,6 +210,83 @@ ARK_HD_NOINLINE typename Fp28<P>::Vec one28_ni() {
   return Fp28<P>::from_fp(Fp<P>::one()).to_vec();
 }
 
+// Where zz / zzz of the pair's accumulator live between their uses.  ZzRegs: in the accumulator's own registers.  ZzLds
+// (round 6): in LDS.  The lane-pair addition over BLS12-381 does not fit 256 registers -- the code object of the first
+// round-6 library shows the allocator writing three 14-limb values (new zz, new zzz and one more) to scratch memory while
+// the fused Y3 pass runs and fetching them back at the end of every addition: 53 scratch loads + 41 stores per iteration
+// (tools/code_object_stats.py), and the kernel 11 % slower than round 5's (7.17 against 6.47 ms per 2^20-term launch), whose
+// spills happened to sit in the flush path.  zz and zzz are each read twice and written once per addition, so they are the
+// cheapest state to keep elsewhere, and so are x and y (the new x is dead during the fused Y3 pass, where the pressure peaks;
+// with all four there the listing shows 5 scratch loads + 4 stores per addition): 4 x 4 b128 slots per lane (256 B; 64 KiB for
+// 256 lanes, two workgroups per CU), every lane on its own consecutive 16-byte column, i.e. conflict-free: 32 ds_read_b128 +
+// 16 ds_write_b128 per addition of ~7 600 instructions.
+template <class P>
+struct ZzRegs {
+  Acc28<P>& a;
+  ARK_D Fp28<P> zz() const { return a.zz; }
+  ARK_D Fp28<P> zzz() const { return a.zzz; }
+  ARK_D Fp28<P> x() const { return a.x; }
+  ARK_D Fp28<P> y() const { return a.y; }
+  ARK_D void set_y(const Fp28<P>& v) const { a.y = v; }
+  ARK_D void set_zz(const Fp28<P>& v) const { a.zz = v; }
+  ARK_D void set_zzz(const Fp28<P>& v) const { a.zzz = v; }
+  ARK_D void set_x(const Fp28<P>& v) const { a.x = v; }
+};
+#ifndef ARK_G2L28_LDS_VALUES
+#define ARK_G2L28_LDS_VALUES 4      // how many of zz, zzz, x, y (in that order) live in LDS: 0 (none: rounds 2-5), 2, 3, 4
+#endif
+template <class P, int NV = ARK_G2L28_LDS_VALUES>
+struct ZzLds {
+  using F = Fp28<P>;
+  static constexpr int N = F::N, QN = (N + 3) / 4;
+  static constexpr int VALUES = NV < 2 ? 2 : NV;
+  Acc28<P>& a;        // the coordinates that stay in registers
+  uint4* mine;        // quad q of value s (0: zz, 1: zzz, 2: x, 3: y) sits at mine[(s * QN + q) * stride]
+  uint32_t stride;    // lanes of the workgroup
+  static size_t bytes(uint32_t threads) { return (size_t)VALUES * QN * threads * sizeof(uint4); }
+  // (the barrier keeps the compiler from serving a later read out of registers it loaded earlier: the point of the exercise
+  // is that the value is NOT live in between)
+  ARK_D F get(int s) const {
+    asm volatile("" ::: "memory");
+    F r;
+#pragma unroll
+    for (int q = 0; q < QN; q++) {
+      const uint4 t = mine[(size_t)(s * QN + q) * stride];
+      r.l[4 * q] = t.x;
+      if (4 * q + 1 < N) r.l[4 * q + 1] = t.y;
+      if (4 * q + 2 < N) r.l[4 * q + 2] = t.z;
+      if (4 * q + 3 < N) r.l[4 * q + 3] = t.w;
+    }
+    return r;
+  }
+  ARK_D void put(int s, const F& v) const {
+#pragma unroll
+    for (int q = 0; q < QN; q++)
+      mine[(size_t)(s * QN + q) * stride] = make_uint4(v.l[4 * q], 4 * q + 1 < N ? v.l[4 * q + 1] : 0u, 4 * q + 2 < N ? v.l[4 * q + 2] : 0u,
+                                                         4 * q + 3 < N ? v.l[4 * q + 3] : 0u);
+  }
+  ARK_D F zz() const { return get(0); }
+  ARK_D F zzz() const { return get(1); }
+  ARK_D void set_zz(const F& v) const { put(0, v); }
+  ARK_D void set_zzz(const F& v) const { put(1, v); }
+  ARK_D F x() const {
+    if constexpr (VALUES > 2) return get(2);
+    else return a.x;
+  }
+  ARK_D void set_x(const F& v) const {
+    if constexpr (VALUES > 2) put(2, v);
+    else a.x = v;
+  }
+  ARK_D F y() const {
+    if constexpr (VALUES > 3) return get(3);
+    else return a.y;
+  }
+  ARK_D void set_y(const F& v) const {
+    if constexpr (VALUES > 3) put(3, v);
+    else a.y = v;
+  }
+};
+
 // acc += (px, +-py).  Value/limb classes (field28.cuh): table coordinates are canonical; acc.x is normalised and
 // < 6.1 p; acc.y, acc.zz, acc.zzz are products (< 1.05 p, normalised) -- or, right after a bucket was opened with a
 // negated point, acc.y = norm(2p - py) < 2p.
@@ -219,8 +296,8 @@ ARK_HD_NOINLINE typename Fp28<P>::Vec one28_ni() {
 //   X3 = norm(R^2 + 5p - (PPP + 2Q))             (< 6.1 p)
 //   Y3 = R (Q + 8p - X3) + (3p - Y1) PPP         (one fused pass; operand limbs < 2^29.6 each)
 // Largest column: 14 * 2^59.2 + 14 * 2^57.6 + 14 * 2^56 < 2^63.5.
-template <class P>
-ARK_D void madd28(Acc28<P>& acc, bool& empty, const Fp28<P>& px, const Fp28<P>& py, bool negate) {
+template <class P, class Z>
+ARK_D void madd28z(Acc28<P>& acc, const Z& z, bool& empty, const Fp28<P>& px, const Fp28<P>& py, bool negate) {
   using F = Fp28<P>;
   F pys;
   {
@@ -230,26 +307,27 @@ ARK_D void madd28(Acc28<P>& acc, bool& empty, const Fp28<P>& px, const Fp28<P>& 
   }
   if (empty) {
     const F one = F::from_vec(one28_ni<P>());
-    acc.x = px;
-    acc.y = F::norm(pys);
-    acc.zz = one;
-    acc.zzz = one;
+    z.set_x(px);
+    z.set_y(F::norm(pys));
+    z.set_zz(one);
+    z.set_zzz(one);
     empty = false;
     return;
   }
-  const F U2 = F::mul(px, acc.zz);
-  const F S2 = F::mul(pys, acc.zzz);
-  const F Pd = F::template sub<8, 1>(U2, acc.x);
-  const F R = F::template sub<3, 1>(S2, acc.y);
+  const F U2 = F::mul(px, z.zz());
+  const F S2 = F::mul(pys, z.zzz());
+  const F Pd = F::template sub<8, 1>(U2, z.x());
+  const F R = F::template sub<3, 1>(S2, z.y());
   if (Pd.multiple_hint() < 10u) {
     const int cls = madd28_classify<P>(Pd, R);
     if (cls == 1) {
       const F yn = F::norm(pys);
-      acc.x = F::from_vec(dbl28_coord_ni<P>(px, yn, 0));
-      acc.y = F::from_vec(dbl28_coord_ni<P>(px, yn, 1));
-      acc.zz = F::from_vec(dbl28_coord_ni<P>(px, yn, 2));
-      acc.zzz = F::from_vec(dbl28_coord_ni<P>(px, yn, 3));
-      if (acc.zz.limbs_all_zero()) empty = true;       // 2P = infinity (no such point on these curves)
+      z.set_x(F::from_vec(dbl28_coord_ni<P>(px, yn, 0)));
+      z.set_y(F::from_vec(dbl28_coord_ni<P>(px, yn, 1)));
+      const F nzz = F::from_vec(dbl28_coord_ni<P>(px, yn, 2));
+      z.set_zz(nzz);
+      z.set_zzz(F::from_vec(dbl28_coord_ni<P>(px, yn, 3)));
+      if (nzz.limbs_all_zero()) empty = true;       // 2P = infinity (no such point on these curves)
       return;
     }
     if (cls == 2) {
@@ -259,15 +337,110 @@ ARK_D void madd28(Acc28<P>& acc, bool& empty, const Fp28<P>& px, const Fp28<P>& 
   }
   const F PP = F::sqr(Pd);
   const F PPP = F::mul(Pd, PP);
-  const F Q = F::mul(acc.x, PP);
-  acc.zz = F::mul(acc.zz, PP);
-  acc.zzz = F::mul(acc.zzz, PPP);
+  const F Q = F::mul(z.x(), PP);
+  z.set_zz(F::mul(z.zz(), PP));
+  z.set_zzz(F::mul(z.zzz(), PPP));
   const F W = F::add(PPP, F::add(Q, Q));
   const F X3 = F::norm(F::add(F::sqr(R), F::template neg<5, 4>(W)));
   const F T = F::template sub<8, 1>(Q, X3);
-  const F NY = F::template neg<3, 1>(acc.y);
-  acc.y = F::mul2sum(R, T, NY, PPP);
-  acc.x = X3;
+  const F NY = F::template neg<3, 1>(z.y());
+  z.set_x(X3);
+  z.set_y(F::mul2sum(R, T, NY, PPP));
+}
+template <class P>
+ARK_D void madd28(Acc28<P>& acc, bool& empty, const Fp28<P>& px, const Fp28<P>& py, bool negate) {
+  const ZzRegs<P> z{acc};
+  madd28z<P, ZzRegs<P>>(acc, z, empty, px, py, negate);
+}
+
+// EXPERIMENT (round 6, run O): the G1 walk at THREE waves per SIMD.  11.3 found a launch to be a relay of two waves at 1.2x the
+// pace of one -- 91 % of what the instruction mix can issue; a third wave could take the slots the two leave.  168 registers
+// per lane at that occupancy: x, zz, zzz of the accumulator live in LDS (ZzLds, 192 B per lane: 144 KiB per CU at 768 lanes),
+// the row is gathered at the top of its own iteration from an index that arrived one iteration earlier (no 32-register
+// prefetch).  Built only with -DARK_G1_W3=1.
+#ifndef ARK_G1_W3
+#define ARK_G1_W3 0
+#endif
+#ifndef ARK_G1_W3_VALUES
+#define ARK_G1_W3_VALUES 3
+#endif
+template <class P>
+__global__ void __launch_bounds__(MSM_THREADS, 3)
+msm_accumulate28w3_kernel(const Affine28U<P>* __restrict__ bases, const uint32_t* __restrict__ sorted_keys,
+                          const uint32_t* __restrict__ sorted_vals, const uint32_t* __restrict__ total_ptr,
+                          const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ counts,
+                          Msm28Slot<P, 4>* __restrict__ buckets, Msm28Slot<P, 4>* __restrict__ head,
+                          uint32_t* __restrict__ head_key, Msm28Slot<P, 4>* __restrict__ tail,
+                          uint32_t* __restrict__ tail_key, uint32_t seg_len) {
+  using F = Fp28<P>;
+  using Row = Affine28U<P>;
+  using Zt = ZzLds<P, ARK_G1_W3_VALUES>;
+  constexpr int Q = Row::Q;
+  const uint32_t seg = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t total = *total_ptr;
+  const uint64_t start64 = (uint64_t)seg * seg_len;
+  if (start64 >= total) return;
+  const uint32_t start = (uint32_t)start64;
+  const uint32_t end = (start + seg_len < total) ? start + seg_len : total;
+  uint32_t cur_key = sorted_keys[start];
+  uint32_t run_start = start;
+  bool first_run = true;
+  bool empty = true;
+  Acc28<P> acc;
+  acc.x = F::zero();
+  acc.y = F::zero();
+  acc.zz = F::zero();
+  acc.zzz = F::zero();
+  ARK_DYN_SMEM(uint4, zlds);
+  const Zt z{acc, zlds + threadIdx.x, blockDim.x};
+  auto flush = [&](uint32_t key, uint32_t run_end) __attribute__((always_inline)) {
+    if (!empty) {
+      acc.x = z.x();
+      acc.y = z.y();
+      acc.zz = z.zz();
+      acc.zzz = z.zzz();
+    }
+    msm_flush_slot28<P>(buckets, head, tail, head_key, tail_key, true, key, acc, empty, first_run, run_start, run_end, seg, offsets,
+                        counts, sizeof(Slot28<P>));
+  };
+  uint32_t v_next = sorted_vals[start];
+  for (uint32_t e = start; e < end; e++) {
+    const uint32_t key = sorted_keys[e];
+    const uint32_t v = v_next;
+    F px, py;
+    {
+      const uint4* src = reinterpret_cast<const uint4*>(bases + (v & ARK_TBL_MASK));
+      uint32_t d[4 * Q];
+#pragma unroll
+      for (int k = 0; k < Q; k++) {
+        const uint4 t = src[k];
+        d[4 * k + 0] = t.x;
+        d[4 * k + 1] = t.y;
+        d[4 * k + 2] = t.z;
+        d[4 * k + 3] = t.w;
+      }
+#pragma unroll
+      for (int k = 0; k < F::N; k++) {
+        px.l[k] = d[k];
+        py.l[k] = d[F::N + k];
+      }
+    }
+    const uint32_t en = (e + 1 < end) ? e + 1 : e;
+    v_next = sorted_vals[en];
+    if (key != cur_key) {
+      flush(cur_key, e);
+      cur_key = key;
+      run_start = e;
+      first_run = false;
+      empty = true;
+    }
+    uint32_t any = 0;
+#pragma unroll
+    for (int k = 0; k < F::N; k++) any |= px.l[k] | py.l[k];
+    if (any == 0) continue;                              // base at infinity
+    madd28z<P, Zt>(acc, z, empty, px, py, (v >> 31) != 0);
+  }
+  flush(cur_key, end);
 }
 
 // Same contract as msm_accumulate_kernel<Fp<P>, false>; `bases` holds UNPACKED rows (Affine28U): the plain segment walk of
@@ -648,83 +821,6 @@ ARK_HD_NOINLINE typename Fp28<P>::Vec dbl28_g2_coord_ni(Fp28<P> x, Fp28<P> y, in
 // The addition comes in two halves so that the accumulation loop can issue the gather of the NEXT table row between
 // them: after the first half px / py are dead, and the row's latency hides under the eight products of the second.
 // madd28_g2_head returns false when the entry is already dealt with (bucket opened, doubling, cancellation).
-// Where zz / zzz of the pair's accumulator live between their uses.  ZzRegs: in the accumulator's own registers.  ZzLds
-// (round 6): in LDS.  The lane-pair addition over BLS12-381 does not fit 256 registers -- the code object of the first
-// round-6 library shows the allocator writing three 14-limb values (new zz, new zzz and one more) to scratch memory while
-// the fused Y3 pass runs and fetching them back at the end of every addition: 53 scratch loads + 41 stores per iteration
-// (tools/code_object_stats.py), and the kernel 11 % slower than round 5's (7.17 against 6.47 ms per 2^20-term launch), whose
-// spills happened to sit in the flush path.  zz and zzz are each read twice and written once per addition, so they are the
-// cheapest state to keep elsewhere, and so are x and y (the new x is dead during the fused Y3 pass, where the pressure peaks;
-// with all four there the listing shows 5 scratch loads + 4 stores per addition): 4 x 4 b128 slots per lane (256 B; 64 KiB for
-// 256 lanes, two workgroups per CU), every lane on its own consecutive 16-byte column, i.e. conflict-free: 32 ds_read_b128 +
-// 16 ds_write_b128 per addition of ~7 600 instructions.
-template <class P>
-struct ZzRegs {
-  Acc28<P>& a;
-  ARK_D Fp28<P> zz() const { return a.zz; }
-  ARK_D Fp28<P> zzz() const { return a.zzz; }
-  ARK_D Fp28<P> x() const { return a.x; }
-  ARK_D Fp28<P> y() const { return a.y; }
-  ARK_D void set_y(const Fp28<P>& v) const { a.y = v; }
-  ARK_D void set_zz(const Fp28<P>& v) const { a.zz = v; }
-  ARK_D void set_zzz(const Fp28<P>& v) const { a.zzz = v; }
-  ARK_D void set_x(const Fp28<P>& v) const { a.x = v; }
-};
-#ifndef ARK_G2L28_LDS_VALUES
-#define ARK_G2L28_LDS_VALUES 4      // how many of zz, zzz, x, y (in that order) live in LDS: 0 (none: rounds 2-5), 2, 3, 4
-#endif
-template <class P>
-struct ZzLds {
-  using F = Fp28<P>;
-  static constexpr int N = F::N, QN = (N + 3) / 4;
-  static constexpr int VALUES = ARK_G2L28_LDS_VALUES < 2 ? 2 : ARK_G2L28_LDS_VALUES;
-  Acc28<P>& a;        // the coordinates that stay in registers
-  uint4* mine;        // quad q of value s (0: zz, 1: zzz, 2: x, 3: y) sits at mine[(s * QN + q) * stride]
-  uint32_t stride;    // lanes of the workgroup
-  static size_t bytes(uint32_t threads) { return (size_t)VALUES * QN * threads * sizeof(uint4); }
-  // (the barrier keeps the compiler from serving a later read out of registers it loaded earlier: the point of the exercise
-  // is that the value is NOT live in between)
-  ARK_D F get(int s) const {
-    asm volatile("" ::: "memory");
-    F r;
-#pragma unroll
-    for (int q = 0; q < QN; q++) {
-      const uint4 t = mine[(size_t)(s * QN + q) * stride];
-      r.l[4 * q] = t.x;
-      if (4 * q + 1 < N) r.l[4 * q + 1] = t.y;
-      if (4 * q + 2 < N) r.l[4 * q + 2] = t.z;
-      if (4 * q + 3 < N) r.l[4 * q + 3] = t.w;
-    }
-    return r;
-  }
-  ARK_D void put(int s, const F& v) const {
-#pragma unroll
-    for (int q = 0; q < QN; q++)
-      mine[(size_t)(s * QN + q) * stride] = make_uint4(v.l[4 * q], 4 * q + 1 < N ? v.l[4 * q + 1] : 0u, 4 * q + 2 < N ? v.l[4 * q + 2] : 0u,
-                                                         4 * q + 3 < N ? v.l[4 * q + 3] : 0u);
-  }
-  ARK_D F zz() const { return get(0); }
-  ARK_D F zzz() const { return get(1); }
-  ARK_D void set_zz(const F& v) const { put(0, v); }
-  ARK_D void set_zzz(const F& v) const { put(1, v); }
-  ARK_D F x() const {
-    if constexpr (VALUES > 2) return get(2);
-    else return a.x;
-  }
-  ARK_D void set_x(const F& v) const {
-    if constexpr (VALUES > 2) put(2, v);
-    else a.x = v;
-  }
-  ARK_D F y() const {
-    if constexpr (VALUES > 3) return get(3);
-    else return a.y;
-  }
-  ARK_D void set_y(const F& v) const {
-    if constexpr (VALUES > 3) put(3, v);
-    else a.y = v;
-  }
-};
-
 template <class P, class Z>
 ARK_D bool madd28_g2_head(Acc28<P>& acc, const Z& z, bool& empty, const Fp28<P>& px, const Fp28<P>& py, bool negate,
                           Fp28<P>& Pd, Fp28<P>& R) {
