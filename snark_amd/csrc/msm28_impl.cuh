@@ -353,96 +353,9 @@ ARK_D void madd28(Acc28<P>& acc, bool& empty, const Fp28<P>& px, const Fp28<P>& 
   madd28z<P, ZzRegs<P>>(acc, z, empty, px, py, negate);
 }
 
-// EXPERIMENT (round 6, run O): the G1 walk at THREE waves per SIMD.  11.3 found a launch to be a relay of two waves at 1.2x the
-// pace of one -- 91 % of what the instruction mix can issue; a third wave could take the slots the two leave.  168 registers
-// per lane at that occupancy: x, zz, zzz of the accumulator live in LDS (ZzLds, 192 B per lane: 144 KiB per CU at 768 lanes),
-// the row is gathered at the top of its own iteration from an index that arrived one iteration earlier (no 32-register
-// prefetch).  Built only with -DARK_G1_W3=1.
-#ifndef ARK_G1_W3
-#define ARK_G1_W3 0
-#endif
-#ifndef ARK_G1_W3_VALUES
-#define ARK_G1_W3_VALUES 3
-#endif
-template <class P>
-__global__ void __launch_bounds__(MSM_THREADS, 3)
-msm_accumulate28w3_kernel(const Affine28U<P>* __restrict__ bases, const uint32_t* __restrict__ sorted_keys,
-                          const uint32_t* __restrict__ sorted_vals, const uint32_t* __restrict__ total_ptr,
-                          const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ counts,
-                          Msm28Slot<P, 4>* __restrict__ buckets, Msm28Slot<P, 4>* __restrict__ head,
-                          uint32_t* __restrict__ head_key, Msm28Slot<P, 4>* __restrict__ tail,
-                          uint32_t* __restrict__ tail_key, uint32_t seg_len) {
-  using F = Fp28<P>;
-  using Row = Affine28U<P>;
-  using Zt = ZzLds<P, ARK_G1_W3_VALUES>;
-  constexpr int Q = Row::Q;
-  const uint32_t seg = blockIdx.x * blockDim.x + threadIdx.x;
-  const uint32_t total = *total_ptr;
-  const uint64_t start64 = (uint64_t)seg * seg_len;
-  if (start64 >= total) return;
-  const uint32_t start = (uint32_t)start64;
-  const uint32_t end = (start + seg_len < total) ? start + seg_len : total;
-  uint32_t cur_key = sorted_keys[start];
-  uint32_t run_start = start;
-  bool first_run = true;
-  bool empty = true;
-  Acc28<P> acc;
-  acc.x = F::zero();
-  acc.y = F::zero();
-  acc.zz = F::zero();
-  acc.zzz = F::zero();
-  ARK_DYN_SMEM(uint4, zlds);
-  const Zt z{acc, zlds + threadIdx.x, blockDim.x};
-  auto flush = [&](uint32_t key, uint32_t run_end) __attribute__((always_inline)) {
-    if (!empty) {
-      acc.x = z.x();
-      acc.y = z.y();
-      acc.zz = z.zz();
-      acc.zzz = z.zzz();
-    }
-    msm_flush_slot28<P>(buckets, head, tail, head_key, tail_key, true, key, acc, empty, first_run, run_start, run_end, seg, offsets,
-                        counts, sizeof(Slot28<P>));
-  };
-  uint32_t v_next = sorted_vals[start];
-  for (uint32_t e = start; e < end; e++) {
-    const uint32_t key = sorted_keys[e];
-    const uint32_t v = v_next;
-    F px, py;
-    {
-      const uint4* src = reinterpret_cast<const uint4*>(bases + (v & ARK_TBL_MASK));
-      uint32_t d[4 * Q];
-#pragma unroll
-      for (int k = 0; k < Q; k++) {
-        const uint4 t = src[k];
-        d[4 * k + 0] = t.x;
-        d[4 * k + 1] = t.y;
-        d[4 * k + 2] = t.z;
-        d[4 * k + 3] = t.w;
-      }
-#pragma unroll
-      for (int k = 0; k < F::N; k++) {
-        px.l[k] = d[k];
-        py.l[k] = d[F::N + k];
-      }
-    }
-    const uint32_t en = (e + 1 < end) ? e + 1 : e;
-    v_next = sorted_vals[en];
-    if (key != cur_key) {
-      flush(cur_key, e);
-      cur_key = key;
-      run_start = e;
-      first_run = false;
-      empty = true;
-    }
-    uint32_t any = 0;
-#pragma unroll
-    for (int k = 0; k < F::N; k++) any |= px.l[k] | py.l[k];
-    if (any == 0) continue;                              // base at infinity
-    madd28z<P, Zt>(acc, z, empty, px, py, (v >> 31) != 0);
-  }
-  flush(cur_key, end);
-}
-
+// (Round 6, run O: this walk at THREE waves per SIMD -- 168 registers, x / zz / zzz of the accumulator in LDS through ZzLds, no
+// row prefetch, `msm_accumulate28w3_kernel` of commit 2a07047 -- measured 4.7 % slower per launch and 3.7 % per proof in
+// flight, profiles/r06_runO_g1_three_waves.txt: a third wave does not take the slots the relay of two leaves.)
 // Same contract as msm_accumulate_kernel<Fp<P>, false>; `bases` holds UNPACKED rows (Affine28U): the plain segment walk of
 // rounds 2-4 -- the row of the next entry prefetched into registers, a finished run flushed where it ends.
 //

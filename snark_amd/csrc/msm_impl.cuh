@@ -1694,15 +1694,6 @@ static void msm_accumulate_phase(ark355_ctx* ctx, const MsmSort& s, MsmBuckets& 
                b.head_key.as<uint32_t>(), msm_slots28<P, 4>(b, p.total_buckets, 2), b.tail_key.as<uint32_t>(), b.seg_len);
   } else if (fmt == 1) {
     using P = typename F::Params;
-#if ARK_G1_W3
-    if (Fp28<P>::N > 12) {
-      ARK_LAUNCH((msm_accumulate28w3_kernel<P>), dim3((segs + acc_t - 1) / acc_t), dim3(acc_t), (ZzLds<P, ARK_G1_W3_VALUES>::bytes(acc_t)), stream,
-                 reinterpret_cast<const Affine28U<P>*>(d_bases), s.sorted_keys.as<uint32_t>(),
-                 s.sorted_vals.as<uint32_t>(), s.total.as<uint32_t>(), s.offsets.as<uint32_t>(),
-                 s.counts.as<uint32_t>(), msm_slots28<P, 4>(b, p.total_buckets, 0), msm_slots28<P, 4>(b, p.total_buckets, 1),
-                 b.head_key.as<uint32_t>(), msm_slots28<P, 4>(b, p.total_buckets, 2), b.tail_key.as<uint32_t>(), b.seg_len);
-    } else
-#endif
     ARK_LAUNCH((msm_accumulate28_kernel<P>), dim3((segs + acc_t - 1) / acc_t), dim3(acc_t), 0, stream,
                reinterpret_cast<const Affine28U<P>*>(d_bases), s.sorted_keys.as<uint32_t>(),
                s.sorted_vals.as<uint32_t>(), s.total.as<uint32_t>(), s.offsets.as<uint32_t>(),
