@@ -288,16 +288,22 @@ msm_digits_kernel(const Fr* __restrict__ scalars, uint32_t n, int mont, uint32_t
 // 0.17 ms for the 2^17..2^18-entry tables of the two-level sort.)
 constexpr uint32_t SCAN_THREADS = 1024;
 constexpr uint32_t SCAN_EPT = 16;
+// Tables of more than SCAN_SPLIT_MIN counters (2^19 buckets at c = 20; the first sort level of long vectors) are cut into spans of
+// whole tiles, one workgroup each: this kernel scans its span from zero and leaves the span's total in span_total[blockIdx.x],
+// scan_add_spans_kernel adds the totals of the spans in front (round 6: one workgroup took 144 us per 2^19-counter table, 0.5 ms
+// per proof at c = 20 -- profiles/r06_runM_c20_fixed_cost.txt).  span = 0: one workgroup, the whole table.
 static __global__ void __launch_bounds__(SCAN_THREADS)
 scan_exclusive_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, uint32_t m,
-                      uint32_t* __restrict__ total) {
+                      uint32_t* __restrict__ total, uint32_t span, uint32_t* __restrict__ span_total) {
   __shared__ uint32_t wave_tot[SCAN_THREADS / 64];
   __shared__ uint32_t carry_s;
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   if (tid == 0) carry_s = 0;
   __syncthreads();
   constexpr uint32_t TILE = SCAN_THREADS * SCAN_EPT;
-  for (uint64_t base = 0; base < m; base += TILE) {
+  const uint64_t lo = span ? (uint64_t)blockIdx.x * span : 0;
+  const uint64_t hi = span ? ((lo + span < m) ? lo + span : (uint64_t)m) : (uint64_t)m;
+  for (uint64_t base = lo; base < hi; base += TILE) {
     // thread t owns SCAN_EPT consecutive counters: four aligned 16-byte pieces
     uint32_t v[SCAN_EPT];
     const uint64_t first = base + (uint64_t)tid * SCAN_EPT;
@@ -356,7 +362,60 @@ scan_exclusive_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ ou
     if (tid == 0) carry_s += tile_total;
     __syncthreads();
   }
-  if (tid == 0 && total) *total = carry_s;
+  if (tid == 0) {
+    if (span) span_total[blockIdx.x] = carry_s;
+    else if (total) *total = carry_s;
+  }
+}
+#if defined(ARK_EMUL)
+constexpr uint32_t SCAN_SPLIT_MIN = SCAN_THREADS * SCAN_EPT;           // (the CPU tier reaches 2^16 buckets at most: split from one tile on, so that it runs this path)
+#else
+constexpr uint32_t SCAN_SPLIT_MIN = 4 * SCAN_THREADS * SCAN_EPT;       // 65 536 counters
+#endif
+constexpr uint32_t SCAN_MAX_SPANS = 256;
+static __global__ void __launch_bounds__(SCAN_THREADS)
+scan_add_spans_kernel(uint32_t* __restrict__ out, uint32_t m, uint32_t* __restrict__ total, uint32_t span,
+                      const uint32_t* __restrict__ span_total, uint32_t spans) {
+  __shared__ uint32_t off_s;
+  if (threadIdx.x == 0) {
+    uint32_t o = 0;
+    for (uint32_t g = 0; g < blockIdx.x; g++) o += span_total[g];
+    off_s = o;
+    if (blockIdx.x + 1 == spans && total) *total = o + span_total[blockIdx.x];
+  }
+  __syncthreads();
+  const uint32_t off = off_s;
+  if (off == 0) return;
+  const uint64_t lo = (uint64_t)blockIdx.x * span;
+  const uint64_t hi = (lo + span < m) ? lo + span : (uint64_t)m;
+  for (uint64_t i = lo + 4ull * threadIdx.x; i < hi; i += 4ull * SCAN_THREADS) {       // span and lo are multiples of the tile: 16-byte aligned
+    if (i + 3 < hi) {
+      uint4 t = *reinterpret_cast<uint4*>(out + i);
+      t.x += off; t.y += off; t.z += off; t.w += off;
+      *reinterpret_cast<uint4*>(out + i) = t;
+    } else {
+      for (uint64_t k = i; k < hi; k++) out[k] += off;
+    }
+  }
+}
+// exclusive scan of m counters on `stream`; *total (may be null) = their sum.  aux: SCAN_MAX_SPANS words of scratch.
+static inline void scan_exclusive(hipStream_t stream, const uint32_t* in, uint32_t* out, uint32_t m, uint32_t* total, DevBuf& aux) {
+  constexpr uint32_t TILE = SCAN_THREADS * SCAN_EPT;
+  if (m <= SCAN_SPLIT_MIN) {
+    ARK_LAUNCH(scan_exclusive_kernel, dim3(1), dim3(SCAN_THREADS), 0, stream, in, out, m, total, 0u, (uint32_t*)nullptr);
+    ARK_CHECK_LAUNCH();
+    return;
+  }
+  uint32_t tiles = (m + TILE - 1) / TILE;
+  uint32_t tiles_per_span = (tiles + SCAN_MAX_SPANS - 1) / SCAN_MAX_SPANS;
+  if (tiles_per_span < 1) tiles_per_span = 1;
+  const uint32_t span = tiles_per_span * TILE;
+  const uint32_t spans = (m + span - 1) / span;
+  aux.ensure((size_t)SCAN_MAX_SPANS * 4);
+  ARK_LAUNCH(scan_exclusive_kernel, dim3(spans), dim3(SCAN_THREADS), 0, stream, in, out, m, (uint32_t*)nullptr, span, aux.as<uint32_t>());
+  ARK_CHECK_LAUNCH();
+  ARK_LAUNCH(scan_add_spans_kernel, dim3(spans), dim3(SCAN_THREADS), 0, stream, out, m, total, span, (const uint32_t*)aux.as<uint32_t>(), spans);
+  ARK_CHECK_LAUNCH();
 }
 
 // ---- K3: scatter (counting sort) ----------------------------------------------------------------------
@@ -1467,7 +1526,7 @@ static inline void fill_bytes(FillBatch* fb, void* p, uint8_t v, size_t bytes, h
 // Scratch for one MSM "sort" (shared by several accumulations over the same scalars).
 struct MsmSort {
   MsmPlan plan;
-  DevBuf keys, vals, counts, offsets, cursor, sorted_keys, sorted_vals, total, hist, hist_scanned;
+  DevBuf keys, vals, counts, offsets, cursor, sorted_keys, sorted_vals, total, hist, hist_scanned, scan_aux;
 };
 
 // Plan one sort (window size, buffer sizes) and clear its counters -- through `fb` when the caller batches the fills of
@@ -1518,9 +1577,7 @@ static void msm_sort_run(ark355_ctx* ctx, MsmSort& s, const void* d_scalars, uin
                mont, p.c, p.windows, msm_digit_flags(p), stride, s.keys.as<uint32_t>(), s.vals.as<uint32_t>(),
                s.counts.as<uint32_t>());
     ARK_CHECK_LAUNCH();
-    ARK_LAUNCH(scan_exclusive_kernel, dim3(1), dim3(SCAN_THREADS), 0, stream, s.counts.as<uint32_t>(),
-               s.offsets.as<uint32_t>(), p.total_buckets, s.total.as<uint32_t>());
-    ARK_CHECK_LAUNCH();
+    scan_exclusive(stream, s.counts.as<uint32_t>(), s.offsets.as<uint32_t>(), p.total_buckets, s.total.as<uint32_t>(), s.scan_aux);
     const uint32_t grid_e = (uint32_t)((entries + MSM_THREADS - 1) / MSM_THREADS);
     ARK_LAUNCH(msm_scatter_kernel, dim3(grid_e), dim3(MSM_THREADS), 0, stream, s.keys.as<uint32_t>(),
                s.vals.as<uint32_t>(), entries, s.offsets.as<uint32_t>(), s.cursor.as<uint32_t>(),
@@ -1538,9 +1595,7 @@ static void msm_sort_run(ark355_ctx* ctx, MsmSort& s, const void* d_scalars, uin
              mont, p.c, p.windows, msm_digit_flags(p), stride, bins, s.hist.as<uint32_t>());
   ARK_CHECK_LAUNCH();
   ARK_REQUIRE(hist_elems < (1ull << 31), ARK355_EINVAL, "sort histogram too large");
-  ARK_LAUNCH(scan_exclusive_kernel, dim3(1), dim3(SCAN_THREADS), 0, stream, s.hist.as<uint32_t>(),
-             s.hist_scanned.as<uint32_t>(), (uint32_t)hist_elems, s.total.as<uint32_t>());
-  ARK_CHECK_LAUNCH();
+  scan_exclusive(stream, s.hist.as<uint32_t>(), s.hist_scanned.as<uint32_t>(), (uint32_t)hist_elems, s.total.as<uint32_t>(), s.scan_aux);
   ARK_LAUNCH((sort_hi_scatter_kernel<Fr>), dim3(grid1), dim3(SORT_HI_THREADS), 0, stream, (const Fr*)d_scalars,
              (uint32_t)n, mont, p.c, p.windows, msm_digit_flags(p), stride, bins, s.hist_scanned.as<uint32_t>(),
              s.keys.as<uint32_t>(), s.vals.as<uint32_t>());
@@ -1551,9 +1606,7 @@ static void msm_sort_run(ark355_ctx* ctx, MsmSort& s, const void* d_scalars, uin
              s.vals.as<uint32_t>(), s.total.as<uint32_t>(), s.counts.as<uint32_t>(), s.offsets.as<uint32_t>(),
              s.cursor.as<uint32_t>(), s.sorted_keys.as<uint32_t>(), s.sorted_vals.as<uint32_t>());
   ARK_CHECK_LAUNCH();
-  ARK_LAUNCH(scan_exclusive_kernel, dim3(1), dim3(SCAN_THREADS), 0, stream, s.counts.as<uint32_t>(),
-             s.offsets.as<uint32_t>(), p.total_buckets, s.total.as<uint32_t>());
-  ARK_CHECK_LAUNCH();
+  scan_exclusive(stream, s.counts.as<uint32_t>(), s.offsets.as<uint32_t>(), p.total_buckets, s.total.as<uint32_t>(), s.scan_aux);
   ARK_LAUNCH((sort_lo_kernel<true>), dim3(grid2), dim3(MSM_THREADS), 0, stream, s.keys.as<uint32_t>(),
              s.vals.as<uint32_t>(), s.total.as<uint32_t>(), s.counts.as<uint32_t>(), s.offsets.as<uint32_t>(),
              s.cursor.as<uint32_t>(), s.sorted_keys.as<uint32_t>(), s.sorted_vals.as<uint32_t>());
