@@ -218,7 +218,8 @@ ARK_HD_NOINLINE typename Fp28<P>::Vec one28_ni() {
 // spills happened to sit in the flush path.  zz and zzz are each read twice and written once per addition, so they are the
 // cheapest state to keep elsewhere, and so are x and y (the new x is dead during the fused Y3 pass, where the pressure peaks;
 // with all four there the listing shows 5 scratch loads + 4 stores per addition): 4 x 4 b128 slots per lane (256 B; 64 KiB for
-// 256 lanes, two workgroups per CU), every lane on its own consecutive 16-byte column, i.e. conflict-free: 32 ds_read_b128 +
+// 256 lanes, two workgroups per CU), every lane on its own consecutive 16-byte column (hardware counters, run Q: bank-conflict cycles 5.7 % of the
+// LDS-active cycles, LDS waits 0.06 % of the wave cycles): 32 ds_read_b128 +
 // 16 ds_write_b128 per addition of ~7 600 instructions.
 template <class P>
 struct ZzRegs {
