@@ -519,7 +519,7 @@ __global__ void __launch_bounds__(SORT_HI_THREADS)
 sort_hi_scatter_kernel(const Fr* __restrict__ scalars, uint32_t n, int mont, uint32_t c, uint32_t windows,
                        int precomp, uint32_t table_stride, uint32_t bins,
                        const uint32_t* __restrict__ hist_scanned /* [bin][gridDim.x], exclusive */,
-                       uint32_t* __restrict__ tmp_keys, uint32_t* __restrict__ tmp_vals) {
+                       uint2* __restrict__ tmp /* (key, value) pairs */) {
   __shared__ uint32_t lds[SORT_MAX_BINS];
   for (uint32_t b = threadIdx.x; b < bins; b += blockDim.x) lds[b] = hist_scanned[(size_t)b * gridDim.x + blockIdx.x];
   __syncthreads();
@@ -530,8 +530,7 @@ sort_hi_scatter_kernel(const Fr* __restrict__ scalars, uint32_t n, int mont, uin
       msm_for_each_digit<Fr>(scalars[i], mont, i, n, c, windows, precomp, table_stride,
                              [&](uint32_t, uint32_t key, uint32_t val) {
                                const uint32_t pos = atomicAdd(&lds[key >> SORT_LO_BITS], 1u);
-                               tmp_keys[pos] = key;
-                               tmp_vals[pos] = val;
+                               tmp[pos] = make_uint2(key, val);
                              });
     }
   }
@@ -540,7 +539,7 @@ sort_hi_scatter_kernel(const Fr* __restrict__ scalars, uint32_t n, int mont, uin
 // level 2, shared by the histogram (SCATTER = false) and the scatter pass
 template <bool SCATTER>
 static __global__ void __launch_bounds__(MSM_THREADS)
-sort_lo_kernel(const uint32_t* __restrict__ tmp_keys, const uint32_t* __restrict__ tmp_vals,
+sort_lo_kernel(const uint2* __restrict__ tmp /* (key, value) pairs grouped by bin */,
                const uint32_t* __restrict__ total_ptr, uint32_t* __restrict__ counts,
                const uint32_t* __restrict__ offsets, uint32_t* __restrict__ cursor,
                uint32_t* __restrict__ sorted_keys, uint32_t* __restrict__ sorted_vals) {
@@ -555,10 +554,15 @@ sort_lo_kernel(const uint32_t* __restrict__ tmp_keys, const uint32_t* __restrict
 #pragma unroll
   for (uint32_t j = 0; j < SORT_EPT; j++) {
     const uint32_t e = first + j * MSM_THREADS + threadIdx.x;
-    key[j] = (e < last) ? tmp_keys[e] : MSM_INVALID;
-    if (SCATTER) val[j] = (e < last) ? tmp_vals[e] : 0u;
+    if (SCATTER) {
+      const uint2 t = (e < last) ? tmp[e] : make_uint2(MSM_INVALID, 0u);
+      key[j] = t.x;
+      val[j] = t.y;
+    } else {
+      key[j] = (e < last) ? tmp[e].x : MSM_INVALID;
+    }
   }
-  const uint32_t h0 = tmp_keys[first] >> SORT_LO_BITS, h1 = tmp_keys[last - 1] >> SORT_LO_BITS;
+  const uint32_t h0 = tmp[first].x >> SORT_LO_BITS, h1 = tmp[last - 1].x >> SORT_LO_BITS;
   for (uint32_t hb = h0; hb <= h1; hb++) {                   // entries are grouped by bin: usually 1-2 rounds
     for (uint32_t t = threadIdx.x; t < SORT_LO; t += blockDim.x) cnt[t] = 0;
     __syncthreads();
@@ -1543,8 +1547,11 @@ static void msm_sort_plan(ark355_ctx* ctx, MsmSort& s, uint64_t n, hipStream_t s
   const MsmPlan& p = s.plan;
   const uint64_t entries = (uint64_t)p.windows * n;
   ARK_REQUIRE(entries < (1ull << 31), ARK355_EINVAL, "MSM entry count must be < 2^31");
-  s.keys.ensure(entries * 4);
-  s.vals.ensure(entries * 4);
+  // two-level sort: level 1 writes (key, value) PAIRS into `keys` (one 8-byte store per entry instead of two 4-byte stores into
+  // two arrays: round 6); the one-pass fallback keeps separate arrays
+  const bool two_level = (p.total_buckets + SORT_LO - 1) / SORT_LO <= SORT_MAX_BINS;
+  s.keys.ensure(entries * (two_level ? 8 : 4));
+  if (!two_level) s.vals.ensure(entries * 4);
   s.sorted_keys.ensure(entries * 4 + 16);
   s.sorted_vals.ensure(entries * 4 + 16);
   s.counts.ensure((size_t)p.total_buckets * 4);
@@ -1598,17 +1605,15 @@ static void msm_sort_run(ark355_ctx* ctx, MsmSort& s, const void* d_scalars, uin
   scan_exclusive(stream, s.hist.as<uint32_t>(), s.hist_scanned.as<uint32_t>(), (uint32_t)hist_elems, s.total.as<uint32_t>(), s.scan_aux);
   ARK_LAUNCH((sort_hi_scatter_kernel<Fr>), dim3(grid1), dim3(SORT_HI_THREADS), 0, stream, (const Fr*)d_scalars,
              (uint32_t)n, mont, p.c, p.windows, msm_digit_flags(p), stride, bins, s.hist_scanned.as<uint32_t>(),
-             s.keys.as<uint32_t>(), s.vals.as<uint32_t>());
+             s.keys.as<uint2>());
   ARK_CHECK_LAUNCH();
   // level 2: bucket histogram, bucket offsets, final placement
   const uint32_t grid2 = (uint32_t)((entries + SORT_TILE - 1) / SORT_TILE);
-  ARK_LAUNCH((sort_lo_kernel<false>), dim3(grid2), dim3(MSM_THREADS), 0, stream, s.keys.as<uint32_t>(),
-             s.vals.as<uint32_t>(), s.total.as<uint32_t>(), s.counts.as<uint32_t>(), s.offsets.as<uint32_t>(),
+  ARK_LAUNCH((sort_lo_kernel<false>), dim3(grid2), dim3(MSM_THREADS), 0, stream, (const uint2*)s.keys.as<uint2>(), s.total.as<uint32_t>(), s.counts.as<uint32_t>(), s.offsets.as<uint32_t>(),
              s.cursor.as<uint32_t>(), s.sorted_keys.as<uint32_t>(), s.sorted_vals.as<uint32_t>());
   ARK_CHECK_LAUNCH();
   scan_exclusive(stream, s.counts.as<uint32_t>(), s.offsets.as<uint32_t>(), p.total_buckets, s.total.as<uint32_t>(), s.scan_aux);
-  ARK_LAUNCH((sort_lo_kernel<true>), dim3(grid2), dim3(MSM_THREADS), 0, stream, s.keys.as<uint32_t>(),
-             s.vals.as<uint32_t>(), s.total.as<uint32_t>(), s.counts.as<uint32_t>(), s.offsets.as<uint32_t>(),
+  ARK_LAUNCH((sort_lo_kernel<true>), dim3(grid2), dim3(MSM_THREADS), 0, stream, (const uint2*)s.keys.as<uint2>(), s.total.as<uint32_t>(), s.counts.as<uint32_t>(), s.offsets.as<uint32_t>(),
              s.cursor.as<uint32_t>(), s.sorted_keys.as<uint32_t>(), s.sorted_vals.as<uint32_t>());
   ARK_CHECK_LAUNCH();
 }

@@ -37,6 +37,10 @@ struct uint4 {
   unsigned x, y, z, w;
 };
 static inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) { return uint4{x, y, z, w}; }
+struct alignas(8) uint2 {
+  unsigned x, y;
+};
+static inline uint2 make_uint2(unsigned x, unsigned y) { return uint2{x, y}; }
 
 namespace emu {
 enum State { RUN = 0, WAVE_WAIT = 1, BLOCK_WAIT = 2, DONE = 3 };
