@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 6, GPU run E (evidence of the tree it is run on; one box).  tools/gpu_r6e.sh [tests] [bench] [profiles] [sweeps] [rccl]
-# (no argument: everything).  Outputs under gpurun_out/r6r/; the summaries that are to be judged are copied to profiles/ by hand.
-R=$PWD; O=$R/gpurun_out/r6r; mkdir -p $O
+# (no argument: everything).  Outputs under gpurun_out/r6t/; the summaries that are to be judged are copied to profiles/ by hand.
+R=$PWD; O=$R/gpurun_out/r6t; mkdir -p $O
 want() { [ $# -eq 0 ] && return 0; for a in "${ARGS[@]}"; do [ "$a" = "$1" ] && return 0; done; [ ${#ARGS[@]} -eq 0 ]; }
 ARGS=("$@")
 python tools/gpu_telemetry.py > $O/telemetry_start.txt 2>&1
@@ -18,7 +18,7 @@ if want bench; then
   python - <<'PY'
 import json
 try:
-    d = json.load(open("gpurun_out/r6r/bench_default.json"))
+    d = json.load(open("gpurun_out/r6t/bench_default.json"))
     print("driver cmd: ms_per_step %.3f value %.0f parity %s" % (d["ms_per_step"], d["value"], d["parity"]))
     print("box", json.dumps(d.get("box"))[:900])
     print("alu", json.dumps({k: v for k, v in d["roofline"]["alu"].items() if k in ("achieved", "peak", "frac", "mads_per_add")}))
@@ -43,7 +43,7 @@ if want profiles; then
     echo "pmc fetch $key rc=$?" >> $O/status.txt
     ARK355_SCHED=0 timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc/prof_write -o w -- python $R/bench.py --profile-run --no-check --inflight 1 --steps 1 --warmup 0 "$@" > $O/pmc_write.log 2>&1
     echo "pmc write $key rc=$?" >> $O/status.txt
-    (cd $R && python tools/pmc_summary.py --dir $O/pmc --json $O/pmc_latest.json --merge --workload "$key" --recorded "round 6 run R, final library" >> $O/pmc_summary.txt 2>&1)
+    (cd $R && python tools/pmc_summary.py --dir $O/pmc --json $O/pmc_latest.json --merge --workload "$key" --recorded "round 6 run T, final library" >> $O/pmc_summary.txt 2>&1)
   }
   pmc "bls12_381:n=1048576"
   pmc "bn254:n=1048576" --curve bn254
@@ -63,7 +63,7 @@ if want sweeps; then
 import json, sys
 tag = sys.argv[1]
 try:
-    d = json.load(open("gpurun_out/r6r/%s.json" % tag))
+    d = json.load(open("gpurun_out/r6t/%s.json" % tag))
     lat = {k: round(v, 2) for k, v in (d.get("latency") or {}).items() if k.endswith("_ms")}
     box = d.get("box") or {}
     print("%-18s %8.3f ms/step  %6.2f M/s  cycles/constraint %s  at_ref_clock %s ms  lat %s" % (tag, d["ms_per_step"], d["value"] / 1e6, box.get("gfx_cycles_per_constraint"), box.get("ms_per_step_at_ref_clock"), lat))
@@ -81,7 +81,7 @@ PY
   timeout 100 python tools/shard_rank_bench.py --log-n 22 --world 8 --ranks 0,7 --wm dist --steps 8 > $O/shard_rank_22.json 2> $O/shard_rank.log; echo "shard rc=$?" >> $O/status.txt
   python - <<'PY'
 import json
-for l in open("gpurun_out/r6r/shard_rank_22.json"):
+for l in open("gpurun_out/r6t/shard_rank_22.json"):
     try:
         d = json.loads(l); print("rank path shard", d["shard"], "median", d["ms_median"], "acc", d["accumulate_ms"])
     except Exception: pass
