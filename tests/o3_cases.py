@@ -78,7 +78,7 @@ def check_equation(lib, ctx, C, inst, pk, proofs, python_pairing=False):
 
 
 def check_instance(lib, ctx, C, inst, rs_pairs, batch=0, inflight=4, sharded=False, equation=True, python_pairing=False,
-                   timing=None):
+                   timing=None, self_exchange=True):
     """Key from the oracle's generator; `ark355_prove` (and, with `sharded`, `ark355_prove_sharded` over the real RCCL at
     world size 1 with both exchange modes; with `batch`, `ark355_prove_batch`) byte-compared with `cbase.prove`; with
     `equation` every proof is also put through the Groth16 equation (check_equation)."""
@@ -110,7 +110,7 @@ def check_instance(lib, ctx, C, inst, rs_pairs, batch=0, inflight=4, sharded=Fal
                     got_s = lib.prove_sharded(ctx, comm, pkh, rh, zb, len(z), Z.fr_canon(C, r_), Z.fr_canon(C, s_), sizes,
                                               mode=mode)
                     assert got_s == exp, (C.name, n, "ark355_prove_sharded vs oracle/c", mode)
-        if sharded:
+        if sharded and self_exchange:
             # Policy RCCL_SELF: the key loaded AGAIN, now in the layout of the distributed witness map, whose three all-to-all
             # exchanges run as grouped ncclSend / ncclRecv pairs of rank 0 with itself, and the bucket ring makes one step with
             # itself per MSM -- the point-to-point calls of an 8-GPU proof on the one GPU there is, compared with the ORACLE's

@@ -89,11 +89,13 @@ def test_strided_window_tables_on_the_emulator(emul_lib, emul_ctx, emul_policy, 
         a = np.frombuffer(b, dtype=np.uint8).copy()
         return a.ctypes.data, a
 
-    O.check_resident_msm(emul_lib, emul_ctx, BLS12_381, 1, 1100, to_dev, seed=21)     # c = 8: 32 windows
+    # c = 8: 32 windows (stride 16: a shorter vector at c = 4 -- 64 windows, 4 table blocks, 16 bucket sets -- the plain sums over
+    # 16 sets of 128 buckets are what takes the emulator's time)
+    O.check_resident_msm(emul_lib, emul_ctx, BLS12_381, 1, 1100 if stride != "16" else 300, to_dev, seed=21)
     O.check_resident_msm(emul_lib, emul_ctx, BN254, 2, 150, to_dev, seed=22)          # c = 4: 64 windows
     if stride == "3":
         O.check_instance(emul_lib, emul_ctx, BLS12_381, S.mulchain_csr(BLS12_381.r, 140), [(5, 7)], sharded=True,
-                         equation=False)
+                         equation=False, self_exchange=False)     # (the self exchange: test_large_size_checks_on_the_emulator)
 
 
 def test_table_budget_picks_a_stride_or_reports_enomem(emul_lib, emul_ctx, emul_policy):
