@@ -4,7 +4,7 @@
 namespace emu {
 dim3 g_threadIdx, g_blockIdx, g_blockDim, g_gridDim;
 Thread* g_cur = nullptr;
-ucontext_t g_sched;
+void* g_sched_sp = nullptr;
 uint64_t g_xchg[64];
 unsigned char* g_dyn_smem = nullptr;
 PairBox g_pairbox[1024];
@@ -13,22 +13,63 @@ static const std::function<void()>* g_body = nullptr;
 static const size_t STACK = 1 << 20;
 static std::vector<char*> g_stacks;
 
+// Register-only context switch (System V x86-64): push the callee-saved registers, swap stack pointers, pop, return.
+// No signal mask, no floating-point environment: the coroutines are plain integer / SSE code of one thread.
+#if !defined(__x86_64__)
+#error "the HIP emulator's context switch is written for x86-64"
+#endif
+extern "C" void emu_switch(void** save_sp, void* load_sp);
+asm(R"(
+    .text
+    .globl emu_switch
+    .type emu_switch, @function
+emu_switch:
+    pushq %rbp
+    pushq %rbx
+    pushq %r12
+    pushq %r13
+    pushq %r14
+    pushq %r15
+    movq %rsp, (%rdi)
+    movq %rsi, %rsp
+    popq %r15
+    popq %r14
+    popq %r13
+    popq %r12
+    popq %rbx
+    popq %rbp
+    ret
+    .size emu_switch, .-emu_switch
+)");
+
 void yield(int st) {
   Thread* me = g_cur;
   me->state = st;
-  swapcontext(&me->ctx, &g_sched);
+  emu_switch(&me->sp, g_sched_sp);
 }
 
 static void trampoline() {
   (*g_body)();
   g_cur->state = DONE;
-  swapcontext(&g_cur->ctx, &g_sched);
+  emu_switch(&g_cur->sp, g_sched_sp);
+  abort();                               // a finished coroutine is never resumed
 }
 
 static void resume(Thread& t) {
   g_cur = &t;
   g_threadIdx = t.tid;
-  swapcontext(&g_sched, &t.ctx);
+  emu_switch(&g_sched_sp, t.sp);
+}
+
+// a fresh coroutine: six zeroed callee-saved registers, then the address emu_switch "returns" to; the slot above it is where a
+// caller's return address would sit, so that the entry sees the stack alignment the ABI promises (rsp = 16 k + 8)
+static void* fresh_stack(char* stack, size_t size) {
+  uintptr_t top = ((uintptr_t)stack + size) & ~(uintptr_t)15;
+  void** sp = reinterpret_cast<void**>(top);
+  *--sp = nullptr;                                  // (fake return address of the trampoline)
+  *--sp = reinterpret_cast<void*>(&trampoline);
+  for (int i = 0; i < 6; i++) *--sp = nullptr;      // rbp rbx r12 r13 r14 r15
+  return sp;
 }
 
 void launch(dim3 grid, dim3 block, size_t smem, const std::function<void()>& body) {
@@ -50,11 +91,7 @@ void launch(dim3 grid, dim3 block, size_t smem, const std::function<void()>& bod
           for (unsigned ty = 0; ty < block.y; ty++)
             for (unsigned tx = 0; tx < block.x; tx++, k++) {
               Thread& t = th[k];
-              getcontext(&t.ctx);
-              t.ctx.uc_stack.ss_sp = g_stacks[k];
-              t.ctx.uc_stack.ss_size = STACK;
-              t.ctx.uc_link = nullptr;
-              makecontext(&t.ctx, trampoline, 0);
+              t.sp = fresh_stack(g_stacks[k], STACK);
               t.state = RUN;
               t.tid = dim3(tx, ty, tz);
               g_pairbox[k % 1024] = PairBox();

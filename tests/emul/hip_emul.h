@@ -6,7 +6,8 @@
 // libark355.so (hipcc, gfx950) and fails loudly without it.  tests/emul/build_emul.py compiles the
 // same sources with g++ -DARK_EMUL into tests/emul/libark355_emul.so, which only tests open.
 //
-// Model: blocks run one after another; the threads of a block are ucontext coroutines; a wave is
+// Model: blocks run one after another; the threads of a block are coroutines (a register-only x86-64 context switch: glibc's
+// swapcontext makes a sigprocmask system call per switch, a third of the CPU tier's time until round 6); a wave is
 // 64 consecutive threads.  __syncthreads / wave shuffles yield to a scheduler that releases a
 // barrier once every live thread of the block / wave has arrived.
 #pragma once
@@ -14,7 +15,6 @@
 #include <stdlib.h>
 #include <string.h>
 #include <stdio.h>
-#include <ucontext.h>
 #include <functional>
 #include <vector>
 #include <chrono>
@@ -45,13 +45,13 @@ static inline uint2 make_uint2(unsigned x, unsigned y) { return uint2{x, y}; }
 namespace emu {
 enum State { RUN = 0, WAVE_WAIT = 1, BLOCK_WAIT = 2, DONE = 3 };
 struct Thread {
-  ucontext_t ctx;
+  void* sp;          // saved stack pointer of the coroutine (callee-saved registers are on its stack)
   int state;
   dim3 tid;
 };
 extern dim3 g_threadIdx, g_blockIdx, g_blockDim, g_gridDim;
 extern Thread* g_cur;
-extern ucontext_t g_sched;
+extern void* g_sched_sp;
 extern uint64_t g_xchg[64];
 extern unsigned char* g_dyn_smem;
 // mailbox of the lane-pair exchange (models a DPP quad_perm [1,0,3,2] move): 2-deep ring indexed by sequence parity
